@@ -1,0 +1,83 @@
+"""Shared helpers for the parity tests (bit-exact views, fixture decoding, ULP distance)."""
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLDEN = ROOT / 'tests' / 'golden'
+DTYPES = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
+
+
+def from_raw(a: np.ndarray, dtype: torch.dtype) -> torch.Tensor:
+    """Inverse of gen_golden.raw(): uint16 words -> bf16/fp16 tensor, float32 stays."""
+    if dtype in (torch.bfloat16, torch.float16):
+        return torch.from_numpy(a.astype(np.uint16).view(np.int16).copy()).view(dtype)
+    return torch.from_numpy(a.astype(np.float32).copy())
+
+
+def bits(t: torch.Tensor) -> torch.Tensor:
+    """Integer view for bit-exact comparison."""
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.float32:
+        return t.view(torch.int32)
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.view(torch.int16)
+    return t
+
+
+def assert_bit_equal(a: torch.Tensor, b: torch.Tensor, what: str = '', nan_equal: bool = True):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
+    ia, ib = bits(a), bits(b)
+    neq = ia != ib
+    if nan_equal and a.is_floating_point():
+        neq &= ~(torch.isnan(a) & torch.isnan(b))        # NaN payload/sign is not part of parity
+    if neq.any():
+        idx = neq.flatten().nonzero().flatten()[:8]
+        raise AssertionError(f'{what}: {int(neq.sum())} of {a.numel()} differ, first at {idx.tolist()}: '
+                             f'{a.flatten()[idx].tolist()} vs {b.flatten()[idx].tolist()}')
+
+
+def ordered(t: torch.Tensor) -> torch.Tensor:
+    """Map floats to integers so that adjacent representable values differ by 1."""
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.float32:
+        i = t.view(torch.int32).to(torch.int64)
+        return torch.where(i < 0, -(i & 0x7fffffff), i)
+    i = t.view(torch.int16).to(torch.int64)
+    return torch.where(i < 0, -(i & 0x7fff), i)
+
+
+def ulp_distance(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """|a-b| in units of representable steps of the common dtype (NaN==NaN -> 0)."""
+    d = (ordered(a) - ordered(b)).abs()
+    both_nan = torch.isnan(a.detach().cpu()) & torch.isnan(b.detach().cpu())
+    return torch.where(both_nan, torch.zeros_like(d), d)
+
+
+def load_tables() -> dict:
+    """The built-in quantization tables as float64 numpy arrays (the product's own data file)."""
+    with np.load(ROOT / 'fewbit_amd' / 'data' / 'builtin.npz') as z:
+        return {k: z[k].copy() for k in z.files}
+
+
+def forward_value_ok(x: torch.Tensor, y: torch.Tensor, y_ref: torch.Tensor, tight: bool = False) -> torch.Tensor:
+    """Element-wise verdict for forward activation values (the only floating-point parity in the path).
+
+    The reference's forward values are ATen's (third-party: MKL vsCdfNorm for contiguous fp32, Sleef erf for
+    16-bit and strided inputs -- the two already disagree with each other by up to 5 fp32 steps for x>0 and by
+    the full cancellation noise of 1+erf(x/sqrt2) for x<0).  So the bar is stated on the shared formula
+    y = x*0.5*(1+erf(x*sqrt(1/2))) evaluated in fp32:
+      loose (vs ATen output):   |dy| <= max(1 step of the output dtype at y_ref, 2^-21 * |x|)
+      tight (vs the formula with a correctly rounded erf): |dy| <= max(1 step, 2^-24 * |x|)
+    2^-24*|x| is what ONE fp32 rounding step of erf costs after the *0.5x scaling.  Non-finite x are excluded
+    (ATen itself returns NaN for +inf on some paths); NaN must map to NaN.
+    """
+    xf, yf, rf = x.detach().cpu().double(), y.detach().cpu().double(), y_ref.detach().cpu().double()
+    step_ok = ulp_distance(y, y_ref) <= 1
+    scale = 2.0**-24 if tight else 2.0**-21
+    abs_ok = (yf - rf).abs() <= scale * xf.abs()
+    nan_ok = torch.isnan(xf) & torch.isnan(yf)
+    skip = torch.isinf(xf)
+    return step_ok | abs_ok | nan_ok | skip
