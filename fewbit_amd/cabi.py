@@ -1,0 +1,167 @@
+"""ctypes binding of the C-ABI library ``libfewbit_hip.so`` (include/fewbit_hip.h).
+
+This is the thin, torch-free-in-signature boundary the parity tests and ``bench.py`` drive directly:
+device pointers, sizes and a ``hipStream_t``.  There is no fallback: if the shared library is missing
+every call raises (the product never computes this path on the CPU).
+"""
+import ctypes
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+__all__ = [
+    'CONTINUOUS', 'STEPWISE1', 'LIB_PATH', 'lib', 'loaded', 'bitwidth', 'state_nbytes', 'quantize_forward',
+    'quantize_backward', 'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError',
+]
+
+import os
+
+# FEWBIT_HIP_LIB: kernel-tuning hook (an alternative build of the same library), not a fallback
+LIB_PATH = Path(os.environ.get('FEWBIT_HIP_LIB') or Path(__file__).resolve().with_name('libfewbit_hip.so'))
+
+# enum order of include/fewbit_hip.h
+CONTINUOUS = ('celu', 'elu', 'gelu', 'hardswish', 'logsigmoid', 'mish', 'selu', 'sigmoid', 'silu', 'softplus',
+              'softsign', 'tanh', 'tanhshrink', 'identity')
+STEPWISE1 = ('hardshrink', 'hardsigmoid', 'hardtanh', 'leaky_relu', 'relu', 'relu6', 'softshrink', 'threshold')
+DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+# every symbol include/fewbit_hip.h declares
+SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwidth', 'fewbit_hip_state_nbytes',
+           'fewbit_hip_quantize_forward', 'fewbit_hip_quantize_backward', 'fewbit_hip_stepwise1_forward',
+           'fewbit_hip_stepwise1_backward', 'fewbit_hip_pack_codes', 'fewbit_hip_unpack_codes')
+
+
+class FewbitHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise FewbitHipError(f'{LIB_PATH} is missing: build it with `make -C fewbit_amd/csrc` '
+                                 '(or `python -c "import __graft_entry__ as g; g.build()"`)')
+        L = ctypes.CDLL(str(LIB_PATH))
+        vp, sz, i32, dbl = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_double
+        L.fewbit_hip_abi_version.restype = i32
+        L.fewbit_hip_abi_version.argtypes = []
+        L.fewbit_hip_last_error.restype = ctypes.c_char_p
+        L.fewbit_hip_last_error.argtypes = []
+        L.fewbit_hip_bitwidth.restype = i32
+        L.fewbit_hip_bitwidth.argtypes = [i32]
+        L.fewbit_hip_state_nbytes.restype = sz
+        L.fewbit_hip_state_nbytes.argtypes = [sz, i32]
+        L.fewbit_hip_quantize_forward.restype = i32
+        L.fewbit_hip_quantize_forward.argtypes = [i32, i32, vp, vp, vp, sz, vp, i32, dbl, dbl, vp]
+        L.fewbit_hip_quantize_backward.restype = i32
+        L.fewbit_hip_quantize_backward.argtypes = [i32, vp, vp, vp, sz, vp, i32, vp]
+        L.fewbit_hip_stepwise1_forward.restype = i32
+        L.fewbit_hip_stepwise1_forward.argtypes = [i32, i32, vp, vp, vp, sz, dbl, dbl, vp]
+        L.fewbit_hip_stepwise1_backward.restype = i32
+        L.fewbit_hip_stepwise1_backward.argtypes = [i32, i32, vp, vp, vp, sz, dbl, vp]
+        L.fewbit_hip_pack_codes.restype = i32
+        L.fewbit_hip_pack_codes.argtypes = [vp, vp, sz, i32, vp]
+        L.fewbit_hip_unpack_codes.restype = i32
+        L.fewbit_hip_unpack_codes.argtypes = [vp, vp, sz, i32, vp]
+        _lib = L
+    return _lib
+
+
+def loaded() -> bool:
+    return _lib is not None
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise FewbitHipError(f'fewbit_hip error {rc}: {lib().fewbit_hip_last_error().decode()}')
+
+
+def _dev(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.device.type != 'cuda':
+        raise FewbitHipError(f'{what} must live on the GPU (got {t.device})')
+    if not t.is_contiguous():
+        raise FewbitHipError(f'{what} must be contiguous')
+    return t
+
+
+def _stream(stream: Optional[int]) -> int:
+    return torch.cuda.current_stream().cuda_stream if stream is None else stream
+
+
+def bitwidth(nlevels: int) -> int:
+    return lib().fewbit_hip_bitwidth(nlevels)
+
+
+def state_nbytes(n: int, nbits: int) -> int:
+    return lib().fewbit_hip_state_nbytes(n, nbits)
+
+
+def quantize_forward(fn: str, x: torch.Tensor, borders: torch.Tensor, p0: float = 0.0, p1: float = 0.0,
+                     out: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None,
+                     stream: Optional[int] = None):
+    """-> (y, state).  ``out=x`` runs in place like the reference op; ``borders`` are the inner borders."""
+    x, borders = _dev(x, 'x'), _dev(borders, 'borders')
+    if borders.dtype != x.dtype:
+        raise FewbitHipError(f'borders dtype {borders.dtype} != input dtype {x.dtype}')
+    k = bitwidth(borders.numel() + 1)
+    y = torch.empty_like(x) if out is None else _dev(out, 'out')
+    if state is None:
+        state = torch.empty(state_nbytes(x.numel(), k), dtype=torch.uint8, device=x.device)
+    _check(lib().fewbit_hip_quantize_forward(CONTINUOUS.index(fn), DTYPES[x.dtype], x.data_ptr(), y.data_ptr(),
+                                             state.data_ptr(), x.numel(), borders.data_ptr(), borders.numel(),
+                                             p0, p1, _stream(stream)))
+    return y, state
+
+
+def quantize_backward(gy: torch.Tensor, state: torch.Tensor, levels: torch.Tensor,
+                      out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    gy, state, levels = _dev(gy, 'gy'), _dev(state, 'state'), _dev(levels, 'levels')
+    if levels.dtype != gy.dtype:
+        raise FewbitHipError(f'levels dtype {levels.dtype} != grad dtype {gy.dtype}')
+    k = bitwidth(levels.numel())
+    if state.numel() < state_nbytes(gy.numel(), k):
+        raise FewbitHipError('state buffer too small')
+    gx = torch.empty_like(gy) if out is None else _dev(out, 'out')
+    _check(lib().fewbit_hip_quantize_backward(DTYPES[gy.dtype], gy.data_ptr(), state.data_ptr(), gx.data_ptr(),
+                                              gy.numel(), levels.data_ptr(), levels.numel(), _stream(stream)))
+    return gx
+
+
+def stepwise1_forward(fn: str, x: torch.Tensor, p0: float = 0.0, p1: float = 0.0,
+                      out: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None,
+                      stream: Optional[int] = None):
+    x = _dev(x, 'x')
+    y = torch.empty_like(x) if out is None else _dev(out, 'out')
+    if state is None:
+        state = torch.empty(state_nbytes(x.numel(), 1), dtype=torch.uint8, device=x.device)
+    _check(lib().fewbit_hip_stepwise1_forward(STEPWISE1.index(fn), DTYPES[x.dtype], x.data_ptr(), y.data_ptr(),
+                                              state.data_ptr(), x.numel(), p0, p1, _stream(stream)))
+    return y, state
+
+
+def stepwise1_backward(fn: str, gy: torch.Tensor, state: torch.Tensor, p0: float = 0.0,
+                       out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    gy, state = _dev(gy, 'gy'), _dev(state, 'state')
+    gx = torch.empty_like(gy) if out is None else _dev(out, 'out')
+    _check(lib().fewbit_hip_stepwise1_backward(STEPWISE1.index(fn), DTYPES[gy.dtype], gy.data_ptr(),
+                                               state.data_ptr(), gx.data_ptr(), gy.numel(), p0, _stream(stream)))
+    return gx
+
+
+def pack_codes(codes: torch.Tensor, nbits: int, stream: Optional[int] = None) -> torch.Tensor:
+    codes = _dev(codes, 'codes')
+    assert codes.dtype == torch.int32
+    state = torch.empty(state_nbytes(codes.numel(), nbits), dtype=torch.uint8, device=codes.device)
+    _check(lib().fewbit_hip_pack_codes(codes.data_ptr(), state.data_ptr(), codes.numel(), nbits, _stream(stream)))
+    return state
+
+
+def unpack_codes(state: torch.Tensor, n: int, nbits: int, stream: Optional[int] = None) -> torch.Tensor:
+    state = _dev(state, 'state')
+    codes = torch.empty(n, dtype=torch.int32, device=state.device)
+    _check(lib().fewbit_hip_unpack_codes(state.data_ptr(), codes.data_ptr(), n, nbits, _stream(stream)))
+    return codes

@@ -1,0 +1,364 @@
+// fewbit_device.h -- device-side building blocks shared by the gfx950 kernels.
+//
+// Written for CDNA4 only (wave64, v_cvt_pk_bf16_f32, DPP); there is no other target.
+// Vocabulary: a GROUP is 8 consecutive elements; its k-bit codes occupy exactly k bytes of the
+// packed state (fewbit/cpu/codec.h:33-57 in the reference), so groups are the unit of work.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fewbit_hip.h"
+
+namespace fewbit_hip {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+// occupancy the streaming kernels are built for: 8 waves per SIMD = 32 per CU, i.e. at most 64 VGPRs.
+// (One VGPR over and the hardware admits 7 blocks per CU; the 8th then runs as a second round that
+// nearly doubles the duration of a ~10 us kernel -- seen with per-wave timestamps.)
+constexpr int kWavesPerSimd = 8;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bits_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f32_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// ------------------------------------------------------------------ scalar element I/O
+template <int DT> struct Elem;
+
+template <> struct Elem<FEWBIT_F32> {
+    typedef float type;
+    static constexpr int kSize = 4;
+    static __device__ __forceinline__ float load(const void *p, size_t i) { return static_cast<const float *>(p)[i]; }
+    static __device__ __forceinline__ void store(void *p, size_t i, float v) { static_cast<float *>(p)[i] = v; }
+};
+
+template <> struct Elem<FEWBIT_F16> {
+    typedef _Float16 type;
+    static constexpr int kSize = 2;
+    static __device__ __forceinline__ float load(const void *p, size_t i) {
+        return static_cast<float>(static_cast<const _Float16 *>(p)[i]);
+    }
+    static __device__ __forceinline__ void store(void *p, size_t i, float v) {
+        static_cast<_Float16 *>(p)[i] = static_cast<_Float16>(v);  // v_cvt_f16_f32, RNE
+    }
+};
+
+template <> struct Elem<FEWBIT_BF16> {
+    typedef uint16_t type;
+    static constexpr int kSize = 2;
+    static __device__ __forceinline__ float load(const void *p, size_t i) {
+        return bits_f32(static_cast<uint32_t>(static_cast<const uint16_t *>(p)[i]) << 16);
+    }
+    static __device__ __forceinline__ void store(void *p, size_t i, float v) {
+        static_cast<__bf16 *>(p)[i] = static_cast<__bf16>(v);  // v_cvt_pk_bf16_f32, RNE
+    }
+};
+
+// ------------------------------------------------------------------ whole-group (8 element) I/O
+// 16-bit dtypes: one 16-byte access per lane, lane-contiguous -> each wave instruction moves 1 KiB
+// of contiguous memory.  fp32: two 16-byte accesses per lane (32-byte lane stride).
+// `Raw` is the group as loaded (4 or 8 VGPRs): the software pipeline prefetches the next tile in this
+// form and only unpacks to 8 floats when the tile is computed.
+template <int DT> struct GroupIO;
+
+// Stores take an NT flag: the forward kernel writes y and the state with nontemporal stores (they are
+// not read again by this kernel and, written normally, push the still-to-be-read input out of L2 /
+// Infinity Cache: measured -1.2 us on the 4096x4096 bf16 forward); loads are always plain
+// (nontemporal loads measured +2 us).
+#define FEWBIT_LD(p) (*(p))
+template <bool NT, typename T> __device__ __forceinline__ void store_as(T *p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <> struct GroupIO<FEWBIT_F32> {
+    struct Raw { f32x4 a, b; };
+    static __device__ __forceinline__ Raw load_raw(const void *base, size_t g) {
+        const f32x4 *p = static_cast<const f32x4 *>(base) + 2 * g;
+        return Raw{FEWBIT_LD(p), FEWBIT_LD(p + 1)};
+    }
+    static __device__ __forceinline__ void unpack(const Raw &r, float (&v)[8]) {
+        v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w;
+        v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+    }
+    template <bool NT = false>
+    static __device__ __forceinline__ void store(void *base, size_t g, const float (&v)[8]) {
+        f32x4 *p = static_cast<f32x4 *>(base) + 2 * g;
+        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        store_as<NT>(p, a);
+        store_as<NT>(p + 1, b);
+    }
+};
+
+template <> struct GroupIO<FEWBIT_BF16> {
+    struct Raw { u32x4 q; };
+    static __device__ __forceinline__ Raw load_raw(const void *base, size_t g) {
+        return Raw{FEWBIT_LD(static_cast<const u32x4 *>(base) + g)};
+    }
+    static __device__ __forceinline__ void unpack(const Raw &r, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = bits_f32(r.q[i] << 16);
+            v[2 * i + 1] = bits_f32(r.q[i] & 0xffff0000u);
+        }
+    }
+    template <bool NT = false>
+    static __device__ __forceinline__ void store(void *base, size_t g, const float (&v)[8]) {
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x2 f = {v[2 * i], v[2 * i + 1]};
+            w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));  // v_cvt_pk_bf16_f32
+        }
+        store_as<NT>(static_cast<u32x4 *>(base) + g, w);
+    }
+};
+
+template <> struct GroupIO<FEWBIT_F16> {
+    struct Raw { u32x4 q; };
+    static __device__ __forceinline__ Raw load_raw(const void *base, size_t g) {
+        return Raw{FEWBIT_LD(static_cast<const u32x4 *>(base) + g)};
+    }
+    static __device__ __forceinline__ void unpack(const Raw &r, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(r.q[i] & 0xffffu)));
+            v[2 * i + 1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(r.q[i] >> 16)));
+        }
+    }
+    template <bool NT = false>
+    static __device__ __forceinline__ void store(void *base, size_t g, const float (&v)[8]) {
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x2 f = {v[2 * i], v[2 * i + 1]};
+            w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));  // v_cvt_pk_f16_f32, RNE
+        }
+        store_as<NT>(static_cast<u32x4 *>(base) + g, w);
+    }
+};
+
+// ------------------------------------------------------------------ packed state access, one group
+// K bytes at byte offset K*g.  Written/read with the widest naturally aligned pieces.
+template <int K> __device__ __forceinline__ void store_state(uint8_t *state, size_t g, uint32_t w) {
+    uint8_t *p = state + static_cast<size_t>(K) * g;
+    if constexpr (K == 1) {
+        p[0] = static_cast<uint8_t>(w);
+    } else if constexpr (K == 2) {
+        *reinterpret_cast<uint16_t *>(p) = static_cast<uint16_t>(w);
+    } else if constexpr (K == 3) {
+        // 3*g is even for even g: one ushort + one ubyte either way, in aligned order
+        if (g & 1) {
+            p[0] = static_cast<uint8_t>(w);
+            *reinterpret_cast<uint16_t *>(p + 1) = static_cast<uint16_t>(w >> 8);
+        } else {
+            *reinterpret_cast<uint16_t *>(p) = static_cast<uint16_t>(w);
+            p[2] = static_cast<uint8_t>(w >> 16);
+        }
+    } else {
+        *reinterpret_cast<uint32_t *>(p) = w;
+    }
+}
+
+template <int K> __device__ __forceinline__ uint32_t load_state(const uint8_t *state, size_t g) {
+    const uint8_t *p = state + static_cast<size_t>(K) * g;
+    if constexpr (K == 1) {
+        return p[0];
+    } else if constexpr (K == 2) {
+        return *reinterpret_cast<const uint16_t *>(p);
+    } else if constexpr (K == 3) {
+        if (g & 1) return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(*reinterpret_cast<const uint16_t *>(p + 1)) << 8);
+        return static_cast<uint32_t>(*reinterpret_cast<const uint16_t *>(p)) | (static_cast<uint32_t>(p[2]) << 16);
+    } else {
+        return *reinterpret_cast<const uint32_t *>(p);
+    }
+}
+
+// ------------------------------------------------------------------ packed state access, quad of groups
+// Fast-path form.  Four adjacent lanes (a quad) own four adjacent groups = 4*K contiguous state bytes =
+// K dwords.  The quad exchanges its 8K-bit words with DPP quad_perm moves (VALU cross-lane, no LDS) so
+// that lane i ends up holding dword min(i, K-1) of the quad; ALL lanes then store/load a naturally
+// aligned dword (lanes beyond K-1 duplicate a neighbour: same address, same value).  No byte or short
+// accesses, and no exec-divergent branch around a memory instruction -- the latter matters because a
+// VMEM op issued on only some paths makes hipcc's s_waitcnt counting conservative and would serialise
+// the software pipeline.
+#define FEWBIT_QUAD_PERM(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+
+template <int CTRL> __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), CTRL, 0xf, 0xf, true));
+}
+
+// byte offset (relative to the state of group g - (lane&3)) handled by this lane, and the dword it holds
+template <int K, bool NT = false>
+__device__ __forceinline__ void store_state_quad(uint8_t *state, size_t g, int lane, uint32_t w) {
+    const int i = lane & 3;
+    uint8_t *quad = state + static_cast<size_t>(K) * (g - i);  // 4*K-byte aligned when state is dword aligned
+    if constexpr (K == 1) {
+        uint32_t t = quad_perm<FEWBIT_QUAD_PERM(0, 0, 2, 2)>(w) | (quad_perm<FEWBIT_QUAD_PERM(1, 1, 3, 3)>(w) << 8);
+        uint32_t d = quad_perm<FEWBIT_QUAD_PERM(0, 0, 0, 0)>(t) | (quad_perm<FEWBIT_QUAD_PERM(2, 2, 2, 2)>(t) << 16);
+        store_as<NT>(reinterpret_cast<uint32_t *>(quad), d);
+    } else if constexpr (K == 2) {
+        uint32_t d = quad_perm<FEWBIT_QUAD_PERM(0, 0, 2, 2)>(w) | (quad_perm<FEWBIT_QUAD_PERM(1, 1, 3, 3)>(w) << 16);
+        store_as<NT>(reinterpret_cast<uint32_t *>(quad + 4 * (i >> 1)), d);
+    } else if constexpr (K == 3) {
+        // C = w0 | w1<<24 | w2<<48 | w3<<72;  dword j = (w_j >> 8j) | (w_{j+1} << (24-8j)),  j = min(i,2)
+        const int j = i < 2 ? i : 2;
+        const uint32_t lo = quad_perm<FEWBIT_QUAD_PERM(0, 1, 2, 2)>(w);
+        const uint32_t hi = quad_perm<FEWBIT_QUAD_PERM(1, 2, 3, 3)>(w);
+        const uint32_t d = (lo >> (8 * j)) | (hi << (24 - 8 * j));
+        store_as<NT>(reinterpret_cast<uint32_t *>(quad + 4 * j), d);
+    } else {
+        store_as<NT>(reinterpret_cast<uint32_t *>(state + 4 * g), w);
+    }
+}
+
+template <int K> __device__ __forceinline__ uint32_t load_state_quad_raw(const uint8_t *state, size_t g, int lane) {
+    const int i = lane & 3;
+    const uint8_t *quad = state + static_cast<size_t>(K) * (g - i);
+    if constexpr (K == 1) return *reinterpret_cast<const uint32_t *>(quad);
+    else if constexpr (K == 2) return *reinterpret_cast<const uint32_t *>(quad + 4 * (i >> 1));
+    else if constexpr (K == 3) return *reinterpret_cast<const uint32_t *>(quad + 4 * (i < 2 ? i : 2));
+    else return *reinterpret_cast<const uint32_t *>(state + 4 * g);
+}
+
+// turn the dword fetched by load_state_quad_raw into this lane's 8K-bit word (bits above 8K are junk)
+template <int K> __device__ __forceinline__ uint32_t load_state_quad_fix(uint32_t raw, int lane) {
+    const int i = lane & 3;
+    if constexpr (K == 1) return raw >> (8 * i);
+    else if constexpr (K == 2) return raw >> (16 * (i & 1));
+    else if constexpr (K == 3) {
+        // lane holds dword min(i,2); need bits [24i, 24i+24) of the quad: dwords {0,0,1,2} and the next one
+        const uint32_t a = quad_perm<FEWBIT_QUAD_PERM(0, 0, 1, 2)>(raw);
+        const uint32_t b = quad_perm<FEWBIT_QUAD_PERM(1, 1, 2, 2)>(raw);
+        return __builtin_amdgcn_alignbit(b, a, (24 * i) & 31);
+    } else return raw;
+}
+
+// ------------------------------------------------------------------ activation math (fp32)
+// Two accuracy classes, chosen by the I/O dtype (see DESIGN.md "forward values"):
+//   precise : fp32 I/O.  ocml math; GELU as ATen's x*0.5*(1+erf(x*sqrt(1/2))).
+//   fast    : fp16/bf16 I/O, where the result is rounded to 11/8 significant bits anyway.
+//             Branch-free, built from the cheap VALU class (v_fma/v_mul/v_add) plus the hardware
+//             transcendentals v_exp_f32 / v_rcp_f32 (1 ulp each).
+__device__ __forceinline__ float relu_raw(float x) {
+    // v_max_f32 without the canonicalising self-max hipcc puts in front of fmaxf()
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// gelu(x) = relu(x) - |x| * Phi(-|x|),  Phi(-a) = exp2(-1 + a*P(a)),  P of degree 7 fitted by
+// tools/fit_gelu.py (max abs error of Phi(-a) in fp32 evaluation 4.5e-8; leading coefficient < 0 so
+// the exponent runs to -inf, never +inf, for huge |x|).  11 VALU instructions, one transcendental.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float a = __builtin_fabsf(x);
+    float r = -2.834918860e-06f;
+    r = __builtin_fmaf(r, a, 3.937771180e-05f);
+    r = __builtin_fmaf(r, a, -1.861801138e-04f);
+    r = __builtin_fmaf(r, a, -1.369371021e-04f);
+    r = __builtin_fmaf(r, a, 7.063421421e-03f);
+    r = __builtin_fmaf(r, a, -5.249617994e-02f);
+    r = __builtin_fmaf(r, a, -4.592081904e-01f);
+    r = __builtin_fmaf(r, a, -1.151105165e+00f);
+    const float q = __builtin_fmaf(r, a, -1.0f);
+    const float h = __builtin_amdgcn_exp2f(q);
+    return __builtin_fmaf(-a, h, relu_raw(x));
+}
+
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int FN, bool FAST> struct Act {
+    // p0/p1 are wave-uniform kernel arguments
+    static __device__ __forceinline__ float eval(float x, float p0, float p1) {
+        if constexpr (FN == FEWBIT_CELU) {
+            return x > 0.0f ? x : p0 * expm1f(x / p0);
+        } else if constexpr (FN == FEWBIT_ELU) {
+            return x > 0.0f ? x : p0 * expm1f(x);
+        } else if constexpr (FN == FEWBIT_GELU) {
+            if constexpr (FAST) return gelu_fast(x);
+            // ATen: x * 0.5 * (1 + erf(x * M_SQRT1_2)), in this order, in fp32
+            return (x * 0.5f) * (1.0f + erff(x * 0.70710678118654752440f));
+        } else if constexpr (FN == FEWBIT_HARDSWISH) {
+            float t = fminf(fmaxf(x + 3.0f, 0.0f), 6.0f);
+            return x * t / 6.0f;
+        } else if constexpr (FN == FEWBIT_LOGSIGMOID) {
+            return fminf(0.0f, x) - log1pf(expf(-fabsf(x)));
+        } else if constexpr (FN == FEWBIT_MISH) {
+            float sp = x > 20.0f ? x : log1pf(expf(x));
+            return x * tanhf(sp);
+        } else if constexpr (FN == FEWBIT_SELU) {
+            const float alpha = 1.6732632423543772848170429916717f;
+            const float scale = 1.0507009873554804934193349852946f;
+            return x > 0.0f ? scale * x : (scale * alpha) * expm1f(x);
+        } else if constexpr (FN == FEWBIT_SIGMOID) {
+            if constexpr (FAST) return sigmoid_fast(x);
+            return 1.0f / (1.0f + expf(-x));
+        } else if constexpr (FN == FEWBIT_SILU) {
+            if constexpr (FAST) return x * sigmoid_fast(x);
+            return x / (1.0f + expf(-x));
+        } else if constexpr (FN == FEWBIT_SOFTPLUS) {
+            float bx = x * p0;
+            return bx > p1 ? x : log1pf(expf(bx)) / p0;
+        } else if constexpr (FN == FEWBIT_SOFTSIGN) {
+            return x / (1.0f + fabsf(x));
+        } else if constexpr (FN == FEWBIT_TANH) {
+            return tanhf(x);
+        } else if constexpr (FN == FEWBIT_TANHSHRINK) {
+            return x - tanhf(x);
+        } else {
+            return x;
+        }
+    }
+};
+
+// 1-bit family: value and derivative-branch bit (fewbit/cuda/codec.cu:298-487 for the bit rules)
+template <int FN> struct Step1 {
+    static __device__ __forceinline__ float eval(float x, float p0, float p1, uint32_t &bit) {
+        if constexpr (FN == FEWBIT_HARDSHRINK) {
+            bool keep = (x < -p0) || (x > p0);
+            bit = keep;
+            return keep ? x : 0.0f;
+        } else if constexpr (FN == FEWBIT_HARDSIGMOID) {
+            bool lo = x <= -3.0f, hi = x >= 3.0f;
+            bit = !(lo || hi);
+            return lo ? 0.0f : (hi ? 1.0f : (x + 3.0f) / 6.0f);
+        } else if constexpr (FN == FEWBIT_HARDTANH) {
+            bool lo = x <= p0, hi = x >= p1;
+            bit = !(lo || hi);
+            return lo ? p0 : (hi ? p1 : x);
+        } else if constexpr (FN == FEWBIT_LEAKY_RELU) {
+            bool pos = x >= 0.0f;
+            bit = !pos;
+            return pos ? x : p0 * x;
+        } else if constexpr (FN == FEWBIT_RELU) {
+            bool off = x <= 0.0f;
+            bit = !off;
+            return off ? 0.0f : x;
+        } else if constexpr (FN == FEWBIT_RELU6) {
+            bool lo = x <= 0.0f, hi = x >= 6.0f;
+            bit = !(lo || hi);
+            return lo ? 0.0f : (hi ? 6.0f : x);
+        } else if constexpr (FN == FEWBIT_SOFTSHRINK) {
+            bool lo = x < -p0, hi = x > p0;
+            bit = lo || hi;
+            return lo ? x + p0 : (hi ? x - p0 : 0.0f);
+        } else {  // FEWBIT_THRESHOLD
+            bool off = x <= p0;
+            bit = !off;
+            return off ? p1 : x;
+        }
+    }
+};
+
+}  // namespace fewbit_hip

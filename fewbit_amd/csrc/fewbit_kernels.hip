@@ -1,0 +1,689 @@
+// fewbit_kernels.hip -- gfx950 kernels + the C-ABI (include/fewbit_hip.h) of FewBit's
+// quantized-activation path.  From-scratch CDNA4 design; what each kernel replaces in the reference
+// (skolai/fewbit) is cited at its definition.
+//
+// Work decomposition (see DESIGN.md "kernels"):
+//   group      = 8 consecutive elements  <-> exactly K bytes of packed state
+//   wave tile  = 64 lanes x U groups; load u of a wave covers 64 lane-contiguous groups, so every
+//                wave-level memory instruction on x / y / gy / gx touches one contiguous span
+//                (1 KiB for 16-bit dtypes)
+//   block      = 4 waves = 4 consecutive wave tiles; grid = ceil(#tiles / 4): one tile per wave,
+//                no loop, all loads of a tile issued before the first use
+// Tables: the 2^K-1 borders live in SGPRs (one v_readlane each, loaded by lanes 0..2^K-2);
+// the 2^K levels are staged in LDS and gathered per element in backward.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "fewbit_codepack.h"
+#include "fewbit_device.h"
+
+namespace fewbit_hip {
+
+// ------------------------------------------------------------------------------------------------
+// code of one element against NB sorted borders (edge path only; the fast path uses pack_group):
+//   code = #{ j : b_j < x }, and NaN -> NB because the predicate is !(b_j >= x)
+// which is torch.searchsorted's CPU rule used by the reference (fewbit/cpu/gelu.cc:17).
+template <int NB> __device__ __forceinline__ uint32_t count_below(const float (&b)[NB], float x) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) c += !(b[j] >= x) ? 1u : 0u;
+    return c;
+}
+
+// lanes 0..NB-1 fetch one border each; every lane then holds all NB (wave-uniform) values
+template <int DT, int NB> __device__ __forceinline__ void load_borders(const void *borders, float (&b)[NB]) {
+    const int lane = threadIdx.x & (kWave - 1);
+    float mine = 0.0f;
+    if (lane < NB) mine = Elem<DT>::load(borders, lane);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b[j] = bits_f32(__builtin_amdgcn_readlane(f32_bits(mine), j));
+}
+
+// Work distribution shared by the streaming kernels.  A TILE is U*64 consecutive full groups; wave w of
+// the launch owns tiles w, w + nwaves, w + 2*nwaves, ... so that at any moment the resident waves read
+// one contiguous window of memory.  Whatever does not fill a tile (fewer than U*64 full groups plus the
+// ragged last group) is the TAIL, done element-wise by the last wave.
+// wave / nwaves / ntiles are wave-uniform and kept in SGPRs (readfirstlane), so the tile loop is a
+// scalar loop and every address is "scalar base + lane offset".
+struct Span {
+    size_t wave, nwaves, ntiles, tail_g0, ngroups;
+    int lane;
+};
+
+template <int U> __device__ __forceinline__ Span make_span(size_t n) {
+    Span s;
+    s.lane = threadIdx.x & (kWave - 1);
+    s.nwaves = static_cast<size_t>(gridDim.x) * kWavesPerBlock;
+    s.wave = static_cast<size_t>(blockIdx.x) * kWavesPerBlock +
+             static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
+    s.ntiles = (n >> 3) / (static_cast<size_t>(U) * kWave);
+    s.tail_g0 = s.ntiles * (static_cast<size_t>(U) * kWave);
+    s.ngroups = (n + 7) >> 3;
+    return s;
+}
+
+#ifdef FEWBIT_TRACE
+// debug variant: per-wave timestamps (s_memrealtime, 100 MHz) of the pipeline stages
+__device__ unsigned long long g_trace[1 << 17];
+#define FEWBIT_STAMP(slot)                                                                      \
+    do {                                                                                        \
+        if ((threadIdx.x & 63) == 0 && s.wave < (1u << 13)) g_trace[s.wave * 16 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define FEWBIT_STAMP(slot) do { } while (0)
+#endif
+
+// Two-buffer software pipeline over the tiles of one wave: the loads of the next tile are issued
+// before the current tile is processed, and the two register buffers alternate (no copies), so the
+// only wait in front of process(tile i) is for loads issued a whole tile earlier.
+//   load(t, buf)    issues the global loads of tile t into buf (no use of the data)
+//   process(t, buf) consumes buf and stores the results of tile t
+// Neither may contain an exec-divergent branch around a memory instruction (same s_waitcnt reason).
+// The input pointers of these kernels are deliberately NOT __restrict__: outputs may alias inputs
+// (in-place, as the reference op), and with noalias inputs LLVM sinks the prefetch loads below the
+// stores of process(), right in front of their use, which undoes the pipeline.
+//   init()          runs once, after the first tile's loads are in flight (table setup hides there)
+template <typename Buf, typename Init, typename Load, typename Process>
+__device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&load, Process &&process) {
+    Buf A, B;
+    size_t t = s.wave;
+    if (t >= s.ntiles) {
+        init();
+        return;
+    }
+    const size_t last = s.ntiles - 1;
+    FEWBIT_STAMP(0);
+    load(t, A);
+    init();
+    FEWBIT_STAMP(1);
+    int slot = 2;
+    for (;;) {
+        // prefetches are unconditional (clamped to the last tile, whose data is then simply dropped):
+        // a load issued on only one path would make the s_waitcnt in front of process() count for the
+        // shorter path and wait for the prefetch itself
+        const size_t t1 = t + s.nwaves;
+        load(t1 < last ? t1 : last, B);
+        process(t, A);
+        FEWBIT_STAMP(slot); ++slot;
+        if (t1 >= s.ntiles) break;
+        const size_t t2 = t1 + s.nwaves;
+        load(t2 < last ? t2 : last, A);
+        process(t1, B);
+        FEWBIT_STAMP(slot); ++slot;
+        if (t2 >= s.ntiles) break;
+        t = t2;
+    }
+}
+
+// occupancy each forward instantiation is compiled for: 8 waves/SIMD (<= 64 VGPRs) where the table and
+// the two prefetch buffers fit without spilling, 6 (<= 80) for 4-bit tables (15 border VGPRs), fp32
+// groups (8 VGPRs per buffer) and mish (ocml log1p+exp+tanh).  The launcher sizes the grid from the occupancy the runtime reports.
+template <int FN, int DT, int K> constexpr int forward_waves_per_simd() {
+    return (K == 4 || DT == FEWBIT_F32 || FN == FEWBIT_MISH) ? 6 : kWavesPerSimd;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused forward for 2^K-level tables, K in 1..4: activation + quantize + pack, software-pipelined:
+// the loads of tile i+1 are in flight while tile i is bucketed, evaluated and stored.
+// Replaces StepwiseKernel<Fn> + BinarySearch + DeflateWarpKernel (fewbit/cuda/codec.cu:489-504,
+// :118-131, :142-165).
+template <int FN, int DT, int K, int U>
+__global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void quantize_forward_kernel(const void *x, void *y,
+                                                                  uint8_t *__restrict__ state, size_t n,
+                                                                  const void *__restrict__ borders, float p0,
+                                                                  float p1) {
+    constexpr int NB = (1 << K) - 1;
+    constexpr bool kFast = (DT != FEWBIT_F32);
+    typedef typename GroupIO<DT>::Raw Raw;
+    const Span s = make_span<U>(n);
+
+    float b[NB];
+
+    struct Buf { Raw r[U]; };
+    pipeline2<Buf>(
+        s, [&]() { load_borders<DT, NB>(borders, b); },
+        [&](size_t t, Buf &buf) {
+#if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 4)
+            t = s.wave;  // ablation: every iteration re-reads and re-writes the wave's first tile (cache resident)
+#endif
+#pragma unroll
+            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + s.lane);
+        },
+        [&](size_t t, const Buf &buf) {
+#if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 4)
+            t = s.wave;
+#endif
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float v[8];
+                GroupIO<DT>::unpack(buf.r[u], v);
+#if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 2)
+                const uint32_t w = f32_bits(v[0]) & 0xffffffu;  // ablation: no bucketing
+#else
+                const uint32_t w = pack_group<K>(v, b);
+#endif
+#if !(defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 1))
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
+#endif
+                const size_t g = (t * U + u) * kWave + s.lane;
+                GroupIO<DT>::template store<true>(y, g, v);
+                store_state_quad<K, true>(state, g, s.lane, w);
+            }
+        });
+
+    // ---- tail: per-group and per-element guards, last wave only
+    if (s.wave != s.nwaves - 1) return;
+    for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
+        const size_t e0 = g << 3;
+        uint32_t w = 0;
+        for (int i = 0; i < 8; ++i) {
+            if (e0 + i < n) {
+                float xv = Elem<DT>::load(x, e0 + i);
+                w |= count_below<NB>(b, xv) << (K * i);
+                Elem<DT>::store(y, e0 + i, Act<FN, kFast>::eval(xv, p0, p1));
+            }
+        }
+        store_state<K>(state, g, w);
+    }
+}
+
+// Generic forward: any table size up to 255 borders (K up to 8), any pointer alignment.
+// One thread per group, borders staged in LDS, lower_bound per element.
+template <int FN, int DT>
+__global__ __launch_bounds__(kBlock) void quantize_forward_generic_kernel(const void *__restrict__ x, void *y,
+                                                                          uint8_t *__restrict__ state, size_t n,
+                                                                          const void *__restrict__ borders,
+                                                                          int nborders, int nbits, float p0, float p1) {
+    __shared__ float sb[256];
+    for (int j = threadIdx.x; j < nborders; j += kBlock) sb[j] = Elem<DT>::load(borders, j);
+    __syncthreads();
+    const size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const size_t e0 = g << 3;
+    if (e0 >= n) return;
+    uint64_t w = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (e0 + i < n) {
+            float xv = Elem<DT>::load(x, e0 + i);
+            int lo = 0, hi = nborders;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (!(sb[mid] >= xv)) lo = mid + 1;
+                else hi = mid;
+            }
+            w |= static_cast<uint64_t>(lo) << (nbits * i);
+            Elem<DT>::store(y, e0 + i, Act<FN, (DT != FEWBIT_F32)>::eval(xv, p0, p1));
+        }
+    }
+    uint8_t *p = state + static_cast<size_t>(nbits) * g;
+    for (int j = 0; j < nbits; ++j) p[j] = static_cast<uint8_t>(w >> (8 * j));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused backward: unpack + level gather (LDS) + multiply, same software pipeline.
+// Replaces StepwiseBackwardKernel + InflateWarpKernel (fewbit/cuda/codec.cu:655-663, :184-203).
+template <int DT, int K, int U>
+__global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kernel(const void *gy,
+                                                                   const uint8_t *state, void *gx,
+                                                                   size_t n, const void *__restrict__ levels,
+                                                                   int nlevels) {
+    constexpr int NL = 1 << K;
+    constexpr uint32_t kMask = NL - 1;
+    typedef typename GroupIO<DT>::Raw Raw;
+    __shared__ float lut[NL];
+    const Span s = make_span<U>(n);
+
+    struct Buf { Raw r[U]; uint32_t w[U]; };
+    pipeline2<Buf>(
+        s,
+        [&]() {  // every wave of the block gets here exactly once, so the barrier is safe
+            if (threadIdx.x < NL) lut[threadIdx.x] = threadIdx.x < nlevels ? Elem<DT>::load(levels, threadIdx.x) : 0.0f;
+            __syncthreads();
+        },
+        [&](size_t t, Buf &buf) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + s.lane);
+                buf.w[u] = load_state_quad_raw<K>(state, (t * U + u) * kWave + s.lane, s.lane);
+            }
+        },
+        [&](size_t t, const Buf &buf) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float v[8];
+                GroupIO<DT>::unpack(buf.r[u], v);
+                const uint32_t w = load_state_quad_fix<K>(buf.w[u], s.lane);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = lut[(w >> (K * i)) & kMask] * v[i];
+                GroupIO<DT>::store(gx, (t * U + u) * kWave + s.lane, v);
+            }
+        });
+
+    if (s.wave != s.nwaves - 1) return;
+    for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
+        const size_t e0 = g << 3;
+        const uint32_t w = load_state<K>(state, g);
+        for (int i = 0; i < 8; ++i)
+            if (e0 + i < n) Elem<DT>::store(gx, e0 + i, lut[(w >> (K * i)) & kMask] * Elem<DT>::load(gy, e0 + i));
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void quantize_backward_generic_kernel(const void *__restrict__ gy,
+                                                                           const uint8_t *__restrict__ state,
+                                                                           void *gx, size_t n,
+                                                                           const void *__restrict__ levels,
+                                                                           int nlevels, int nbits) {
+    __shared__ float lut[256];
+    for (int j = threadIdx.x; j < 256; j += kBlock) lut[j] = j < nlevels ? Elem<DT>::load(levels, j) : 0.0f;
+    __syncthreads();
+    const size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const size_t e0 = g << 3;
+    if (e0 >= n) return;
+    const uint8_t *p = state + static_cast<size_t>(nbits) * g;
+    uint64_t w = 0;
+    for (int j = 0; j < nbits; ++j) w |= static_cast<uint64_t>(p[j]) << (8 * j);
+    const uint32_t mask = (1u << nbits) - 1u;
+    for (int i = 0; i < 8; ++i)
+        if (e0 + i < n)
+            Elem<DT>::store(gx, e0 + i, lut[static_cast<uint32_t>(w >> (nbits * i)) & mask] * Elem<DT>::load(gy, e0 + i));
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1-bit family (ReLU & co): exact derivative, one bit per element.
+// Replaces the eight <Name>Kernel / <Name>BackwardKernel pairs, fewbit/cuda/codec.cu:298-487.
+template <int FN, int DT, int U>
+__global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kernel(const void *x, void *y,
+                                                                   uint8_t *__restrict__ state, size_t n, float p0,
+                                                                   float p1, bool aligned) {
+    typedef typename GroupIO<DT>::Raw Raw;
+    Span s = make_span<U>(n);
+    if (!aligned) {  // everything through the element-wise tail
+        s.ntiles = 0;
+        s.tail_g0 = 0;
+    }
+    struct Buf { Raw r[U]; };
+    pipeline2<Buf>(
+        s, []() {},
+        [&](size_t t, Buf &buf) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + s.lane);
+        },
+        [&](size_t t, const Buf &buf) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float v[8];
+                GroupIO<DT>::unpack(buf.r[u], v);
+                uint32_t w = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    uint32_t bit;
+                    v[i] = Step1<FN>::eval(v[i], p0, p1, bit);
+                    w |= bit << i;
+                }
+                const size_t g = (t * U + u) * kWave + s.lane;
+                GroupIO<DT>::template store<true>(y, g, v);
+                store_state_quad<1, true>(state, g, s.lane, w);
+            }
+        });
+    if (aligned && s.wave != s.nwaves - 1) return;
+    // tail (or the whole range when misaligned: every wave strides over the groups)
+    const size_t first = aligned ? s.tail_g0 + s.lane : s.wave * kWave + s.lane;
+    const size_t step = aligned ? kWave : s.nwaves * kWave;
+    for (size_t g = first; g < s.ngroups; g += step) {
+        const size_t e0 = g << 3;
+        uint32_t w = 0;
+        for (int i = 0; i < 8; ++i) {
+            if (e0 + i < n) {
+                uint32_t bit;
+                Elem<DT>::store(y, e0 + i, Step1<FN>::eval(Elem<DT>::load(x, e0 + i), p0, p1, bit));
+                w |= bit << i;
+            }
+        }
+        store_state<1>(state, g, w);
+    }
+}
+
+template <int DT, int U>
+__global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_backward_kernel(const void *gy,
+                                                                    const uint8_t *state, void *gx,
+                                                                    size_t n, float m0, float m1, bool aligned) {
+    typedef typename GroupIO<DT>::Raw Raw;
+    Span s = make_span<U>(n);
+    if (!aligned) {
+        s.ntiles = 0;
+        s.tail_g0 = 0;
+    }
+    struct Buf { Raw r[U]; uint32_t w[U]; };
+    pipeline2<Buf>(
+        s, []() {},
+        [&](size_t t, Buf &buf) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + s.lane);
+                buf.w[u] = load_state_quad_raw<1>(state, (t * U + u) * kWave + s.lane, s.lane);
+            }
+        },
+        [&](size_t t, const Buf &buf) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float v[8];
+                GroupIO<DT>::unpack(buf.r[u], v);
+                const uint32_t w = load_state_quad_fix<1>(buf.w[u], s.lane);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (((w >> i) & 1u) ? m1 : m0) * v[i];
+                GroupIO<DT>::store(gx, (t * U + u) * kWave + s.lane, v);
+            }
+        });
+    if (aligned && s.wave != s.nwaves - 1) return;
+    const size_t first = aligned ? s.tail_g0 + s.lane : s.wave * kWave + s.lane;
+    const size_t step = aligned ? kWave : s.nwaves * kWave;
+    for (size_t g = first; g < s.ngroups; g += step) {
+        const size_t e0 = g << 3;
+        const uint32_t w = load_state<1>(state, g);
+        for (int i = 0; i < 8; ++i)
+            if (e0 + i < n) Elem<DT>::store(gx, e0 + i, (((w >> i) & 1u) ? m1 : m0) * Elem<DT>::load(gy, e0 + i));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone codec (test seam for the layout): int32 codes <-> packed bytes, width 1..8.
+// Replaces DeflateBlockKernel / InflateBlockKernel (fewbit/cuda/codec.cu:166-182, :205-220).
+__global__ __launch_bounds__(kBlock) void pack_codes_kernel(const int32_t *__restrict__ codes,
+                                                            uint8_t *__restrict__ state, size_t n, int nbits) {
+    const size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const size_t e0 = g << 3;
+    if (e0 >= n) return;
+    const uint64_t mask = (1ull << nbits) - 1ull;
+    uint64_t w = 0;
+    for (int i = 0; i < 8; ++i)
+        if (e0 + i < n) w |= (static_cast<uint64_t>(static_cast<uint32_t>(codes[e0 + i])) & mask) << (nbits * i);
+    uint8_t *p = state + static_cast<size_t>(nbits) * g;
+    for (int j = 0; j < nbits; ++j) p[j] = static_cast<uint8_t>(w >> (8 * j));
+}
+
+__global__ __launch_bounds__(kBlock) void unpack_codes_kernel(const uint8_t *__restrict__ state,
+                                                              int32_t *__restrict__ codes, size_t n, int nbits) {
+    const size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const size_t e0 = g << 3;
+    if (e0 >= n) return;
+    const uint8_t *p = state + static_cast<size_t>(nbits) * g;
+    uint64_t w = 0;
+    for (int j = 0; j < nbits; ++j) w |= static_cast<uint64_t>(p[j]) << (8 * j);
+    const uint64_t mask = (1ull << nbits) - 1ull;
+    for (int i = 0; i < 8; ++i)
+        if (e0 + i < n) codes[e0 + i] = static_cast<int32_t>((w >> (nbits * i)) & mask);
+}
+
+// ================================================================================================
+// host side: argument checks, dispatch, launch
+// ================================================================================================
+namespace {
+
+thread_local char g_last_error[256] = "";
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof g_last_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return FEWBIT_OK;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+// groups per lane per pipeline stage (tunable, FEWBIT_HIP_U) and resident waves per CU the grid is
+// sized for (FEWBIT_HIP_WAVES_PER_CU); defaults from measurements on MI355X, see DESIGN.md
+#ifndef FEWBIT_U16
+#define FEWBIT_U16 1
+#endif
+#ifndef FEWBIT_U32
+#define FEWBIT_U32 1
+#endif
+template <int DT> struct Tile { static constexpr int U = (DT == FEWBIT_F32) ? FEWBIT_U32 : FEWBIT_U16; };
+
+int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// resident blocks per CU of a kernel (runtime's occupancy answer, cached per kernel); the streaming
+// kernels are launched with exactly one resident generation of waves, which then loop over tiles.
+// FEWBIT_HIP_WAVES_PER_CU (tuning hook) caps it.
+template <auto Kern> int resident_blocks_per_cu() {
+    static int cached = 0;  // one per kernel instantiation
+    if (cached == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kern, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
+        if (nb > 8) nb = 8;
+        const char *e = getenv("FEWBIT_HIP_WAVES_PER_CU");
+        if (e && atoi(e) >= kWavesPerBlock && atoi(e) / kWavesPerBlock < nb) nb = atoi(e) / kWavesPerBlock;
+        cached = nb;
+    }
+    return cached;
+}
+
+// blocks for the streaming kernels: one wave per tile until the chip is full, then waves loop
+template <auto Kern> unsigned tile_grid(size_t n, int U) {
+    const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
+    size_t blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const size_t cap = static_cast<size_t>(device_cus()) * resident_blocks_per_cu<Kern>();
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return static_cast<unsigned>(blocks);
+}
+
+// launch a streaming kernel instantiation with its resident-generation grid
+#define FB_LAUNCH_TILED(KERN, N, U, STREAM, ...) \
+    hipLaunchKernelGGL((KERN), dim3(tile_grid<(KERN)>((N), (U))), dim3(kBlock), 0, (STREAM), __VA_ARGS__)
+
+unsigned group_grid(size_t n) { return static_cast<unsigned>(((n + 7) / 8 + kBlock - 1) / kBlock); }
+
+template <int FN, int DT>
+int launch_forward(const void *x, void *y, uint8_t *state, size_t n, const void *borders, int nborders, int k,
+                   float p0, float p1, hipStream_t s) {
+    constexpr int U = Tile<DT>::U;
+    const bool fast = (nborders == (1 << k) - 1) && k <= 4 && aligned16(x) && aligned16(y) && aligned4(state);
+    if (fast) {
+        switch (k) {
+        case 1: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 1, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
+        case 2: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 2, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
+        case 3: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 3, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
+        default: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 4, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
+        }
+    } else {
+        hipLaunchKernelGGL((quantize_forward_generic_kernel<FN, DT>), dim3(group_grid(n)), dim3(kBlock), 0, s, x, y,
+                           state, n, borders, nborders, k, p0, p1);
+    }
+    return check_launch("quantize_forward");
+}
+
+template <int FN>
+int dispatch_forward_dtype(int dtype, const void *x, void *y, uint8_t *state, size_t n, const void *borders,
+                           int nborders, int k, float p0, float p1, hipStream_t s) {
+    switch (dtype) {
+    case FEWBIT_F32: return launch_forward<FN, FEWBIT_F32>(x, y, state, n, borders, nborders, k, p0, p1, s);
+    case FEWBIT_F16: return launch_forward<FN, FEWBIT_F16>(x, y, state, n, borders, nborders, k, p0, p1, s);
+    case FEWBIT_BF16: return launch_forward<FN, FEWBIT_BF16>(x, y, state, n, borders, nborders, k, p0, p1, s);
+    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    }
+}
+
+template <int DT>
+int launch_backward(const void *gy, const uint8_t *state, void *gx, size_t n, const void *levels, int nlevels, int k,
+                    hipStream_t s) {
+    constexpr int U = Tile<DT>::U;
+    const bool fast = k <= 4 && aligned16(gy) && aligned16(gx) && aligned4(state);
+    if (fast) {
+        switch (k) {
+        case 1: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 1, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
+        case 2: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 2, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
+        case 3: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 3, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
+        default: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 4, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
+        }
+    } else {
+        hipLaunchKernelGGL((quantize_backward_generic_kernel<DT>), dim3(group_grid(n)), dim3(kBlock), 0, s, gy, state,
+                           gx, n, levels, nlevels, k);
+    }
+    return check_launch("quantize_backward");
+}
+
+template <int FN, int DT>
+int launch_step1_forward(const void *x, void *y, uint8_t *state, size_t n, float p0, float p1, hipStream_t s) {
+    constexpr int U = Tile<DT>::U;
+    FB_LAUNCH_TILED((stepwise1_forward_kernel<FN, DT, U>), n, U, s, x, y, state, n, p0, p1,
+                    aligned16(x) && aligned16(y) && aligned4(state));
+    return check_launch("stepwise1_forward");
+}
+
+template <int FN>
+int dispatch_step1_dtype(int dtype, const void *x, void *y, uint8_t *state, size_t n, float p0, float p1,
+                         hipStream_t s) {
+    switch (dtype) {
+    case FEWBIT_F32: return launch_step1_forward<FN, FEWBIT_F32>(x, y, state, n, p0, p1, s);
+    case FEWBIT_F16: return launch_step1_forward<FN, FEWBIT_F16>(x, y, state, n, p0, p1, s);
+    case FEWBIT_BF16: return launch_step1_forward<FN, FEWBIT_BF16>(x, y, state, n, p0, p1, s);
+    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    }
+}
+
+}  // namespace
+}  // namespace fewbit_hip
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+using namespace fewbit_hip;
+
+extern "C" {
+
+#ifdef FEWBIT_TRACE
+int fewbit_hip_debug_trace(unsigned long long *host, size_t count) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+int fewbit_hip_abi_version(void) { return FEWBIT_HIP_ABI_VERSION; }
+
+const char *fewbit_hip_last_error(void) { return g_last_error; }
+
+int fewbit_hip_bitwidth(int nlevels) {
+    int k = 0;
+    while ((1 << k) < nlevels) ++k;
+    return k < 1 ? 1 : k;
+}
+
+size_t fewbit_hip_state_nbytes(size_t n, int nbits) { return static_cast<size_t>(nbits) * ((n + 7) / 8); }
+
+int fewbit_hip_quantize_forward(int fn, int dtype, const void *x, void *y, uint8_t *state, size_t n,
+                                const void *borders, int nborders, double p0, double p1, void *stream) {
+    if (nborders < 1 || nborders > 255) return fail(FEWBIT_ERR_UNSUPPORTED, "nborders=%d outside [1,255]", nborders);
+    if (n == 0) return FEWBIT_OK;
+    if (!x || !y || !state || !borders) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+    const int k = fewbit_hip_bitwidth(nborders + 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float a = static_cast<float>(p0), b = static_cast<float>(p1);
+#define FB_CASE(F) case F: return dispatch_forward_dtype<F>(dtype, x, y, state, n, borders, nborders, k, a, b, s);
+    switch (fn) {
+        FB_CASE(FEWBIT_CELU) FB_CASE(FEWBIT_ELU) FB_CASE(FEWBIT_GELU) FB_CASE(FEWBIT_HARDSWISH)
+        FB_CASE(FEWBIT_LOGSIGMOID) FB_CASE(FEWBIT_MISH) FB_CASE(FEWBIT_SELU) FB_CASE(FEWBIT_SIGMOID)
+        FB_CASE(FEWBIT_SILU) FB_CASE(FEWBIT_SOFTPLUS) FB_CASE(FEWBIT_SOFTSIGN) FB_CASE(FEWBIT_TANH)
+        FB_CASE(FEWBIT_TANHSHRINK) FB_CASE(FEWBIT_IDENTITY)
+    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown continuous fn %d", fn);
+    }
+#undef FB_CASE
+}
+
+int fewbit_hip_quantize_backward(int dtype, const void *gy, const uint8_t *state, void *gx, size_t n,
+                                 const void *levels, int nlevels, void *stream) {
+    if (nlevels < 2 || nlevels > 256) return fail(FEWBIT_ERR_UNSUPPORTED, "nlevels=%d outside [2,256]", nlevels);
+    if (n == 0) return FEWBIT_OK;
+    if (!gy || !gx || !state || !levels) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+    const int k = fewbit_hip_bitwidth(nlevels);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case FEWBIT_F32: return launch_backward<FEWBIT_F32>(gy, state, gx, n, levels, nlevels, k, s);
+    case FEWBIT_F16: return launch_backward<FEWBIT_F16>(gy, state, gx, n, levels, nlevels, k, s);
+    case FEWBIT_BF16: return launch_backward<FEWBIT_BF16>(gy, state, gx, n, levels, nlevels, k, s);
+    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    }
+}
+
+int fewbit_hip_stepwise1_forward(int fn, int dtype, const void *x, void *y, uint8_t *state, size_t n, double p0,
+                                 double p1, void *stream) {
+    if (n == 0) return FEWBIT_OK;
+    if (!x || !y || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float a = static_cast<float>(p0), b = static_cast<float>(p1);
+#define FB_CASE(F) case F: return dispatch_step1_dtype<F>(dtype, x, y, state, n, a, b, s);
+    switch (fn) {
+        FB_CASE(FEWBIT_HARDSHRINK) FB_CASE(FEWBIT_HARDSIGMOID) FB_CASE(FEWBIT_HARDTANH) FB_CASE(FEWBIT_LEAKY_RELU)
+        FB_CASE(FEWBIT_RELU) FB_CASE(FEWBIT_RELU6) FB_CASE(FEWBIT_SOFTSHRINK) FB_CASE(FEWBIT_THRESHOLD)
+    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown stepwise fn %d", fn);
+    }
+#undef FB_CASE
+}
+
+int fewbit_hip_stepwise1_backward(int fn, int dtype, const void *gy, const uint8_t *state, void *gx, size_t n,
+                                  double p0, void *stream) {
+    if (fn < 0 || fn >= FEWBIT_STEPWISE_COUNT) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown stepwise fn %d", fn);
+    if (n == 0) return FEWBIT_OK;
+    if (!gy || !gx || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+    const bool al = aligned16(gy) && aligned16(gx) && aligned4(state);
+    float m0 = 0.0f, m1 = 1.0f;
+    if (fn == FEWBIT_HARDSIGMOID) m1 = 1.0f / 6.0f;
+    if (fn == FEWBIT_LEAKY_RELU) { m0 = 1.0f; m1 = static_cast<float>(p0); }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case FEWBIT_F32:
+        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_F32, Tile<FEWBIT_F32>::U>), n, Tile<FEWBIT_F32>::U, s, gy, state, gx, n, m0, m1, al);
+        break;
+    case FEWBIT_F16:
+        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_F16, Tile<FEWBIT_F16>::U>), n, Tile<FEWBIT_F16>::U, s, gy, state, gx, n, m0, m1, al);
+        break;
+    case FEWBIT_BF16:
+        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_BF16, Tile<FEWBIT_BF16>::U>), n, Tile<FEWBIT_BF16>::U, s, gy, state, gx, n, m0, m1, al);
+        break;
+    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    }
+    return check_launch("stepwise1_backward");
+}
+
+int fewbit_hip_pack_codes(const int32_t *codes, uint8_t *state, size_t n, int nbits, void *stream) {
+    if (nbits < 1 || nbits > 8) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "nbits=%d outside [1,8]", nbits);
+    if (n == 0) return FEWBIT_OK;
+    if (!codes || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+    hipLaunchKernelGGL(pack_codes_kernel, dim3(group_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), codes,
+                       state, n, nbits);
+    return check_launch("pack_codes");
+}
+
+int fewbit_hip_unpack_codes(const uint8_t *state, int32_t *codes, size_t n, int nbits, void *stream) {
+    if (nbits < 1 || nbits > 8) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "nbits=%d outside [1,8]", nbits);
+    if (n == 0) return FEWBIT_OK;
+    if (!codes || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+    hipLaunchKernelGGL(unpack_codes_kernel, dim3(group_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       state, codes, n, nbits);
+    return check_launch("unpack_codes");
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+/*
+ * fewbit_hip.h -- C-ABI of the MI355X (gfx950) implementation of FewBit's
+ * quantized-activation path.  Plain pointers and sizes, no torch types.
+ *
+ * Every pointer is a DEVICE pointer; `stream` is a hipStream_t passed as
+ * void* (NULL = the null stream).  Calls only enqueue work on `stream`; they
+ * never synchronise.  Return value: FEWBIT_OK or a negative fewbit_status;
+ * fewbit_hip_last_error() gives the message of the last failure on the
+ * calling thread.
+ *
+ * Which reference interface each entry point replaces (paths relative to the
+ * reference tree skolai/fewbit):
+ *
+ *   fewbit_hip_quantize_forward   <- the 13 `DECLARE_CONTINOUS_FUNC` launchers
+ *                                    Celu ... Tanhshrink, fewbit/cuda/codec.h:74-91
+ *                                    (kernel StepwiseKernel, fewbit/cuda/codec.cu:489-504)
+ *   fewbit_hip_quantize_backward  <- StepwiseBackward, fewbit/cuda/codec.h:93-95
+ *                                    (fewbit/cuda/codec.cu:655-670)
+ *   fewbit_hip_stepwise1_forward  <- Hardshrink/Hardsigmoid/Hardtanh/LeakyRelu/Relu/Relu6/
+ *                                    Softshrink/Threshold, fewbit/cuda/codec.h:58-67
+ *   fewbit_hip_stepwise1_backward <- <Name>Backward, fewbit/cuda/codec.h:58-67
+ *   fewbit_hip_pack_codes         <- DeflateBlock, fewbit/cuda/codec.h:17-18 (layout of
+ *                                    fewbit::Deflate, fewbit/cpu/codec.h:33-57)
+ *   fewbit_hip_unpack_codes       <- InflateBlock, fewbit/cuda/codec.h:22-23
+ *   fewbit_hip_state_nbytes       <- buffer_len = nobits * ceil(n/8),
+ *                                    fewbit/cuda/activation.cc:349-351
+ *   fewbit_hip_bitwidth           <- GetBitWidth, fewbit/cuda/activation.cc:17-21 (the
+ *                                    off-by-one of that function is NOT reproduced; this is
+ *                                    ceil(log2(nlevels)) as on the CPU path, fewbit/cpu/gelu.cc:18,36)
+ *
+ * Differences from the reference launchers, all additive: fp16/bf16 I/O besides
+ * fp32, 64-bit element counts, an explicit stream, and error returns.
+ *
+ * Packed state layout (identical to the reference): element i occupies bits
+ * [k*i, k*(i+1)) of one little-endian, LSB-first bitstream, so every 8
+ * consecutive elements map to exactly k bytes.  The state buffer is
+ * k*ceil(n/8) bytes; codes of the padding elements are zero.
+ */
+#ifndef FEWBIT_HIP_H_
+#define FEWBIT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEWBIT_HIP_ABI_VERSION 1
+
+typedef enum fewbit_status {
+    FEWBIT_OK = 0,
+    FEWBIT_ERR_INVALID_ARGUMENT = -1, /* bad enum, null pointer, table size, misuse */
+    FEWBIT_ERR_UNSUPPORTED = -2,      /* e.g. more than 256 levels */
+    FEWBIT_ERR_LAUNCH = -3            /* HIP reported an error at launch */
+} fewbit_status;
+
+typedef enum fewbit_dtype { FEWBIT_F32 = 0, FEWBIT_F16 = 1, FEWBIT_BF16 = 2 } fewbit_dtype;
+
+/* continuous activations: k-bit code from a border table (fewbit/fewbit.cc:21-33) */
+typedef enum fewbit_continuous_fn {
+    FEWBIT_CELU = 0,     /* p0 = alpha */
+    FEWBIT_ELU = 1,      /* p0 = alpha */
+    FEWBIT_GELU = 2,
+    FEWBIT_HARDSWISH = 3,
+    FEWBIT_LOGSIGMOID = 4,
+    FEWBIT_MISH = 5,
+    FEWBIT_SELU = 6,
+    FEWBIT_SIGMOID = 7,
+    FEWBIT_SILU = 8,
+    FEWBIT_SOFTPLUS = 9, /* p0 = beta, p1 = threshold */
+    FEWBIT_SOFTSIGN = 10,
+    FEWBIT_TANH = 11,
+    FEWBIT_TANHSHRINK = 12,
+    FEWBIT_IDENTITY = 13, /* y = x: quantize only (custom `stepwise` tables) */
+    FEWBIT_CONTINUOUS_COUNT = 14
+} fewbit_continuous_fn;
+
+/* piecewise-linear activations: exact 1-bit state (fewbit/fewbit.cc:10-18) */
+typedef enum fewbit_stepwise_fn {
+    FEWBIT_HARDSHRINK = 0, /* p0 = lambd */
+    FEWBIT_HARDSIGMOID = 1,
+    FEWBIT_HARDTANH = 2,   /* p0 = min_val, p1 = max_val */
+    FEWBIT_LEAKY_RELU = 3, /* p0 = negative_slope (forward AND backward) */
+    FEWBIT_RELU = 4,
+    FEWBIT_RELU6 = 5,
+    FEWBIT_SOFTSHRINK = 6, /* p0 = lambd */
+    FEWBIT_THRESHOLD = 7,  /* p0 = threshold, p1 = value */
+    FEWBIT_STEPWISE_COUNT = 8
+} fewbit_stepwise_fn;
+
+int fewbit_hip_abi_version(void);
+const char *fewbit_hip_last_error(void);
+
+/* k = ceil(log2(nlevels)), at least 1 */
+int fewbit_hip_bitwidth(int nlevels);
+/* k * ceil(n/8) */
+size_t fewbit_hip_state_nbytes(size_t n, int nbits);
+
+/*
+ * Fused forward: y[i] = fn(x[i]); code[i] = #{ j : borders[j] < x[i] } (NaN -> nborders);
+ * state = packed k-bit codes, k = fewbit_hip_bitwidth(nborders + 1).
+ *   x, y     n elements of `dtype`; y may alias x (in-place, as the reference op does)
+ *   state    fewbit_hip_state_nbytes(n, k) bytes, fully overwritten
+ *   borders  nborders INNER borders, ascending, same dtype as x (1 <= nborders <= 255)
+ */
+int fewbit_hip_quantize_forward(int fn, int dtype, const void *x, void *y, uint8_t *state, size_t n,
+                                const void *borders, int nborders, double p0, double p1, void *stream);
+
+/*
+ * Fused backward: gx[i] = levels[code[i]] * gy[i], product in fp32, rounded to nearest even.
+ *   levels   nlevels values of `dtype` (2 <= nlevels <= 256); k = fewbit_hip_bitwidth(nlevels)
+ *   gx may alias gy.
+ */
+int fewbit_hip_quantize_backward(int dtype, const void *gy, const uint8_t *state, void *gx, size_t n,
+                                 const void *levels, int nlevels, void *stream);
+
+/* 1-bit family forward: y = fn(x), state bit i = "derivative is the non-default branch" */
+int fewbit_hip_stepwise1_forward(int fn, int dtype, const void *x, void *y, uint8_t *state, size_t n, double p0,
+                                 double p1, void *stream);
+
+/* 1-bit family backward: gx = (bit ? m1 : m0) * gy; (m0,m1) = (0,1), hardsigmoid (0,1/6), leaky_relu (1,p0) */
+int fewbit_hip_stepwise1_backward(int fn, int dtype, const void *gy, const uint8_t *state, void *gx, size_t n,
+                                  double p0, void *stream);
+
+/* stand-alone codec (test seam): int32 codes <-> packed state, 1 <= nbits <= 8 */
+int fewbit_hip_pack_codes(const int32_t *codes, uint8_t *state, size_t n, int nbits, void *stream);
+int fewbit_hip_unpack_codes(const uint8_t *state, int32_t *codes, size_t n, int nbits, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEWBIT_HIP_H_ */
