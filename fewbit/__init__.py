@@ -1,0 +1,16 @@
+"""Drop-in alias: ``import fewbit`` resolves to the MI355X implementation in ``fewbit_amd`` with the module layout
+of the reference package (``fewbit.functional``, ``fewbit.functional.activations.store``, ``fewbit.modules``,
+``fewbit.util``)."""
+import sys
+
+import fewbit_amd
+from fewbit_amd import *  # noqa: F401,F403
+from fewbit_amd import functional, modules, util, store as _store_mod, map_module, memory_usage_hooks, __version__  # noqa: F401
+
+sys.modules[__name__ + '.functional'] = functional
+sys.modules[__name__ + '.functional.activations'] = functional
+sys.modules[__name__ + '.modules'] = modules
+sys.modules[__name__ + '.modules.activations'] = modules
+sys.modules[__name__ + '.util'] = util
+functional.activations = functional
+modules.activations = modules

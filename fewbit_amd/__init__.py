@@ -1,0 +1,55 @@
+"""fewbit_amd -- MI355X (gfx950) implementation of FewBit's quantized-activation backward path.
+
+``import fewbit`` (the thin alias package next to this one) gives the reference's surface:
+``fewbit.functional.*``, ``fewbit.GELU(bits=3)`` & co, ``fewbit.map_module`` and ``torch.ops.fewbit.*``.
+
+Native library: ``fewbit_amd/libfewbit.so`` (TORCH_LIBRARY(fewbit) glue) which links ``libfewbit_hip.so`` (HIP
+kernels + C-ABI).  As in the reference (fewbit/__init__.py:17-23) the environment variable ``FEWBIT_NATIVE`` in
+{0, no, false} skips loading it and a load failure is a ``RuntimeWarning``; unlike the reference there is no Python
+fallback for GPU tensors afterwards -- they raise (host tensors keep working through plain PyTorch).
+"""
+from os import getenv
+from pathlib import Path
+from warnings import warn
+
+import torch
+
+_NATIVE_PATH = Path(__file__).resolve().with_name('libfewbit.so')
+_native_error = 'not attempted'
+_native_loaded = False
+
+
+def native_loaded() -> bool:
+    return _native_loaded
+
+
+def native_error() -> str:
+    return _native_error
+
+
+def load_native(path=None) -> bool:
+    """Load the operator library (idempotent).  Returns True when ``torch.ops.fewbit`` is backed by it."""
+    global _native_loaded, _native_error
+    if _native_loaded:
+        return True
+    try:
+        torch.ops.load_library(str(path or _NATIVE_PATH))
+        torch.ops.fewbit.gelu  # noqa: B018  (AttributeError/RuntimeError if the registration is missing)
+        _native_loaded, _native_error = True, ''
+    except Exception as e:  # noqa: BLE001  -- OSError, RuntimeError, AttributeError all mean "not available"
+        _native_error = f'{type(e).__name__}: {e}'
+    return _native_loaded
+
+
+if getenv('FEWBIT_NATIVE') not in ('0', 'no', 'false'):
+    if not load_native():
+        warn(f'Failed to load ops library: {_native_error}.', RuntimeWarning)
+else:
+    _native_error = 'disabled by FEWBIT_NATIVE'
+
+from . import functional  # noqa: E402,F401
+from . import modules  # noqa: E402,F401
+from .modules import *  # noqa: E402,F401,F403
+from .util import map_module, memory_usage_hooks  # noqa: E402,F401
+
+__version__ = '0.1.0'

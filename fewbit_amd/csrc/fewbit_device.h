@@ -30,6 +30,15 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bits_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t f32_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
+// Product rounded to fp32 and kept as such.  Without the barrier hipcc contracts (fp16 -> fp32) * m -> fp16 into
+// v_fma_mixlo_f16 with a +0 addend, which turns a -0 product into +0 (the gradient of a negative gy through a
+// zero level must stay -0 to match the reference bit for bit).
+__device__ __forceinline__ float mul_f32(float a, float b) {
+    float r = a * b;
+    asm("" : "+v"(r));
+    return r;
+}
+
 // ------------------------------------------------------------------ scalar element I/O
 template <int DT> struct Elem;
 

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kerne
         const size_t e0 = g << 3;
         const uint32_t w = load_state<K>(state, g);
         for (int i = 0; i < 8; ++i)
-            if (e0 + i < n) Elem<DT>::store(gx, e0 + i, lut[(w >> (K * i)) & kMask] * Elem<DT>::load(gy, e0 + i));
+            if (e0 + i < n) Elem<DT>::store(gx, e0 + i, mul_f32(lut[(w >> (K * i)) & kMask], Elem<DT>::load(gy, e0 + i)));
     }
 }
 
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void quantize_backward_generic_kernel(const
     const uint32_t mask = (1u << nbits) - 1u;
     for (int i = 0; i < 8; ++i)
         if (e0 + i < n)
-            Elem<DT>::store(gx, e0 + i, lut[static_cast<uint32_t>(w >> (nbits * i)) & mask] * Elem<DT>::load(gy, e0 + i));
+            Elem<DT>::store(gx, e0 + i, mul_f32(lut[static_cast<uint32_t>(w >> (nbits * i)) & mask], Elem<DT>::load(gy, e0 + i)));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_backward_kern
         const size_t e0 = g << 3;
         const uint32_t w = load_state<1>(state, g);
         for (int i = 0; i < 8; ++i)
-            if (e0 + i < n) Elem<DT>::store(gx, e0 + i, (((w >> i) & 1u) ? m1 : m0) * Elem<DT>::load(gy, e0 + i));
+            if (e0 + i < n) Elem<DT>::store(gx, e0 + i, mul_f32(((w >> i) & 1u) ? m1 : m0, Elem<DT>::load(gy, e0 + i)));
     }
 }
 

@@ -1,0 +1,106 @@
+"""``fewbit.<Module>``: drop-in ``torch.nn`` activation modules with a few-bit backward.
+
+Mirror of fewbit/modules/activations.py: 21 classes generated from the matching ``torch.nn`` classes (constructor
+signature minus ``inplace``/``approximate`` plus keyword-only ``bits``; ``repr`` like ``GELU(bits=3)``) and
+``Stepwise`` for a custom table.
+"""
+import inspect
+from inspect import Parameter, Signature
+from typing import Optional, Tuple
+
+import torch
+
+from . import functional
+
+STEPWISE = ('Hardshrink', 'Hardsigmoid', 'Hardtanh', 'LeakyReLU', 'ReLU', 'ReLU6', 'Softshrink', 'Stepwise',
+            'Threshold')
+CONTINOUS = ('CELU', 'ELU', 'GELU', 'Hardswish', 'LogSigmoid', 'Mish', 'SELU', 'Sigmoid', 'SiLU', 'Softplus',
+             'Softsign', 'Tanh', 'Tanhshrink')
+
+__all__ = STEPWISE + CONTINOUS
+
+_PARAM_BITS = Parameter('bits', Parameter.KEYWORD_ONLY, default=None, annotation=Optional[int])
+
+
+class Stepwise(torch.nn.Module):
+    """Custom stepwise approximation: identity forward, ``levels[bucket(x)] * grad`` backward.
+
+    :param borders: inner borders of the intervals (or with both outer sentinels, which are then dropped).
+    :param levels: value of the derivative on every interval.
+    :param parity: declared by the reference, not implemented (must be None).
+    :param shift: declared by the reference, not implemented (must be None).
+    """
+
+    def __init__(self, borders: torch.Tensor, levels: torch.Tensor, parity: Optional[bool] = None,
+                 shift: Optional[Tuple[float, float]] = None):
+        if borders.ndim != 1 or levels.ndim != 1:
+            raise ValueError('Exepected number of dimensions of `borders` and `levels` is one.')
+        if borders.numel() > levels.numel():
+            borders = borders[1:-1]
+        if borders.numel() + 1 != levels.numel():
+            raise ValueError('Size of `borders` should be lesser than size of `levels` by one.')
+        if levels.numel() > 256:
+            raise ValueError('Maximal number of step limited to 256.')
+        super().__init__()
+        self.register_buffer('borders', borders, True)
+        self.register_buffer('levels', levels, True)
+        self.parity = parity
+        self.shift = shift
+
+    def forward(self, xs: torch.Tensor) -> torch.Tensor:
+        return functional.stepwise(xs, self.borders, self.levels, self.parity, self.shift)
+
+
+class BuiltInStepwiseFunction(torch.nn.Module):
+    """Base of the generated modules: binds the constructor arguments once, forwards them on every call."""
+
+    _impl_name: str = ''
+    _signature: Signature = Signature()
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        ref = getattr(torch.nn, cls.__name__)
+        sig = inspect.signature(ref.__init__)
+        params = list(sig.parameters.values())
+        # torch >= 2 declares some activations as (self, *args, **kwargs): keep `self` only
+        if len(params) == 3 and params[1].kind == Parameter.VAR_POSITIONAL and params[2].kind == Parameter.VAR_KEYWORD:
+            params = params[:1]
+        params = [p for p in params if p.name not in ('approximate', 'inplace')] + [_PARAM_BITS]
+        cls._signature = sig.replace(parameters=params)
+        cls._impl_name = 'leaky_relu' if cls.__name__ == 'LeakyReLU' else cls.__name__.lower()
+        cls._impl = staticmethod(getattr(functional, cls._impl_name))
+        accepted = inspect.signature(cls._impl).parameters
+        cls._forwarded = tuple(p.name for p in params[1:] if p.name in accepted)
+
+        def __init__(self, *args, **kwargs):
+            BuiltInStepwiseFunction.__init__(self, *args, **kwargs)
+
+        __init__.__signature__ = cls._signature
+        cls.__init__ = __init__
+        cls.__doc__ = (f'Few-bit :class:`torch.nn.{ref.__name__}`: same forward, backward from a ``bits``-bit code per '
+                       f'element (default 3; exact 1-bit state for piecewise-linear functions).\n\n'
+                       f'    See Also:\n        :class:`torch.nn.{ref.__name__}` -- Original PyTorch implementation.\n')
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        bound = self._signature.bind(self, *args, **kwargs)
+        bound.apply_defaults()
+        bound.arguments.pop('self')
+        self.reprs = []
+        for name, value in bound.arguments.items():
+            setattr(self, name, value)
+            self.reprs.append(f'{name}={value}')
+        # keyword arguments handed to the functional on every forward (only those it knows)
+        self.kwargs = {name: bound.arguments[name] for name in self._forwarded}
+
+    def __repr__(self) -> str:
+        return f'{type(self).__name__}({", ".join(self.reprs)})'
+
+    def forward(self, xs: torch.Tensor) -> torch.Tensor:
+        return self._impl(xs, **self.kwargs)
+
+
+for _name in __all__:
+    if _name not in globals():
+        globals()[_name] = type(_name, (BuiltInStepwiseFunction, ), {'__module__': __name__})
+del _name

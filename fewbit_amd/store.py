@@ -1,0 +1,77 @@
+"""Table store: (function, bits) -> (borders[2^k+1], levels[2^k]) with per-(device, dtype) casts cached.
+
+Mirrors the reference's ``StepwiseStore`` (fewbit/functional/activations.py:24-86): same methods, same npz
+key scheme ``{func}{bits:02d}-borders`` / ``-levels``, same KeyError for an unknown table, and the same cast
+``tensor.to(device, dtype)`` of the float64 tables (so the 16-bit borders are bit-identical to the reference's).
+"""
+from pathlib import Path
+from typing import Dict, Iterator, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+__all__ = ['StepwiseStore', 'store', 'BUILTIN_TABLES']
+
+BUILTIN_TABLES = Path(__file__).resolve().parent / 'data' / 'builtin.npz'
+
+Table = Tuple[torch.Tensor, torch.Tensor]
+
+
+class StepwiseStore:
+    """Stepwise approximations of activation-function derivatives, keyed by (name, bits)."""
+
+    def __init__(self):
+        self._store: Dict[Tuple[str, int], Table] = {}
+        self._cache: Dict[Tuple[str, int, torch.device, torch.dtype], Table] = {}
+
+    def __len__(self) -> int:
+        return len(self._store)
+
+    def __repr__(self) -> str:
+        return f'{type(self).__name__}(stored={len(self._store)}, cached={len(self._cache)})'
+
+    def __contains__(self, key: Tuple[str, int]) -> bool:
+        return tuple(key) in self._store
+
+    def add(self, name: str, bits: int, value: Table) -> None:
+        borders, values = value
+        if borders.ndim != 1 or values.ndim != 1 or borders.numel() != values.numel() + 1:
+            raise ValueError('Expected one-dimensional `borders` (with both sentinels) one longer than `levels`.')
+        entry = (borders, values.to(borders))
+        self._store[(name, int(bits))] = entry
+        # drop stale casts of a replaced table
+        for key in [k for k in self._cache if k[:2] == (name, int(bits))]:
+            del self._cache[key]
+        self._cache[(name, int(bits), borders.device, borders.dtype)] = entry
+
+    def get(self, name: str, bits: int, device: Union[None, str, torch.device] = None,
+            dtype: Optional[torch.dtype] = None) -> Table:
+        device = torch.device(device or 'cpu')
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        dtype = dtype or torch.float32
+        key = (name, bits, device, dtype)
+        hit = self._cache.get(key)
+        if hit is not None:
+            return hit
+        leaf = self._store.get((name, bits))
+        if leaf is None:
+            raise KeyError(f'There is not {bits}-bit quantized gradients for activation function {name}.')
+        cast = tuple(el.to(device, dtype) for el in leaf)
+        self._cache[key] = cast
+        return cast
+
+    def items(self, cached: bool = False) -> Iterator:
+        yield from (self._cache if cached else self._store).items()
+
+    def load(self, path: Union[str, Path]) -> 'StepwiseStore':
+        """Add every table of an npz file whose arrays are named ``{func}{bits:02d}-borders|levels``."""
+        with np.load(path) as npz:
+            for key in sorted({k.split('-', 1)[0] for k in npz.keys()}):
+                name, bits = key[:-2], int(key[-2:])
+                self.add(name, bits, (torch.tensor(npz[f'{key}-borders']), torch.tensor(npz[f'{key}-levels'])))
+        return self
+
+
+store = StepwiseStore()
+store.load(BUILTIN_TABLES)

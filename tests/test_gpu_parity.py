@@ -1,0 +1,322 @@
+"""Parity of the gfx950 kernels, called through the C-ABI (fewbit_amd.cabi -> libfewbit_hip.so), against
+  * golden vectors produced by running the reference (tests/golden/*.npz),
+  * the CPU oracle on seeded inputs with special values spliced in,
+  * size-independent properties at BASELINE.json's full sizes.
+Bar: packed codes, unpacked codes and gradients bit-exact; forward values within helpers.forward_value_ok."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from fewbit_amd import cabi
+from fewbit_amd.sharding import shard_range, state_range
+from fewbit_amd.store import store
+from helpers import DTYPES, GOLDEN, assert_bit_equal, forward_value_ok, from_raw
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+PARAMS = {'celu': (1.3,), 'elu': (0.7,), 'softplus': (2.0, 5.0)}
+
+
+@pytest.fixture(scope='module')
+def qref():
+    with np.load(GOLDEN / 'quantize_ref.npz') as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope='module')
+def cref():
+    with np.load(GOLDEN / 'codec_ref.npz') as z:
+        return {k: z[k] for k in z.files}
+
+
+def make_x(n, dtype, borders, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(n, generator=g) * 1.5).to(dtype)
+    gy = torch.randn(n, generator=g).to(dtype)
+    if n >= 64:
+        iv = torch.int32 if dtype == torch.float32 else torch.int16
+        b = borders.to(dtype)
+        sp = torch.cat([torch.tensor([float('nan'), float('inf'), -float('inf'), 0.0, -0.0, 100.0, -100.0, 200.0,
+                                      -200.0, 1e-30, -1e-30, 6.0, -6.0, 12.0, -12.0]).to(dtype),
+                        b, (b.view(iv) + 1).view(dtype), (b.view(iv) - 1).view(dtype),
+                        torch.tensor([-1], dtype=iv).view(dtype)])                       # negative NaN
+        m = min(sp.numel(), n // 2)
+        x[n // 3:n // 3 + m] = sp[:m]
+    return x, gy
+
+
+def test_library_is_the_hip_build():
+    assert cabi.lib().fewbit_hip_abi_version() == 1
+    assert cabi.LIB_PATH.name.startswith('libfewbit_hip')
+
+
+@pytest.mark.parametrize('k', (2, 3, 4))
+@pytest.mark.parametrize('dt', list(DTYPES))
+def test_golden_vectors_from_reference_run(qref, k, dt):
+    dtype = DTYPES[dt]
+    borders = from_raw(qref[f'gelu{k:02d}_{dt}_borders'], dtype).to(DEV)
+    levels = from_raw(qref[f'gelu{k:02d}_{dt}_levels'], dtype).to(DEV)
+    for n in (1, 7, 8, 9, 64, 65, 257, 1001):
+        key = f'gelu{k:02d}_{dt}_{n}'
+        x, gy = from_raw(qref[key + '_x'], dtype), from_raw(qref[key + '_gy'], dtype)
+        y, state = cabi.quantize_forward('gelu', x.to(DEV), borders)
+        want = torch.from_numpy(qref[key + '_state'])
+        assert state.numel() == k * ((n + 7) // 8)
+        assert_bit_equal(state.cpu()[:want.numel()], want, key + ' state')
+        assert not state.cpu()[want.numel():].any()
+        gx = cabi.quantize_backward(gy.to(DEV), state, levels)
+        assert_bit_equal(gx.cpu(), from_raw(qref[key + '_gx'], dtype), key + ' gx')
+        ok = forward_value_ok(x, y.cpu(), from_raw(qref[key + '_y'], dtype))
+        assert ok.all(), (key, x[~ok][:4], y.cpu()[~ok][:4])
+
+
+@pytest.mark.parametrize('name,k,dt,n', [('silu', 2, 'f16', 1001), ('silu', 4, 'f16', 1001), ('tanh', 3, 'f32', 257)])
+def test_golden_other_tables(qref, name, k, dt, n):
+    dtype = DTYPES[dt]
+    key = f'{name}{k:02d}_{dt}_{n}'
+    borders = from_raw(qref[f'{name}{k:02d}_{dt}_borders'], dtype).to(DEV)
+    levels = from_raw(qref[f'{name}{k:02d}_{dt}_levels'], dtype).to(DEV)
+    x, gy = from_raw(qref[key + '_x'], dtype), from_raw(qref[key + '_gy'], dtype)
+    _, state = cabi.quantize_forward(name, x.to(DEV), borders)
+    want = torch.from_numpy(qref[key + '_state'])
+    assert_bit_equal(state.cpu()[:want.numel()], want, key + ' state')
+    assert_bit_equal(cabi.quantize_backward(gy.to(DEV), state, levels).cpu(), from_raw(qref[key + '_gx'], dtype), key)
+
+
+@pytest.mark.parametrize('k', range(1, 9))
+def test_codec_kernels_golden(cref, k):
+    for n in (1, 5, 8, 11, 64, 256, 1001):
+        codes = torch.from_numpy(cref[f'k{k}_n{n}_codes'].astype(np.int32))
+        want = torch.from_numpy(cref[f'k{k}_n{n}_bytes'])
+        state = cabi.pack_codes(codes.to(DEV), k)
+        assert_bit_equal(state.cpu()[:want.numel()], want, f'pack k{k} n{n}')
+        assert_bit_equal(cabi.unpack_codes(state, n, k).cpu(), codes, f'unpack k{k} n{n}')
+
+
+@pytest.mark.parametrize('dt', list(DTYPES))
+def test_relu_1bit_golden(cref, dt):
+    dtype = DTYPES[dt]
+    x = from_raw(cref[f'relu01_{dt}_x'], dtype)
+    gy = from_raw(cref[f'relu01_{dt}_gy'], dtype)
+    y, state = cabi.stepwise1_forward('relu', x.to(DEV))
+    assert_bit_equal(state.cpu(), torch.from_numpy(cref[f'relu01_{dt}_state']), 'relu state')
+    y_ref = from_raw(cref[f'relu01_{dt}_y'], dtype)
+    assert ((y.cpu() == y_ref) | (torch.isnan(y.cpu()) & torch.isnan(y_ref))).all()
+    gx = cabi.stepwise1_backward('relu', gy.to(DEV), state)
+    assert_bit_equal(gx.cpu(), oracle.stepwise1_backward('relu', gy, state.cpu()), 'relu gx')
+
+
+SIZES = (1, 7, 8, 9, 63, 511, 512, 513, 1023, 1025, 4097, 100003)
+
+
+@pytest.mark.parametrize('k', (1, 2, 3, 4))
+@pytest.mark.parametrize('dt', list(DTYPES))
+@pytest.mark.parametrize('name', ('gelu', 'silu'))
+def test_forward_backward_vs_oracle(name, dt, k):
+    dtype = DTYPES[dt]
+    borders, levels = store.get(name, k, 'cpu', dtype)
+    inner = borders[1:-1].contiguous()
+    for n in SIZES:
+        x, gy = make_x(n, dtype, inner, seed=17 * n + k)
+        y_o, s_o, kk = oracle.quantize(name, x, inner)
+        gx_o = oracle.quantize_backward(gy, s_o, levels)
+        state = torch.full((cabi.state_nbytes(n, k),), 0xFF, dtype=torch.uint8, device=DEV)   # must be fully overwritten
+        y, state = cabi.quantize_forward(name, x.to(DEV), inner.to(DEV), state=state)
+        gx = cabi.quantize_backward(gy.to(DEV), state, levels.to(DEV))
+        tag = f'{name} {dt} k{k} n{n}'
+        assert kk == k
+        assert_bit_equal(state.cpu(), s_o, tag + ' state')
+        assert_bit_equal(gx.cpu(), gx_o, tag + ' gx')
+        ok = forward_value_ok(x, y.cpu(), y_o)
+        assert ok.all(), (tag, x[~ok][:4], y.cpu()[~ok][:4], y_o[~ok][:4])
+        assert_bit_equal(cabi.unpack_codes(state, n, k).cpu(), oracle.searchsorted(x, inner).to(torch.int32), tag + ' codes')
+
+
+@pytest.mark.parametrize('name', [f for f in cabi.CONTINUOUS if f not in ('gelu', 'silu', 'identity')])
+@pytest.mark.parametrize('dt', list(DTYPES))
+def test_remaining_continuous_functions(name, dt):
+    dtype = DTYPES[dt]
+    p = PARAMS.get(name, ())
+    borders, levels = store.get(name, 3, 'cpu', dtype)
+    inner = borders[1:-1].contiguous()
+    for n in (9, 1023, 4097):
+        x, gy = make_x(n, dtype, inner, seed=n)
+        y_o, s_o, _ = oracle.quantize(name, x, inner, *p)
+        y, state = cabi.quantize_forward(name, x.to(DEV), inner.to(DEV), *p)
+        assert_bit_equal(state.cpu(), s_o, f'{name} {dt} state')
+        assert_bit_equal(cabi.quantize_backward(gy.to(DEV), state, levels.to(DEV)).cpu(),
+                         oracle.quantize_backward(gy, s_o, levels), f'{name} {dt} gx')
+        # values: libm (oracle) vs ocml (device), both ~1 ulp: 4 fp32 steps of slack, or 1 step of a 16-bit output
+        yd, fin = y.cpu(), torch.isfinite(x.float()) & torch.isfinite(y_o.float())
+        if dtype == torch.float32:
+            err = (yd.double() - y_o.double()).abs()[fin]
+            assert (err <= 4 * 2.0**-23 * torch.maximum(y_o.double().abs(), x.double().abs())[fin] + 1e-37).all(), name
+        else:
+            assert forward_value_ok(x, yd, y_o).all(), name
+
+
+STEP_CASES = [('hardshrink', ()), ('hardshrink', (1.0,)), ('hardsigmoid', ()), ('hardtanh', (-1.0, 1.0)),
+              ('hardtanh', (-2.0, 2.0)), ('leaky_relu', (0.01,)), ('leaky_relu', (0.5,)), ('relu', ()), ('relu6', ()),
+              ('softshrink', (0.5,)), ('softshrink', (1.0,)), ('threshold', (1.0, 3.0))]
+
+
+@pytest.mark.parametrize('name,p', STEP_CASES)
+@pytest.mark.parametrize('dt', list(DTYPES))
+def test_stepwise1_family_vs_oracle(name, p, dt):
+    dtype = DTYPES[dt]
+    for n in (1, 9, 511, 513, 4097, 100003):
+        g = torch.Generator().manual_seed(n)
+        x = (torch.randn(n, generator=g) * 3).to(dtype)
+        gy = torch.randn(n, generator=g).to(dtype)
+        if n > 64:
+            x[:8] = torch.tensor([0.0, -0.0, float('nan'), float('inf'), -float('inf'), 3.0, -3.0, 6.0]).to(dtype)
+            x[8:8 + len(p)] = torch.tensor(p).to(dtype)
+        y_o, s_o = oracle.stepwise1_forward(name, x, *p)
+        y, state = cabi.stepwise1_forward(name, x.to(DEV), *p)
+        assert_bit_equal(state.cpu(), s_o, f'{name} {dt} n{n} state')
+        yd = y.cpu()
+        assert ((yd == y_o) | (torch.isnan(yd) & torch.isnan(y_o))).all(), f'{name} {dt} n{n} values'
+        bp = p[:1] if name == 'leaky_relu' else ()
+        assert_bit_equal(cabi.stepwise1_backward(name, gy.to(DEV), state, *bp).cpu(),
+                         oracle.stepwise1_backward(name, gy, s_o, *bp), f'{name} {dt} n{n} gx')
+
+
+def test_empty_input_and_in_place_and_misaligned():
+    dtype = torch.bfloat16
+    borders, levels = store.get('gelu', 3, DEV, dtype)
+    inner = borders[1:-1].contiguous()
+    e = torch.empty(0, dtype=dtype, device=DEV)
+    y, st = cabi.quantize_forward('gelu', e, inner)
+    assert y.numel() == 0 and st.numel() == 0 and cabi.quantize_backward(e, st, levels).numel() == 0
+    # in place (y aliases x), as the reference op runs
+    x, gy = make_x(20011, dtype, inner.cpu(), 5)
+    y_o, s_o, _ = oracle.quantize('gelu', x, inner.cpu())
+    xd = x.to(DEV)
+    y, st = cabi.quantize_forward('gelu', xd, inner, out=xd)
+    assert y.data_ptr() == xd.data_ptr()
+    assert_bit_equal(st.cpu(), s_o, 'in-place state')
+    assert forward_value_ok(x, xd.cpu(), y_o).all()
+    gyd = gy.to(DEV)
+    gx = cabi.quantize_backward(gyd, st, levels, out=gyd)
+    assert_bit_equal(gyd.cpu(), oracle.quantize_backward(gy, s_o, levels.cpu()), 'in-place gx')
+    # misaligned views: data / state pointers that are not 16 / 4 byte aligned take the generic kernels
+    base = torch.zeros(20011 + 8, dtype=dtype, device=DEV)
+    for off in (1, 3):
+        xv = base[off:off + 20011]
+        xv.copy_(x)
+        sbuf = torch.zeros(cabi.state_nbytes(20011, 3) + 4, dtype=torch.uint8, device=DEV)
+        for soff in (0, 1):
+            y, st = cabi.quantize_forward('gelu', xv, inner, state=sbuf[soff:soff + cabi.state_nbytes(20011, 3)])
+            assert_bit_equal(st.cpu(), s_o, f'misaligned x+{off} state+{soff}')
+            gv = torch.zeros(20011 + 8, dtype=dtype, device=DEV)[off:off + 20011]
+            gv.copy_(gy)
+            assert_bit_equal(cabi.quantize_backward(gv, st, levels).cpu(), oracle.quantize_backward(gy, s_o, levels.cpu()), 'mis gx')
+    # 1-bit family, misaligned
+    xs, ss = oracle.stepwise1_forward('relu', x)
+    xv = base[1:1 + 20011]
+    xv.copy_(x)
+    y, st = cabi.stepwise1_forward('relu', xv)
+    assert_bit_equal(st.cpu(), ss, 'misaligned relu state')
+
+
+@pytest.mark.parametrize('nlevels', (2, 3, 5, 8, 9, 17, 33, 100, 256))
+def test_custom_tables_any_size(nlevels):
+    """Non power-of-two level counts and wide codes (up to 8 bits) go through the generic kernels."""
+    g = torch.Generator().manual_seed(nlevels)
+    for dtype in (torch.float32, torch.bfloat16):
+        inner = torch.sort(torch.randn(nlevels - 1, generator=g) * 1.5).values.to(dtype).unique()
+        if inner.numel() != nlevels - 1:
+            inner = torch.linspace(-3, 3, nlevels - 1).to(dtype)
+        levels = torch.randn(nlevels, generator=g).to(dtype)
+        x, gy = make_x(5003, dtype, inner, nlevels)
+        y_o, s_o, k = oracle.quantize('identity' if False else 'tanh', x, inner)
+        _, st = cabi.quantize_forward('tanh', x.to(DEV), inner.to(DEV))
+        assert st.numel() == k * ((5003 + 7) // 8)
+        assert_bit_equal(st.cpu(), s_o, f'custom {nlevels} state')
+        assert_bit_equal(cabi.quantize_backward(gy.to(DEV), st, levels.to(DEV)).cpu(),
+                         oracle.quantize_backward(gy, s_o, levels), f'custom {nlevels} gx')
+    # identity forward (the `stepwise` op)
+    y, st = cabi.quantize_forward('identity', x.to(DEV), inner.to(DEV))
+    assert_bit_equal(y.cpu(), x, 'identity')
+
+
+def test_argument_errors_are_reported():
+    x = torch.zeros(16, dtype=torch.float32, device=DEV)
+    with pytest.raises(cabi.FewbitHipError):
+        cabi.quantize_forward('gelu', x, torch.zeros(3, dtype=torch.bfloat16, device=DEV))       # dtype mismatch
+    with pytest.raises(cabi.FewbitHipError):
+        cabi.quantize_forward('gelu', torch.zeros(16), torch.zeros(3))                            # host tensors
+    L = cabi.lib()
+    assert L.fewbit_hip_quantize_forward(99, 0, x.data_ptr(), x.data_ptr(), x.data_ptr(), 16, x.data_ptr(), 3, 0.0, 0.0, 0) < 0
+    assert b'unknown continuous fn' in L.fewbit_hip_last_error()
+    assert L.fewbit_hip_quantize_forward(2, 0, x.data_ptr(), x.data_ptr(), x.data_ptr(), 16, x.data_ptr(), 300, 0.0, 0.0, 0) < 0
+    assert L.fewbit_hip_pack_codes(x.data_ptr(), x.data_ptr(), 16, 9, 0) < 0
+
+
+# --------------------------------------------------------------------------------------- full BASELINE sizes
+def _full_case(name, k, dtype, shape, seed=0):
+    torch.manual_seed(seed)
+    x = torch.randn(shape).to(dtype).flatten()
+    torch.manual_seed(seed + 1)
+    gy = torch.randn(shape).to(dtype).flatten()
+    borders, levels = store.get(name, k, 'cpu', dtype)
+    return x, gy, borders[1:-1].contiguous(), levels
+
+
+@pytest.mark.parametrize('name,k,dt,shape', [('gelu', 3, 'bf16', (4096, 4096)), ('silu', 2, 'f16', (8192, 8192)),
+                                             ('silu', 4, 'f16', (8192, 8192)), ('gelu', 3, 'bf16', (8192, 4096))])
+def test_full_size_properties(name, k, dt, shape):
+    dtype = DTYPES[dt]
+    x, gy, inner, levels = _full_case(name, k, dtype, shape)
+    n = x.numel()
+    xd, gyd, bd, ld = x.to(DEV), gy.to(DEV), inner.to(DEV), levels.to(DEV)
+    y, state = cabi.quantize_forward(name, xd, bd)
+    gx = cabi.quantize_backward(gyd, state, ld)
+    # (1) codes == an independent bucketing of the same inputs (torch.bucketize on the GPU, right=False)
+    codes = cabi.unpack_codes(state, n, k)
+    assert torch.equal(codes, torch.bucketize(xd.float(), bd.float(), out_int32=True))
+    # (2) pack(unpack(state)) == state  and  gx == levels[codes] * gy computed by torch in fp32
+    assert torch.equal(cabi.pack_codes(codes, k), state)
+    assert torch.equal(gx.view(torch.int16), (ld.float()[codes.long()] * gyd.float()).to(dtype).view(torch.int16))
+    # (3) oracle on a window that straddles the middle; checksum of the whole state vs the oracle's checksum of checksums
+    lo = (n // 2 // 512) * 512 - 512 * 100
+    win = slice(lo, lo + 512 * 300)
+    y_o, s_o, _ = oracle.quantize(name, x[win], inner)
+    sb, se = state_range(win.start, win.stop, k)
+    assert_bit_equal(state[sb:se].cpu(), s_o, 'window state')
+    assert_bit_equal(gx[win].cpu(), oracle.quantize_backward(gy[win], s_o, levels), 'window gx')
+    assert forward_value_ok(x[win], y[win].cpu(), y_o).all()
+    # (4) linearity of backward in gy (x2 is exact in binary floating point) and determinism
+    # (exact wherever both results are normal numbers of the dtype: fp16 subnormals have a fixed spacing)
+    g2 = cabi.quantize_backward(gyd * 2, state, ld)
+    normal = (gx.float().abs() >= 2.0**-13) & (g2.float().abs() < 6e4)
+    assert torch.equal(g2[normal].view(torch.int16), (gx * 2)[normal].view(torch.int16)) and normal.float().mean() > 0.9
+    _, state2 = cabi.quantize_forward(name, xd, bd)
+    assert torch.equal(state, state2)
+    # (5) in place == out of place
+    xi = xd.clone()
+    _, state3 = cabi.quantize_forward(name, xi, bd, out=xi)
+    assert torch.equal(state3, state) and torch.equal(xi.view(torch.int16), y.view(torch.int16))
+    # (6) eight shards with their own launches (what 8 GPUs do) == the unsharded result, byte for byte
+    y8, s8, gx8 = torch.empty_like(y), torch.empty_like(state), torch.empty_like(gx)
+    for r in range(8):
+        b, e = shard_range(n, 8, r)
+        sb, se = state_range(b, e, k)
+        cabi.quantize_forward(name, xd[b:e], bd, out=y8[b:e], state=s8[sb:se])
+        cabi.quantize_backward(gyd[b:e], s8[sb:se], ld, out=gx8[b:e])
+    assert torch.equal(s8, state) and torch.equal(y8.view(torch.int16), y.view(torch.int16))
+    assert torch.equal(gx8.view(torch.int16), gx.view(torch.int16))
+
+
+def test_relu_config1_full_size():
+    # BASELINE configs[0]: relu 1-bit, 1024x1024 fp32 -- whole tensor against the oracle
+    torch.manual_seed(0)
+    x = torch.randn(1024 * 1024)
+    gy = torch.randn(1024 * 1024)
+    y_o, s_o = oracle.stepwise1_forward('relu', x)
+    y, st = cabi.stepwise1_forward('relu', x.to(DEV))
+    assert_bit_equal(st.cpu(), s_o, 'relu state')
+    assert torch.equal(y.cpu(), y_o)
+    assert_bit_equal(cabi.stepwise1_backward('relu', gy.to(DEV), st).cpu(), oracle.stepwise1_backward('relu', gy, s_o), 'gx')
+    assert int(st.cpu().to(torch.int64).sum()) == int(s_o.to(torch.int64).sum())
