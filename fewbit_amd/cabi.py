@@ -12,7 +12,7 @@ import torch
 
 __all__ = [
     'CONTINUOUS', 'STEPWISE1', 'LIB_PATH', 'lib', 'loaded', 'bitwidth', 'state_nbytes', 'quantize_forward',
-    'quantize_backward', 'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError',
+    'quantize_backward', 'bind_forward', 'bind_backward', 'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError',
 ]
 
 import os
@@ -129,6 +129,47 @@ def quantize_backward(gy: torch.Tensor, state: torch.Tensor, levels: torch.Tenso
     _check(lib().fewbit_hip_quantize_backward(DTYPES[gy.dtype], gy.data_ptr(), state.data_ptr(), gx.data_ptr(),
                                               gy.numel(), levels.data_ptr(), levels.numel(), _stream(stream)))
     return gx
+
+
+def bind_forward(fn: str, x: torch.Tensor, borders: torch.Tensor, out: torch.Tensor, state: torch.Tensor,
+                 p0: float = 0.0, p1: float = 0.0, stream: Optional[int] = None):
+    """Pre-resolved launch: returns a zero-argument callable that enqueues exactly this forward (same pointers,
+    same stream) -- for loops where the per-call Python argument handling would otherwise out-weigh a ~10 us kernel."""
+    x, borders, out, state = _dev(x, 'x'), _dev(borders, 'borders'), _dev(out, 'out'), _dev(state, 'state')
+    if borders.dtype != x.dtype or out.dtype != x.dtype:
+        raise FewbitHipError('x, borders and out must share one dtype')
+    k = bitwidth(borders.numel() + 1)
+    if state.numel() < state_nbytes(x.numel(), k) or out.numel() != x.numel():
+        raise FewbitHipError('out/state buffers do not match the input size')
+    f = lib().fewbit_hip_quantize_forward
+    args = (CONTINUOUS.index(fn), DTYPES[x.dtype], x.data_ptr(), out.data_ptr(), state.data_ptr(), x.numel(),
+            borders.data_ptr(), borders.numel(), p0, p1, _stream(stream))
+
+    def launch():
+        if f(*args):
+            _check(-1)
+    launch.keepalive = (x, borders, out, state)
+    return launch
+
+
+def bind_backward(gy: torch.Tensor, state: torch.Tensor, levels: torch.Tensor, out: torch.Tensor,
+                  stream: Optional[int] = None):
+    """Pre-resolved launch of the backward, see bind_forward."""
+    gy, state, levels, out = _dev(gy, 'gy'), _dev(state, 'state'), _dev(levels, 'levels'), _dev(out, 'out')
+    if levels.dtype != gy.dtype or out.dtype != gy.dtype:
+        raise FewbitHipError('gy, levels and out must share one dtype')
+    k = bitwidth(levels.numel())
+    if state.numel() < state_nbytes(gy.numel(), k) or out.numel() != gy.numel():
+        raise FewbitHipError('out/state buffers do not match the input size')
+    f = lib().fewbit_hip_quantize_backward
+    args = (DTYPES[gy.dtype], gy.data_ptr(), state.data_ptr(), out.data_ptr(), gy.numel(), levels.data_ptr(),
+            levels.numel(), _stream(stream))
+
+    def launch():
+        if f(*args):
+            _check(-1)
+    launch.keepalive = (gy, state, levels, out)
+    return launch
 
 
 def stepwise1_forward(fn: str, x: torch.Tensor, p0: float = 0.0, p1: float = 0.0,
