@@ -6,6 +6,18 @@
 using namespace fewbit_hip;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
+// plain C++ bucket: binary search, bits materialised with selects of inline constants, no v_addc
+__device__ __forceinline__ uint32_t code_k3(const float (&b)[7], float x) {
+    const bool A = !(b[3] >= x);
+    const float t = A ? b[5] : b[1];
+    const bool B = !(t >= x);
+    const float p = A ? b[4] : b[0];
+    const float q = A ? b[6] : b[2];
+    const float t0 = B ? q : p;
+    const bool C = !(t0 >= x);
+    return (A ? 4u : 0u) | (B ? 2u : 0u) | (C ? 1u : 0u);
+}
+
 template <int MODE> __global__ __launch_bounds__(256, 8) void k(float* out, const float* bp, int iters) {
     float b[7];
     for (int j = 0; j < 7; ++j) b[j] = bp[j];
@@ -29,6 +41,14 @@ template <int MODE> __global__ __launch_bounds__(256, 8) void k(float* out, cons
                 if (MODE == 34 || MODE == 35) rl = relu_raw(x[i]);
                 x[i] = __builtin_fmaf(-a, h, rl);
             }
+        } else if (MODE == 40 || MODE == 41) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                w |= code_k3(b, x[i]) << (3 * i);
+                if (MODE == 41) x[i] = gelu_fast(x[i]);
+            }
+            acc += w;
         } else if (MODE == 16) {  // interleaved per pair: bucket(pair) then gelu(pair)
             uint32_t w = 0;
 #pragma unroll
@@ -71,6 +91,6 @@ template <int MODE> int run(const char* name, float* out, float* bp) {
 int main() {
     float* out; CHECK(hipMalloc(&out, 256 * 8 * 256 * 4));
     float hb[7] = {-2.4f, -0.71f, -0.326f, 1e-4f, 0.326f, 0.71f, 2.41f}; float* bp; CHECK(hipMalloc(&bp, 28)); CHECK(hipMemcpy(bp, hb, 28, hipMemcpyHostToDevice));
-    run<0>("overhead only (8 adds)", out, bp); run<1>("bucket+pack k3", out, bp); run<2>("gelu_fast", out, bp); run<3>("bucket+pack + gelu", out, bp); run<7>("bucket+pack + gelu + cvt", out, bp); run<32>("gelu: poly only (9 fma)", out, bp); run<33>("gelu: poly + exp", out, bp); run<34>("gelu: poly + max", out, bp); run<35>("gelu: poly+exp+max", out, bp); run<16>("interleaved per pair", out, bp); run<17>("skewed per pair", out, bp);
+    run<0>("overhead only (8 adds)", out, bp); run<1>("bucket+pack k3", out, bp); run<2>("gelu_fast", out, bp); run<3>("bucket+pack + gelu", out, bp); run<7>("bucket+pack + gelu + cvt", out, bp); run<32>("gelu: poly only (9 fma)", out, bp); run<33>("gelu: poly + exp", out, bp); run<34>("gelu: poly + max", out, bp); run<35>("gelu: poly+exp+max", out, bp); run<40>("c++ bucket (no addc)", out, bp); run<41>("c++ bucket + gelu", out, bp); run<16>("interleaved per pair", out, bp); run<17>("skewed per pair", out, bp);
     return 0;
 }

@@ -243,6 +243,32 @@ template <int OP> __global__ __launch_bounds__(256) void bench(float* out, int i
 #define X(i) asm volatile("v_fmamk_f32 %0, %0, 0x3f9d70a4, %1" : "+v"(a##i) : "v"(b));
                 REP8(X)
 #undef X
+            } else if (OP == 70) {  // pairs: v_cmp->sgpr + fma
+#define X(i) asm volatile("v_cmp_nge_f32_e64 %1, %0, %2\n v_fma_f32 %0, %0, %2, %3" : "+v"(a##i), "=s"(m) : "v"(b), "v"(c));
+                REP8(X)
+#undef X
+            } else if (OP == 71) {  // pairs: v_addc(sgpr carry) + fma
+#define X(i) asm volatile("v_addc_co_u32_e64 %0, vcc, %0, %0, %1\n v_fma_f32 %0, %0, %2, %3" : "+v"(a##i) : "s"(m), "v"(b), "v"(c) : "vcc");
+                REP8(X)
+#undef X
+            } else if (OP == 72) {  // pairs: v_max + fma
+#define X(i) asm volatile("v_max_f32 %0, %0, %1\n v_fma_f32 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+                REP8(X)
+#undef X
+            } else if (OP == 73) {  // triples: cmp, cndmask, addc then 3 fma
+#define X(i) asm volatile("v_cmp_nge_f32_e64 %1, %0, %2\n v_fma_f32 %0, %0, %2, %3\n s_nop 0\n v_cndmask_b32_e64 %0, %0, %2, %1\n v_fma_f32 %0, %0, %2, %3\n v_addc_co_u32_e64 %0, vcc, %0, %0, %1\n v_fma_f32 %0, %0, %2, %3" : "+v"(a##i), "=&s"(m) : "v"(b), "v"(c) : "vcc");
+                REP8(X)
+#undef X
+            } else if (OP == 80 || OP == 81 || OP == 82) {
+                unsigned long long mAa, mAb, mBa, mBb, mCa, mCb; float ta, tb, pa, pb, qa, qb; unsigned wacc = 0;
+                if (OP == 80) { asm volatile("v_cmp_nge_f32_e64 %[mAa], %[b3], %[xa]\nv_cmp_nge_f32_e64 %[mAb], %[b3], %[xb]\nv_cndmask_b32_e64 %[pa], %[b0], %[b4], %[mAa]\nv_cndmask_b32_e64 %[pb], %[b0], %[b4], %[mAb]\nv_cndmask_b32_e64 %[ta], %[b1], %[b5], %[mAa]\nv_cndmask_b32_e64 %[tb], %[b1], %[b5], %[mAb]\nv_cmp_nge_f32_e64 %[mBa], %[ta], %[xa]\nv_cmp_nge_f32_e64 %[mBb], %[tb], %[xb]\nv_cndmask_b32_e64 %[qa], %[b2], %[b6], %[mAa]\nv_cndmask_b32_e64 %[qb], %[b2], %[b6], %[mAb]\nv_cndmask_b32_e64 %[ta], %[pa], %[qa], %[mBa]\nv_cndmask_b32_e64 %[tb], %[pb], %[qb], %[mBb]\nv_cmp_nge_f32_e64 %[mCa], %[ta], %[xa]\nv_cmp_nge_f32_e64 %[mCb], %[tb], %[xb]\nv_cndmask_b32_e64 %[pa], 0, 4, %[mAa]\nv_cndmask_b32_e64 %[pb], 0, 4, %[mAb]\nv_cndmask_b32_e64 %[qa], 0, 2, %[mBa]\nv_cndmask_b32_e64 %[qb], 0, 2, %[mBb]\nv_cndmask_b32_e64 %[ta], 0, 1, %[mCa]\nv_cndmask_b32_e64 %[tb], 0, 1, %[mCb]\nv_or3_b32 %[pa], %[pa], %[qa], %[ta]\nv_or3_b32 %[pb], %[pb], %[qb], %[tb]\nv_lshl_or_b32 %[w], %[w], 3, %[pa]\nv_lshl_or_b32 %[w], %[w], 3, %[pb]" : [w] "+v"(wacc), [f0] "+v"(a4), [f1] "+v"(a5), [f2] "+v"(a6), [f3] "+v"(a7), [mAa] "=&s"(mAa), [mAb] "=&s"(mAb), [mBa] "=&s"(mBa), [mBb] "=&s"(mBb), [mCa] "=&s"(mCa), [mCb] "=&s"(mCb), [ta] "=&v"(ta), [tb] "=&v"(tb), [pa] "=&v"(pa), [pb] "=&v"(pb), [qa] "=&v"(qa), [qb] "=&v"(qb) : [xa] "v"(a0), [xb] "v"(a1), [b0] "v"(b), [b1] "v"(c), [b2] "v"(a2), [b3] "v"(a3), [b4] "v"(b), [b5] "v"(c), [b6] "v"(a2)); }
+                if (OP == 81) { asm volatile("v_cmp_nge_f32_e64 %[mAa], %[b3], %[xa]\nv_fma_f32 %[f0], %[f0], %[xa], %[xb]\nv_cmp_nge_f32_e64 %[mAb], %[b3], %[xb]\nv_fma_f32 %[f1], %[f1], %[xa], %[xb]\nv_cndmask_b32_e64 %[pa], %[b0], %[b4], %[mAa]\nv_fma_f32 %[f2], %[f2], %[xa], %[xb]\nv_cndmask_b32_e64 %[pb], %[b0], %[b4], %[mAb]\nv_fma_f32 %[f3], %[f3], %[xa], %[xb]\nv_cndmask_b32_e64 %[ta], %[b1], %[b5], %[mAa]\nv_fma_f32 %[f0], %[f0], %[xa], %[xb]\nv_cndmask_b32_e64 %[tb], %[b1], %[b5], %[mAb]\nv_fma_f32 %[f1], %[f1], %[xa], %[xb]\nv_cmp_nge_f32_e64 %[mBa], %[ta], %[xa]\nv_fma_f32 %[f2], %[f2], %[xa], %[xb]\nv_cmp_nge_f32_e64 %[mBb], %[tb], %[xb]\nv_fma_f32 %[f3], %[f3], %[xa], %[xb]\nv_cndmask_b32_e64 %[qa], %[b2], %[b6], %[mAa]\nv_fma_f32 %[f0], %[f0], %[xa], %[xb]\nv_cndmask_b32_e64 %[qb], %[b2], %[b6], %[mAb]\nv_fma_f32 %[f1], %[f1], %[xa], %[xb]\nv_cndmask_b32_e64 %[ta], %[pa], %[qa], %[mBa]\nv_fma_f32 %[f2], %[f2], %[xa], %[xb]\nv_cndmask_b32_e64 %[tb], %[pb], %[qb], %[mBb]\nv_fma_f32 %[f3], %[f3], %[xa], %[xb]\nv_cmp_nge_f32_e64 %[mCa], %[ta], %[xa]\nv_fma_f32 %[f0], %[f0], %[xa], %[xb]\nv_cmp_nge_f32_e64 %[mCb], %[tb], %[xb]\nv_fma_f32 %[f1], %[f1], %[xa], %[xb]\nv_cndmask_b32_e64 %[pa], 0, 4, %[mAa]\nv_fma_f32 %[f2], %[f2], %[xa], %[xb]\nv_cndmask_b32_e64 %[pb], 0, 4, %[mAb]\nv_fma_f32 %[f3], %[f3], %[xa], %[xb]\nv_cndmask_b32_e64 %[qa], 0, 2, %[mBa]\nv_fma_f32 %[f0], %[f0], %[xa], %[xb]\nv_cndmask_b32_e64 %[qb], 0, 2, %[mBb]\nv_fma_f32 %[f1], %[f1], %[xa], %[xb]\nv_cndmask_b32_e64 %[ta], 0, 1, %[mCa]\nv_fma_f32 %[f2], %[f2], %[xa], %[xb]\nv_cndmask_b32_e64 %[tb], 0, 1, %[mCb]\nv_fma_f32 %[f3], %[f3], %[xa], %[xb]\nv_or3_b32 %[pa], %[pa], %[qa], %[ta]\nv_fma_f32 %[f0], %[f0], %[xa], %[xb]\nv_or3_b32 %[pb], %[pb], %[qb], %[tb]\nv_fma_f32 %[f1], %[f1], %[xa], %[xb]\nv_lshl_or_b32 %[w], %[w], 3, %[pa]\nv_fma_f32 %[f2], %[f2], %[xa], %[xb]\nv_lshl_or_b32 %[w], %[w], 3, %[pb]\nv_fma_f32 %[f3], %[f3], %[xa], %[xb]" : [w] "+v"(wacc), [f0] "+v"(a4), [f1] "+v"(a5), [f2] "+v"(a6), [f3] "+v"(a7), [mAa] "=&s"(mAa), [mAb] "=&s"(mAb), [mBa] "=&s"(mBa), [mBb] "=&s"(mBb), [mCa] "=&s"(mCa), [mCb] "=&s"(mCb), [ta] "=&v"(ta), [tb] "=&v"(tb), [pa] "=&v"(pa), [pb] "=&v"(pb), [qa] "=&v"(qa), [qb] "=&v"(qb) : [xa] "v"(a0), [xb] "v"(a1), [b0] "v"(b), [b1] "v"(c), [b2] "v"(a2), [b3] "v"(a3), [b4] "v"(b), [b5] "v"(c), [b6] "v"(a2)); }
+                if (OP == 82) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+                    REP8(X) REP8(X) REP8(X)
+#undef X
+                }
+                a0 += __builtin_bit_cast(float, wacc & 1u);
             }
         }
     }
@@ -273,6 +299,8 @@ int main() {
     run<6>("v_cvt_pk_bf16", out, 1); run<8>("v_lshl_or", out, 1); run<9>("v_max_f32", out, 1); run<10>("v_bfe_u32", out, 1);
     run<11>("s_or_b64", out, 1); run<12>("fma+s_or", out, 1);
     run<14>("v_add_f32", out, 1); run<15>("v_pk_add_u16", out, 2); run<16>("v_lshlrev_b32", out, 1); run<17>("v_cvt_f32_f16", out, 1);
+    run<80>("bucket S-ops only (24 S)", out, 24); run<81>("bucket 24 S + 24 fma interleaved", out, 48); run<82>("24 fma only", out, 24);
+    run<70>("pairs cmp+fma", out, 2); run<71>("pairs addc+fma", out, 2); run<72>("pairs max+fma", out, 2); run<73>("cmp,f,cnd,f,addc,f (6 valu)", out, 6);
     run<60>("v_fma sgpr operand", out, 1); run<61>("v_fmaak literal", out, 1); run<62>("v_fma sgpr + abs", out, 1); run<63>("v_fmac sgpr", out, 1); run<64>("v_fma inline const", out, 1); run<65>("v_mul sgpr", out, 1); run<66>("v_fmamk literal", out, 1);
     run<50>("clustered 16cnd+16fma (x32)", out, 4); run<51>("alternating cnd,fma (x32)", out, 4); run<52>("clustered one-asm (x32)", out, 4); run<53>("dep chain cmp/cnd (x16 valu)", out, 2);
     run<30>("mix fma+cndmask (pairs)", out, 1); run<31>("mix exp+fma (pairs)", out, 1); run<32>("mix exp+cndmask (pairs)", out, 1); run<33>("mix exp+3fma (per 4)", out, 1);
