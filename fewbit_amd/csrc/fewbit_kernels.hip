@@ -171,8 +171,11 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
                 for (int i = 0; i < 8; ++i) v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
 #endif
                 const size_t g = (t * U + u) * kWave + s.lane;
+                // y: nontemporal (not read again here; keeps the remaining input resident in L2 / Infinity Cache).
+                // state: plain store -- it is what backward reads, and a backward that follows closely finds it
+                // cached (4096x4096 bf16 step 26.5 -> 25.6 us); when backward runs much later it makes no difference.
                 GroupIO<DT>::template store<true>(y, g, v);
-                store_state_quad<K, true>(state, g, s.lane, w);
+                store_state_quad<K, false>(state, g, s.lane, w);
             }
         });
 
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kerne
                 }
                 const size_t g = (t * U + u) * kWave + s.lane;
                 GroupIO<DT>::template store<true>(y, g, v);
-                store_state_quad<1, true>(state, g, s.lane, w);
+                store_state_quad<1, false>(state, g, s.lane, w);
             }
         });
     if (aligned && s.wave != s.nwaves - 1) return;
