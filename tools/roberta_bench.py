@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: RoBERTa-base forward+backward, all GELU -> fewbit.GELU(bits=3), batch 128 x seq 128:
+peak memory and step time against the vanilla model.  Random-init weights of the roberta-base architecture
+(`RobertaConfig()` defaults: 768 / 12 layers / 12 heads / 3072; no network access), synthetic token ids.
+
+The reference's benchmark patches `transformers.activations.ACT2FN['gelu']` with `torch.ops.fewbit.gelu`
+(benchmark/bench-roberta.py:123-149); here the 12 `intermediate_act_fn` modules are swapped with `fewbit.map_module`.
+    python tools/roberta_bench.py [--dtype fp32|bf16] [--steps 10] [--bits 3]
+Prints one JSON line.
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+import torch  # noqa: E402
+
+import fewbit  # noqa: E402
+
+
+def build(dtype, device):
+    from transformers import RobertaConfig, RobertaForSequenceClassification
+    torch.manual_seed(0)
+    cfg = RobertaConfig(num_labels=2)
+    cfg.hidden_dropout_prob = 0.1
+    model = RobertaForSequenceClassification(cfg)
+    return model.to(device=device, dtype=dtype).train()
+
+
+def swap_gelu(model, bits):
+    from transformers.activations import GELUActivation
+    n = [0]
+
+    def fn(mod, path):
+        if isinstance(mod, (GELUActivation, torch.nn.GELU)) and path.endswith('intermediate_act_fn'):
+            n[0] += 1
+            return fewbit.GELU(bits=bits)
+        return mod
+
+    fewbit.map_module(model, fn)
+    return n[0]
+
+
+def run(model, ids, labels, steps, warmup=3):
+    opt = torch.optim.SGD(model.parameters(), lr=1e-4)
+    dev = ids.device
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(input_ids=ids, labels=labels)
+        out.loss.backward()
+        opt.step()
+        return out.loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    base = torch.cuda.memory_allocated(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    peak = torch.cuda.max_memory_allocated(dev)
+    with fewbit.memory_usage_hooks() as usage:
+        model(input_ids=ids, labels=labels).loss.backward()
+    return {'ms_per_step': dt * 1e3, 'peak_bytes': peak, 'peak_minus_resident_bytes': peak - base,
+            'saved_for_backward_bytes': usage.forward, 'loss': float(loss)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--dtype', default='fp32', choices=('fp32', 'bf16'))
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--bits', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--seq', type=int, default=128)
+    args = ap.parse_args()
+    dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[args.dtype]
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(5, 50000, (args.batch, args.seq), generator=g).to(dev)
+    labels = torch.randint(0, 2, (args.batch,), generator=g).to(dev)
+
+    res = {}
+    for name in ('vanilla', 'fewbit'):
+        model = build(dtype, dev)
+        swapped = swap_gelu(model, args.bits) if name == 'fewbit' else 0
+        res[name] = run(model, ids, labels, args.steps)
+        res[name]['gelu_modules_swapped'] = swapped
+        del model
+        torch.cuda.empty_cache()
+    es = 4 if dtype == torch.float32 else 2
+    n_act = 12 * args.batch * args.seq * 3072
+    expect = n_act * es - (args.bits * n_act) // 8
+    out = {'config': f'RoBERTa-base (random init) batch {args.batch} x seq {args.seq}, {args.dtype}, fwd+bwd+SGD step',
+           'bits': args.bits, 'vanilla': res['vanilla'], 'fewbit': res['fewbit'],
+           'peak_saving_bytes': res['vanilla']['peak_bytes'] - res['fewbit']['peak_bytes'],
+           'saved_tensor_saving_bytes': res['vanilla']['saved_for_backward_bytes'] - res['fewbit']['saved_for_backward_bytes'],
+           'expected_saved_tensor_saving_bytes': expect,
+           'step_time_ratio': res['fewbit']['ms_per_step'] / res['vanilla']['ms_per_step']}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
