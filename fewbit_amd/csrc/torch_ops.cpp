@@ -63,8 +63,8 @@ Tensor new_state(const Tensor &like, int64_t numel, int nbits) {
 
 // ---- raw launches (no autograd) ------------------------------------------------------------------
 
-// y = fn(x) written over `self`; returns the packed state
-Tensor launch_quantize(int fn, Tensor &self, const Tensor &bounds, double p0, double p1) {
+// y = fn(self) written to `out` (which may be `self` itself: in place); returns the packed state
+Tensor launch_quantize(int fn, const Tensor &self, Tensor &out, const Tensor &bounds, double p0, double p1) {
     check_input(self, "self");
     check_table(self, bounds, "bounds");
     const Tensor b = bounds.contiguous();  // e.g. borders[1:-1] is already contiguous; strided views are not
@@ -72,7 +72,7 @@ Tensor launch_quantize(int fn, Tensor &self, const Tensor &bounds, double p0, do
     const int nbits = fewbit_hip_bitwidth(static_cast<int>(b.numel()) + 1);
     Tensor state = new_state(self, self.numel(), nbits);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(self.device());
-    check_status(fewbit_hip_quantize_forward(fn, dtype_code(self), self.data_ptr(), self.data_ptr(),
+    check_status(fewbit_hip_quantize_forward(fn, dtype_code(self), self.data_ptr(), out.data_ptr(),
                                              state.data_ptr<uint8_t>(), static_cast<size_t>(self.numel()),
                                              b.data_ptr(), static_cast<int>(b.numel()), p0, p1, current_stream(self)),
                  "quantize_forward");
@@ -104,38 +104,41 @@ Tensor launch_dequantize(const Tensor &grad, const Tensor &state, const Tensor &
 // all 13 continuous activations (+ custom `stepwise` tables): state and levels are what is saved
 struct ContinuousFunction : public torch::autograd::Function<ContinuousFunction> {
     static Tensor forward(AutogradContext *ctx, Tensor self, const Tensor &bounds, const Tensor &levels, int64_t fn,
-                          double p0, double p1) {
+                          double p0, double p1, bool inplace) {
         TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
                     "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(),
                     " and ", levels.numel());
         check_table(self, levels, "levels");
-        Tensor state = launch_quantize(static_cast<int>(fn), self, bounds, p0, p1);
-        ctx->mark_dirty({self});
+        Tensor out = inplace ? self : torch::empty_like(self);
+        Tensor state = launch_quantize(static_cast<int>(fn), self, out, bounds, p0, p1);
+        if (inplace) ctx->mark_dirty({self});
         ctx->save_for_backward({state, levels});
-        return self;
+        return out;
     }
 
     static variable_list backward(AutogradContext *ctx, variable_list grad_output) {
         const auto saved = ctx->get_saved_variables();
-        return {launch_dequantize(grad_output[0], saved[0], saved[1]), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {launch_dequantize(grad_output[0], saved[0], saved[1]), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+                Tensor()};
     }
 };
 
 // the eight piecewise-linear activations with an exact 1-bit state
 struct Stepwise1Function : public torch::autograd::Function<Stepwise1Function> {
-    static Tensor forward(AutogradContext *ctx, Tensor self, int64_t fn, double p0, double p1) {
+    static Tensor forward(AutogradContext *ctx, Tensor self, int64_t fn, double p0, double p1, bool inplace) {
         check_input(self, "self");
+        Tensor out = inplace ? self : torch::empty_like(self);
         Tensor state = new_state(self, self.numel(), 1);
         c10::hip::HIPGuardMasqueradingAsCUDA guard(self.device());
-        check_status(fewbit_hip_stepwise1_forward(static_cast<int>(fn), dtype_code(self), self.data_ptr(), self.data_ptr(),
+        check_status(fewbit_hip_stepwise1_forward(static_cast<int>(fn), dtype_code(self), self.data_ptr(), out.data_ptr(),
                                                   state.data_ptr<uint8_t>(), static_cast<size_t>(self.numel()), p0, p1,
                                                   current_stream(self)),
                      "stepwise1_forward");
-        ctx->mark_dirty({self});
+        if (inplace) ctx->mark_dirty({self});
         ctx->save_for_backward({state});
         ctx->saved_data["fn"] = fn;
         ctx->saved_data["p0"] = p0;
-        return self;
+        return out;
     }
 
     static variable_list backward(AutogradContext *ctx, variable_list grad_output) {
@@ -150,16 +153,16 @@ struct Stepwise1Function : public torch::autograd::Function<Stepwise1Function> {
                                                    saved[0].data_ptr<uint8_t>(), gx.data_ptr(),
                                                    static_cast<size_t>(gy.numel()), p0, current_stream(gy)),
                      "stepwise1_backward");
-        return {gx, Tensor(), Tensor(), Tensor()};
+        return {gx, Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
 Tensor continuous(int fn, const Tensor &self, const Tensor &bounds, const Tensor &levels, double p0 = 0.0, double p1 = 0.0) {
-    return ContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1);
+    return ContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, /*inplace=*/true);
 }
 
 Tensor stepwise1(int fn, const Tensor &self, double p0 = 0.0, double p1 = 0.0) {
-    return Stepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1);
+    return Stepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, /*inplace=*/true);
 }
 
 }  // namespace
@@ -201,10 +204,25 @@ Tensor stepwise(const Tensor &self, const Tensor &b, const Tensor &l, std::optio
     return continuous(FEWBIT_IDENTITY, self, b, l);
 }
 
+// Out-of-place variants (additions, not in the reference): same kernels writing to a fresh tensor.  The python layer
+// uses them when the input is a VIEW (e.g. the 3-D output of nn.Linear): an in-place op on a view makes autograd
+// rebase the view's history (CopySlices), whose backward costs a zero-fill and four full-size copies per call --
+// seen as +5 % step time on RoBERTa-base before this path existed.
+Tensor continuous_out(const Tensor &self, const Tensor &b, const Tensor &l, int64_t fn, double p0, double p1) {
+    TORCH_CHECK(fn >= 0 && fn < FEWBIT_CONTINUOUS_COUNT, "fewbit: unknown continuous function id ", fn);
+    return ContinuousFunction::apply(self, b, l, fn, p0, p1, /*inplace=*/false);
+}
+
+Tensor stepwise1_out(const Tensor &self, int64_t fn, double p0, double p1) {
+    TORCH_CHECK(fn >= 0 && fn < FEWBIT_STEPWISE_COUNT, "fewbit: unknown stepwise function id ", fn);
+    return Stepwise1Function::apply(self, fn, p0, p1, /*inplace=*/false);
+}
+
 // raw pieces, fewbit/cpu/gelu.cc:7-45: quantize(x, bounds) -> (gelu(x), state); out of place like the reference
 std::tuple<Tensor, Tensor> quantize(const Tensor &inputs, const Tensor &bounds) {
-    Tensor outputs = inputs.contiguous().clone();
-    Tensor state = launch_quantize(FEWBIT_GELU, outputs, bounds, 0.0, 0.0);
+    const Tensor x = inputs.contiguous();
+    Tensor outputs = torch::empty_like(x);
+    Tensor state = launch_quantize(FEWBIT_GELU, x, outputs, bounds, 0.0, 0.0);
     return std::make_tuple(outputs, state);
 }
 
@@ -242,6 +260,10 @@ TORCH_LIBRARY(fewbit, m) {
     m.def("tanhshrink(Tensor(a!) self, Tensor bounds, Tensor levels) -> Tensor(a!)");
 
     m.def("stepwise   (Tensor(a!) self, Tensor bounds, Tensor levels, bool? parity=None, int[2]? shift=None) -> Tensor(a!)");
+
+    // additions of this implementation (not part of the reference's operator set)
+    m.def("continuous_out(Tensor self, Tensor bounds, Tensor levels, int fn, float p0 = 0.0, float p1 = 0.0) -> Tensor");
+    m.def("stepwise1_out(Tensor self, int fn, float p0 = 0.0, float p1 = 0.0) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(fewbit, AutogradCUDA, m) {
@@ -269,6 +291,8 @@ TORCH_LIBRARY_IMPL(fewbit, AutogradCUDA, m) {
     m.impl("tanhshrink", fewbit_amd::tanhshrink);
 
     m.impl("stepwise", fewbit_amd::stepwise);
+    m.impl("continuous_out", fewbit_amd::continuous_out);
+    m.impl("stepwise1_out", fewbit_amd::stepwise1_out);
 }
 
 TORCH_LIBRARY_IMPL(fewbit, CUDA, m) {

@@ -55,6 +55,25 @@ def _native_op(name: str):
     return getattr(torch.ops.fewbit, name)
 
 
+# enum order of include/fewbit_hip.h, for the out-of-place operators
+_CONTINUOUS_ID = {n: i for i, n in enumerate(CONTINOUS[:0] + ('celu', 'elu', 'gelu', 'hardswish', 'logsigmoid', 'mish', 'selu',
+                                                              'sigmoid', 'silu', 'softplus', 'softsign', 'tanh',
+                                                              'tanhshrink', 'identity'))}
+_STEPWISE_ID = {n: i for i, n in enumerate(('hardshrink', 'hardsigmoid', 'hardtanh', 'leaky_relu', 'relu', 'relu6',
+                                            'softshrink', 'threshold'))}
+
+
+def _gpu_continuous(name: str, input, inner, levels, extra):
+    """In place like the reference op -- except on a view (say, the reshaped output of nn.Linear), where an in-place
+    op would make autograd rebase the view (CopySlices: a zero-fill plus four full-size copies in backward); there the
+    same kernel writes a fresh tensor and the view's base is simply released."""
+    if input._is_view():
+        p = tuple(extra) + (0.0, ) * (2 - len(extra))
+        _native_op(name)  # loud failure if the library is missing
+        return torch.ops.fewbit.continuous_out(input, inner, levels, _CONTINUOUS_ID[name], *p)
+    return _native_op(name)(input, inner, levels, *extra)
+
+
 class _HostQuantized(torch.autograd.Function):
     """Host-tensor path: codes kept one per byte (reference: FallbackFunc, fewbit/functional/activations.py:89-129)."""
 
@@ -117,7 +136,7 @@ def _make_continuous(name: str) -> Callable:
         inner = borders[1:-1].to(input)
         levels = values.to(input)
         if input.device.type == 'cuda':
-            return _native_op(name)(input, inner, levels, *extra)
+            return _gpu_continuous(name, input, inner, levels, extra)
         return _HostQuantized.apply(impl, input, inner, levels, *extra)
 
     fn.__name__ = fn.__qualname__ = name
@@ -137,6 +156,10 @@ def _make_stepwise1(name: str) -> Callable:
         # `bits` is accepted and ignored: these functions have an exact 1-bit state (generated modules pass it)
         extra = _bind_extra(name, args, kwargs)
         if input.device.type == 'cuda':
+            if input._is_view():                 # see _gpu_continuous
+                p = tuple(extra) + (0.0, ) * (2 - len(extra))
+                _native_op(name)
+                return torch.ops.fewbit.stepwise1_out(input, _STEPWISE_ID[name], *p)
             return _native_op(name)(input, *extra)
         return impl(input, *extra)
 
@@ -154,6 +177,9 @@ def stepwise(input: torch.Tensor, borders: torch.Tensor, levels: torch.Tensor, p
     if parity is not None or shift is not None:
         raise NotImplementedError('stepwise with parity/shift is not implemented')
     if input.device.type == 'cuda':
+        if input._is_view():
+            _native_op('stepwise')
+            return torch.ops.fewbit.continuous_out(input, borders.to(input), levels.to(input), _CONTINUOUS_ID['identity'], 0.0, 0.0)
         return _native_op('stepwise')(input, borders.to(input), levels.to(input))
     return _HostQuantized.apply(lambda t: t.clone(), input, borders.to(input), levels.to(input))
 

@@ -158,3 +158,31 @@ def test_map_module_training_step_and_memory():
     cos = torch.nn.functional.cosine_similarity(g0.flatten(), g1.flatten(), dim=0).item()
     assert cos > 0.97                                        # 3-bit derivative: close, not equal
     assert torch.allclose(base[2].weight.grad, ours[2].weight.grad, rtol=1e-4, atol=1e-6)   # downstream of the activation
+
+
+def test_view_inputs_run_out_of_place_and_match():
+    """nn.Linear on a 3-D input returns a VIEW; an in-place op on it would make autograd rebase the view (CopySlices:
+    a zero-fill and four full-size copies per backward).  The functional layer then writes a fresh tensor instead;
+    values and gradients must be the same as on the in-place route."""
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 256).to(DEV)
+    x = torch.randn(8, 16, 64, device=DEV)
+    h = lin(x)
+    assert h._is_view()
+    out = fewbit.GELU(bits=3)(h)
+    assert out.data_ptr() != h.data_ptr() and not out._is_view()
+    out.sum().backward()
+    g_view = lin.weight.grad.clone()
+    lin.weight.grad = None
+    h2 = lin(x.view(-1, 64))                       # 2-D input: plain tensor, in-place route
+    assert not h2._is_view()
+    out2 = fewbit.GELU(bits=3)(h2)
+    assert out2.data_ptr() == h2.data_ptr()
+    out2.sum().backward()
+    assert torch.equal(out.view(-1, 256), out2) and torch.allclose(g_view, lin.weight.grad, rtol=1e-5, atol=1e-6)
+    r = torch.randn(4, 32, 8, device=DEV, requires_grad=True)
+    v = (r * 1.0).view(4, 256)
+    y = fewbit.functional.relu(v)
+    assert y.data_ptr() != v.data_ptr() and torch.equal(y, F.relu(v))
+    y.sum().backward()
+    assert torch.equal(r.grad.view(4, 256), (v > 0).float())

@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--bits', type=int, default=3)
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--seq', type=int, default=128)
+    ap.add_argument('--only', default=None, choices=(None, 'vanilla', 'fewbit'), help='run a single variant (profiling)')
     args = ap.parse_args()
     dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[args.dtype]
     dev = torch.device('cuda:0')
@@ -88,12 +89,17 @@ def main():
 
     res = {}
     for name in ('vanilla', 'fewbit'):
+        if args.only and name != args.only:
+            continue
         model = build(dtype, dev)
         swapped = swap_gelu(model, args.bits) if name == 'fewbit' else 0
         res[name] = run(model, ids, labels, args.steps)
         res[name]['gelu_modules_swapped'] = swapped
         del model
         torch.cuda.empty_cache()
+    if args.only:
+        print(json.dumps({args.only: res[args.only]}))
+        return
     es = 4 if dtype == torch.float32 else 2
     n_act = 12 * args.batch * args.seq * 3072
     expect = n_act * es - (args.bits * n_act) // 8
