@@ -142,9 +142,48 @@ __device__ __forceinline__ uint32_t push1_k4(uint32_t w, float x, const float (&
     return w;
 }
 
+// ---- plain C++ formulation (build with -DFEWBIT_CXX_BUCKET; kept as the readable statement of the algorithm and
+// as an A/B): the same MSB-first search, bits materialised with selects of inline constants (v_cndmask 0/4, 0/2,
+// 0/1 + v_or3 + v_lshl_or) instead of v_addc.  In isolation it is ~5 % faster than the blocks above (v_addc with an
+// SGPR carry-in does not co-issue with v_fma, v_cmp/v_cndmask do), but inside the forward kernel hipcc's schedule
+// of it needs more than 64 VGPRs and spills (4096x4096 bf16 forward 16.2 -> 18.0 us), so the asm blocks are used.
+template <int K> __device__ __forceinline__ uint32_t bucket(const float (&b)[(1 << K) - 1], float x) {
+    if constexpr (K == 1) {
+        return !(b[0] >= x) ? 1u : 0u;
+    } else if constexpr (K == 2) {
+        const bool A = !(b[1] >= x);
+        const float t = A ? b[2] : b[0];
+        const bool B = !(t >= x);
+        return (A ? 2u : 0u) | (B ? 1u : 0u);
+    } else if constexpr (K == 3) {
+        const bool A = !(b[3] >= x);
+        const float t = A ? b[5] : b[1];
+        const bool B = !(t >= x);
+        const float p = A ? b[4] : b[0];
+        const float q = A ? b[6] : b[2];
+        const float t0 = B ? q : p;
+        const bool C = !(t0 >= x);
+        return (A ? 4u : 0u) | (B ? 2u : 0u) | (C ? 1u : 0u);
+    } else {
+        const bool A = !(b[7] >= x);
+        const float t = A ? b[11] : b[3];
+        const bool B = !(t >= x);
+        const float p = A ? b[9] : b[1];
+        const float q = A ? b[13] : b[5];
+        const float t2 = B ? q : p;
+        const bool C = !(t2 >= x);
+        const float r0 = A ? b[8] : b[0], r1 = A ? b[10] : b[2], r2 = A ? b[12] : b[4], r3 = A ? b[14] : b[6];
+        const float s0 = B ? r2 : r0, s1 = B ? r3 : r1;
+        const float t3 = C ? s1 : s0;
+        const bool D = !(t3 >= x);
+        return (A ? 8u : 0u) | (B ? 4u : 0u) | (C ? 2u : 0u) | (D ? 1u : 0u);
+    }
+}
+
 // packed K-bit codes of one group (8 elements), element i in bits [K*i, K*i+K)
 template <int K> __device__ __forceinline__ uint32_t pack_group(const float (&x)[8], const float (&b)[(1 << K) - 1]) {
     uint32_t w = 0;
+#if !defined(FEWBIT_CXX_BUCKET)
     if constexpr (K == 1) {
         w = push4_k1(w, x[7], x[6], x[5], x[4], b[0]);
         w = push4_k1(w, x[3], x[2], x[1], x[0], b[0]);
@@ -158,6 +197,10 @@ template <int K> __device__ __forceinline__ uint32_t pack_group(const float (&x)
 #pragma unroll
         for (int i = 7; i >= 0; --i) w = push1_k4(w, x[i], b);
     }
+#else
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w |= bucket<K>(b, x[i]) << (K * i);
+#endif
     return w;
 }
 
