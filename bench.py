@@ -94,12 +94,19 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    device = torch.device('cuda', local_rank % ndev)
+    torch.cuda.set_device(device)
+    # control plane only (barrier + max of the elapsed time): RCCL ('nccl' on ROCm).  FEWBIT_BENCH_BACKEND=gloo is a
+    # validation hook that lets several ranks share one GPU, where RCCL refuses duplicate devices.
+    backend = os.environ.get('FEWBIT_BENCH_BACKEND', 'nccl')
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from fewbit_amd import cabi   # raises if libfewbit_hip.so is missing: there is no fallback
     cabi.lib()
@@ -141,7 +148,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -41,6 +41,19 @@ template <int MODE> __global__ __launch_bounds__(256, 8) void k(float* out, cons
                 if (MODE == 34 || MODE == 35) rl = relu_raw(x[i]);
                 x[i] = __builtin_fmaf(-a, h, rl);
             }
+        } else if (MODE == 36) {   // gelu with the 8 exps issued back to back
+            float q[8], a[8];
+            for (int i = 0; i < 8; ++i) {
+                a[i] = __builtin_fabsf(x[i]);
+                float r = -2.834918860e-06f;
+                r = __builtin_fmaf(r, a[i], 3.937771180e-05f); r = __builtin_fmaf(r, a[i], -1.861801138e-04f); r = __builtin_fmaf(r, a[i], -1.369371021e-04f);
+                r = __builtin_fmaf(r, a[i], 7.063421421e-03f); r = __builtin_fmaf(r, a[i], -5.249617994e-02f); r = __builtin_fmaf(r, a[i], -4.592081904e-01f);
+                r = __builtin_fmaf(r, a[i], -1.151105165e+00f);
+                q[i] = __builtin_fmaf(r, a[i], -1.0f);
+            }
+            asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n s_nop 0"
+                         : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]));
+            for (int i = 0; i < 8; ++i) x[i] = __builtin_fmaf(-a[i], q[i], relu_raw(x[i]));
         } else if (MODE == 40 || MODE == 41) {
             uint32_t w = 0;
 #pragma unroll
@@ -91,6 +104,6 @@ template <int MODE> int run(const char* name, float* out, float* bp) {
 int main() {
     float* out; CHECK(hipMalloc(&out, 256 * 8 * 256 * 4));
     float hb[7] = {-2.4f, -0.71f, -0.326f, 1e-4f, 0.326f, 0.71f, 2.41f}; float* bp; CHECK(hipMalloc(&bp, 28)); CHECK(hipMemcpy(bp, hb, 28, hipMemcpyHostToDevice));
-    run<0>("overhead only (8 adds)", out, bp); run<1>("bucket+pack k3", out, bp); run<2>("gelu_fast", out, bp); run<3>("bucket+pack + gelu", out, bp); run<7>("bucket+pack + gelu + cvt", out, bp); run<32>("gelu: poly only (9 fma)", out, bp); run<33>("gelu: poly + exp", out, bp); run<34>("gelu: poly + max", out, bp); run<35>("gelu: poly+exp+max", out, bp); run<40>("c++ bucket (no addc)", out, bp); run<41>("c++ bucket + gelu", out, bp); run<16>("interleaved per pair", out, bp); run<17>("skewed per pair", out, bp);
+    run<0>("overhead only (8 adds)", out, bp); run<1>("bucket+pack k3", out, bp); run<2>("gelu_fast", out, bp); run<3>("bucket+pack + gelu", out, bp); run<7>("bucket+pack + gelu + cvt", out, bp); run<32>("gelu: poly only (9 fma)", out, bp); run<33>("gelu: poly + exp", out, bp); run<34>("gelu: poly + max", out, bp); run<35>("gelu: poly+exp+max", out, bp); run<36>("gelu: exps batched", out, bp); run<40>("c++ bucket (no addc)", out, bp); run<41>("c++ bucket + gelu", out, bp); run<16>("interleaved per pair", out, bp); run<17>("skewed per pair", out, bp);
     return 0;
 }
