@@ -83,3 +83,28 @@ def test_gelu_fp32_dense_sample():
     abs_ok = (y.double() - ref.double()).abs() <= 2.0**-23 * x.double().abs()
     assert (step_ok | abs_ok).all()
     assert (ulp_distance(y, ref) == 0).double().mean() > 0.9
+
+
+def test_erf_fp32_every_binade():
+    """Device erf (through gelu on a table-less identity of the formula): for every fp32 exponent that matters and a
+    dense set of mantissas, y = x*0.5*(1+erf(x/sqrt2)) must equal the same formula with a float64 erf to within
+    max(1 step of y, 2^-23*|x|) -- i.e. erf itself within ~2 ulp including the |z| = 0.92 seam and NaN/inf."""
+    man = torch.arange(0, 1 << 23, 257, dtype=torch.int32)                       # 32 641 mantissas
+    parts = []
+    for e in range(90, 132):                                                      # 2^-37 .. 2^4
+        bits = (e << 23) | man
+        parts += [bits.view(torch.float32), (bits | (1 << 31) - 0 if False else bits).view(torch.float32) * -1.0]
+    seam = torch.tensor(0.921875 * 2 ** 0.5).float()
+    near = (seam.view(torch.int32) + torch.arange(-4000, 4000, dtype=torch.int32)).view(torch.float32)
+    x = torch.cat(parts + [near, -near, torch.tensor([0.0, -0.0, float('inf'), -float('inf'), float('nan'), 1e-45, -1e-45])])
+    b, _ = store.get('gelu', 3, DEV, torch.float32)
+    y, _ = cabi.quantize_forward('gelu', x.to(DEV), b[1:-1].contiguous())
+    y = y.cpu()
+    z = (x * np.float32(0.70710678118654752440)).double().numpy()
+    with np.errstate(invalid='ignore'):
+        ref = (x * 0.5) * (1.0 + torch.from_numpy(erf(z)).float())
+    fin = torch.isfinite(x)
+    ok = (ulp_distance(y, ref) <= 1) | ((y.double() - ref.double()).abs() <= 2.0**-23 * x.double().abs())
+    assert ok[fin].all(), (x[fin][~ok[fin]][:5], y[fin][~ok[fin]][:5], ref[fin][~ok[fin]][:5])
+    assert torch.isnan(y[torch.isnan(x)]).all()
+    assert (ulp_distance(y, ref)[fin] == 0).double().mean() > 0.85
