@@ -138,6 +138,7 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
                                                                   float p1) {
     constexpr int NB = (1 << K) - 1;
     constexpr bool kFast = (DT != FEWBIT_F32);
+    constexpr bool kStreamY = (DT != FEWBIT_F32);
     typedef typename GroupIO<DT>::Raw Raw;
     const Span s = make_span<U>(n);
 
@@ -171,10 +172,12 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
                 for (int i = 0; i < 8; ++i) v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
 #endif
                 const size_t g = (t * U + u) * kWave + s.lane;
-                // y: nontemporal (not read again here; keeps the remaining input resident in L2 / Infinity Cache).
+                // y: nontemporal for 16-bit dtypes (not read again here; keeps the remaining input resident in L2 /
+                // Infinity Cache).  fp32 groups are stored as two 16 B pieces at a 32 B lane stride, i.e. each store
+                // instruction leaves holes that only L2 write-combining fills -- nontemporal there costs 4 us per pass.
                 // state: plain store -- it is what backward reads, and a backward that follows closely finds it
                 // cached (4096x4096 bf16 step 26.5 -> 25.6 us); when backward runs much later it makes no difference.
-                GroupIO<DT>::template store<true>(y, g, v);
+                GroupIO<DT>::template store<kStreamY>(y, g, v);
                 store_state_quad<K, false>(state, g, s.lane, w);
             }
         });
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kerne
                     w |= bit << i;
                 }
                 const size_t g = (t * U + u) * kWave + s.lane;
-                GroupIO<DT>::template store<true>(y, g, v);
+                GroupIO<DT>::template store<(DT != FEWBIT_F32)>(y, g, v);
                 store_state_quad<1, false>(state, g, s.lane, w);
             }
         });
