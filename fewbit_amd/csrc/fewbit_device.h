@@ -324,12 +324,81 @@ __device__ __forceinline__ float erf_precise(float z) {
     return __builtin_copysignf(mag, z);
 }
 
+// ---- fast-class helpers for the remaining functors (16-bit I/O): hardware exp2/log2/rcp plus a short series where
+// the closed form cancels.  Accuracy is checked for EVERY bf16 and fp16 input by tests/test_gpu_numerics.py.
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+
+// exp(x) - 1 for x <= 0 (the only side elu/celu/selu need; for x > 0 the caller's select discards the result,
+// NaN propagates)
+__device__ __forceinline__ float expm1_neg_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * kLog2e) - 1.0f;
+    // |x| < 2^-6: x + x^2/2 + x^3/6 is exact to fp32 rounding; beyond it the subtraction loses < 2^-17 relative
+    const float ser = __builtin_fmaf(__builtin_fmaf(x, 0.16666667f, 0.5f) * x, x, x);
+    return x > -0.015625f ? ser : e;
+}
+
+// log(1 + e) for e >= 0
+__device__ __forceinline__ float log1p_pos_fast(float e) {
+    const float l = __builtin_amdgcn_logf(1.0f + e) * kLn2;          // v_log_f32 = log2
+    const float ser = __builtin_fmaf(__builtin_fmaf(e, 0.33333334f, -0.5f) * e, e, e);
+    return e < 0.0078125f ? ser : l;
+}
+
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float a = __builtin_fabsf(x);
+    const float e2 = __builtin_amdgcn_exp2f(a * (2.0f * kLog2e));
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e2 + 1.0f);   // exp overflow -> rcp(inf) = 0 -> 1
+    const float s = a * a;
+    // |x| < 1/4: x*(1 - s/3 + 2 s^2/15 - 17 s^3/315 + 62 s^4/2835), truncation < 2e-8 relative
+    float p = 0.021869488f;
+    p = __builtin_fmaf(p, s, -0.053968254f);
+    p = __builtin_fmaf(p, s, 0.13333334f);
+    p = __builtin_fmaf(p, s, -0.33333334f);
+    const float small = __builtin_fmaf(p * s, a, a);
+    return __builtin_copysignf(a < 0.25f ? small : big, x);
+}
+
+// x - tanh(x): series x^3/3 - 2x^5/15 + 17x^7/315 - 62x^9/2835 + 1382 x^11/155925 below 1/2 (no cancellation)
+__device__ __forceinline__ float tanhshrink_fast(float x) {
+    const float a = __builtin_fabsf(x);
+    const float s = a * a;
+    float p = 0.0088632358f;
+    p = __builtin_fmaf(p, s, -0.021869488f);
+    p = __builtin_fmaf(p, s, 0.053968254f);
+    p = __builtin_fmaf(p, s, -0.13333334f);
+    p = __builtin_fmaf(p, s, 0.33333334f);
+    const float small = p * s * a;
+    const float big = a - tanh_fast(a);
+    return __builtin_copysignf(a < 0.5f ? small : big, x);
+}
+
+__device__ __forceinline__ float softplus_fast(float x, float beta, float threshold) {
+    const float bx = x * beta;
+    const float e = __builtin_amdgcn_exp2f(bx * kLog2e);
+    return bx > threshold ? x : log1p_pos_fast(e) * __builtin_amdgcn_rcpf(beta);
+}
+
+__device__ __forceinline__ float logsigmoid_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(x) * -kLog2e);
+    return __builtin_fminf(0.0f, x) - log1p_pos_fast(e);
+}
+
+// x * tanh(softplus(x)) = x * n / (n + 2),  n = e^x (e^x + 2): no cancellation anywhere; clamp keeps n finite
+__device__ __forceinline__ float mish_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_fminf(x, 30.0f) * kLog2e);
+    const float n = e * (e + 2.0f);
+    return x * (n * __builtin_amdgcn_rcpf(n + 2.0f));
+}
+
 template <int FN, bool FAST> struct Act {
     // p0/p1 are wave-uniform kernel arguments
     static __device__ __forceinline__ float eval(float x, float p0, float p1) {
         if constexpr (FN == FEWBIT_CELU) {
+            if constexpr (FAST) return x > 0.0f ? x : p0 * expm1_neg_fast(x * __builtin_amdgcn_rcpf(p0));
             return x > 0.0f ? x : p0 * expm1f(x / p0);
         } else if constexpr (FN == FEWBIT_ELU) {
+            if constexpr (FAST) return x > 0.0f ? x : p0 * expm1_neg_fast(x);
             return x > 0.0f ? x : p0 * expm1f(x);
         } else if constexpr (FN == FEWBIT_GELU) {
             if constexpr (FAST) return gelu_fast(x);
@@ -339,13 +408,16 @@ template <int FN, bool FAST> struct Act {
             float t = fminf(fmaxf(x + 3.0f, 0.0f), 6.0f);
             return x * t / 6.0f;
         } else if constexpr (FN == FEWBIT_LOGSIGMOID) {
+            if constexpr (FAST) return logsigmoid_fast(x);
             return fminf(0.0f, x) - log1pf(expf(-fabsf(x)));
         } else if constexpr (FN == FEWBIT_MISH) {
+            if constexpr (FAST) return mish_fast(x);
             float sp = x > 20.0f ? x : log1pf(expf(x));
             return x * tanhf(sp);
         } else if constexpr (FN == FEWBIT_SELU) {
             const float alpha = 1.6732632423543772848170429916717f;
             const float scale = 1.0507009873554804934193349852946f;
+            if constexpr (FAST) return x > 0.0f ? scale * x : (scale * alpha) * expm1_neg_fast(x);
             return x > 0.0f ? scale * x : (scale * alpha) * expm1f(x);
         } else if constexpr (FN == FEWBIT_SIGMOID) {
             if constexpr (FAST) return sigmoid_fast(x);
@@ -354,13 +426,16 @@ template <int FN, bool FAST> struct Act {
             if constexpr (FAST) return x * sigmoid_fast(x);
             return x / (1.0f + expf(-x));
         } else if constexpr (FN == FEWBIT_SOFTPLUS) {
+            if constexpr (FAST) return softplus_fast(x, p0, p1);
             float bx = x * p0;
             return bx > p1 ? x : log1pf(expf(bx)) / p0;
         } else if constexpr (FN == FEWBIT_SOFTSIGN) {
             return x / (1.0f + fabsf(x));
         } else if constexpr (FN == FEWBIT_TANH) {
+            if constexpr (FAST) return tanh_fast(x);
             return tanhf(x);
         } else if constexpr (FN == FEWBIT_TANHSHRINK) {
+            if constexpr (FAST) return tanhshrink_fast(x);
             return x - tanhf(x);
         } else {
             return x;

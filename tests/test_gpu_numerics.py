@@ -108,3 +108,46 @@ def test_erf_fp32_every_binade():
     assert ok[fin].all(), (x[fin][~ok[fin]][:5], y[fin][~ok[fin]][:5], ref[fin][~ok[fin]][:5])
     assert torch.isnan(y[torch.isnan(x)]).all()
     assert (ulp_distance(y, ref)[fin] == 0).double().mean() > 0.85
+
+
+def _exact(name, xd, p):
+    """float64 value of each activation (the definition torch.nn.functional documents)."""
+    with np.errstate(all='ignore'):
+        if name == 'celu': return np.where(xd > 0, xd, p[0] * np.expm1(xd / p[0]))
+        if name == 'elu': return np.where(xd > 0, xd, p[0] * np.expm1(xd))
+        if name == 'selu': return 1.0507009873554804934193349852946 * np.where(xd > 0, xd, 1.6732632423543772848170429916717 * np.expm1(xd))
+        if name == 'hardswish':       # ATen's x*min(max(x+3,0),6)/6 overflows in fp32 above 5.6e37; keep away
+            return np.where(np.abs(xd) < 1e37, xd * np.clip(xd + 3, 0, 6) / 6, np.inf)
+        if name == 'logsigmoid': return np.minimum(0, xd) - np.log1p(np.exp(-np.abs(xd)))
+        if name == 'mish': return xd * np.tanh(np.where(xd > 20, xd, np.log1p(np.exp(np.minimum(xd, 700)))))
+        if name == 'sigmoid': return 1 / (1 + np.exp(-xd))
+        if name == 'softplus': return np.where(xd * p[0] > p[1], xd, np.log1p(np.exp(np.minimum(xd * p[0], 700))) / p[0])
+        if name == 'softsign': return xd / (1 + np.abs(xd))
+        if name == 'tanh': return np.tanh(xd)
+        if name == 'tanhshrink':      # float64 cancels below 1e-3: use the series there
+            s = xd * xd
+            return np.where(np.abs(xd) < 1e-3, xd * s * (1 / 3 - s * (2 / 15 - s * 17 / 315)), xd - np.tanh(xd))
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize('dtype', (torch.bfloat16, torch.float16))
+@pytest.mark.parametrize('name,p', [('celu', (1.3,)), ('elu', (0.7,)), ('selu', ()), ('hardswish', ()), ('logsigmoid', ()),
+                                    ('mish', ()), ('sigmoid', ()), ('softplus', (2.0, 5.0)), ('softplus', (1.0, 20.0)),
+                                    ('softsign', ()), ('tanh', ()), ('tanhshrink', ())])
+def test_remaining_functors_16bit_exhaustive(name, p, dtype):
+    """Every 16-bit input: within 1 step of the correctly rounded exact value, bit-identical for >= 99 %.
+    Outputs below 1e-36 in magnitude (exp underflow region of the hardware transcendentals) need only be that small."""
+    x = all_16bit(dtype)
+    b, _ = store.get(name, 3, DEV, dtype)
+    y, _ = cabi.quantize_forward(name, x.to(DEV), b[1:-1].contiguous(), *p)
+    y = y.cpu()
+    xd = x.double().numpy()
+    exact64 = torch.from_numpy(_exact(name, xd, p))
+    exact = exact64.to(dtype)
+    fin = torch.isfinite(x) & torch.isfinite(exact64)
+    d = ulp_distance(y, exact)
+    tiny = (y.double().abs() <= 1e-36) & (exact64.abs() <= 1e-36)
+    bad = fin & ~((d <= 1) | tiny)
+    assert not bad.any(), (name, x[bad][:6], y[bad][:6], exact[bad][:6])
+    assert (d[fin] == 0).double().mean() >= 0.99, (name, (d[fin] == 0).double().mean())
+    assert torch.isnan(y[torch.isnan(x)]).all()
