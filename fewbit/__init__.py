@@ -5,12 +5,14 @@ import sys
 
 import fewbit_amd
 from fewbit_amd import *  # noqa: F401,F403
-from fewbit_amd import functional, modules, util, store as _store_mod, map_module, memory_usage_hooks, __version__  # noqa: F401
+from fewbit_amd import functional, modules, util, approx, cli, store as _store_mod, map_module, memory_usage_hooks, __version__  # noqa: F401
 
 sys.modules[__name__ + '.functional'] = functional
 sys.modules[__name__ + '.functional.activations'] = functional
 sys.modules[__name__ + '.modules'] = modules
 sys.modules[__name__ + '.modules.activations'] = modules
 sys.modules[__name__ + '.util'] = util
+sys.modules[__name__ + '.approx'] = approx
+sys.modules[__name__ + '.cli'] = cli
 functional.activations = functional
 modules.activations = modules

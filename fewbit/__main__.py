@@ -1,0 +1,4 @@
+from fewbit_amd.cli import main
+
+if __name__ == '__main__':
+    main()
