@@ -320,3 +320,38 @@ def test_relu_config1_full_size():
     assert torch.equal(y.cpu(), y_o)
     assert_bit_equal(cabi.stepwise1_backward('relu', gy.to(DEV), st).cpu(), oracle.stepwise1_backward('relu', gy, s_o), 'gx')
     assert int(st.cpu().to(torch.int64).sum()) == int(s_o.to(torch.int64).sum())
+
+
+def test_more_than_2_pow_32_elements():
+    """The reference's launchers take uint32 element counts (fewbit/cuda/codec.h:29); here sizes are 64-bit.
+    n = 2^32 + 8 * 4099 + 5 bf16 elements (8.6 GB): check the far end, where a 32-bit index would have wrapped."""
+    n = (1 << 32) + 8 * 4099 + 5
+    free, _ = torch.cuda.mem_get_info()
+    if free < 30 * (1 << 30):
+        pytest.skip('needs ~20 GB of free HBM')
+    dtype = torch.bfloat16
+    borders, levels = store.get('gelu', 3, DEV, dtype)
+    inner = borders[1:-1].contiguous()
+    x = torch.empty(n, dtype=dtype, device=DEV)
+    chunk = 1 << 28
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for lo in range(0, n, chunk):
+        x[lo:lo + chunk].normal_(0, 1.5, generator=g)
+    y = torch.empty_like(x)
+    state = torch.empty(cabi.state_nbytes(n, 3), dtype=torch.uint8, device=DEV)
+    cabi.quantize_forward('gelu', x, inner, out=y, state=state)
+    for lo, hi in ((0, 1 << 20), ((1 << 32) - (1 << 20), n)):                     # first MiB and across 2^32 to the ragged end
+        lo8 = lo - lo % 8
+        xs = x[lo8:hi].cpu()
+        y_o, s_o, _ = oracle.quantize('gelu', xs, inner.cpu())
+        sb, se = state_range(lo8, hi, 3)
+        assert_bit_equal(state[sb:se].cpu(), s_o, f'state [{lo8},{hi})')
+        assert forward_value_ok(xs, y[lo8:hi].cpu(), y_o).all()
+    del y
+    tail = slice((1 << 32) - 4096, n)
+    gy_tail = x[tail].clone()
+    cabi.quantize_backward(x, state, levels, out=x)                               # in place, x doubles as gy
+    codes = cabi.unpack_codes(state[3 * (tail.start // 8):], n - tail.start, 3)
+    want = (levels.float()[codes.long()] * gy_tail.float()).to(dtype)
+    assert torch.equal(x[tail].view(torch.int16), want.view(torch.int16))
+    assert state.numel() == 3 * ((n + 7) // 8)
