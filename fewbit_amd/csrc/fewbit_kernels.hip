@@ -54,11 +54,11 @@ struct Span {
     int lane;
 };
 
-template <int U> __device__ __forceinline__ Span make_span(size_t n) {
+template <int U, int WPB = kWavesPerBlock> __device__ __forceinline__ Span make_span(size_t n) {
     Span s;
     s.lane = threadIdx.x & (kWave - 1);
-    s.nwaves = static_cast<size_t>(gridDim.x) * kWavesPerBlock;
-    s.wave = static_cast<size_t>(blockIdx.x) * kWavesPerBlock +
+    s.nwaves = static_cast<size_t>(gridDim.x) * WPB;
+    s.wave = static_cast<size_t>(blockIdx.x) * WPB +
              static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
     s.ntiles = (n >> 3) / (static_cast<size_t>(U) * kWave);
     s.tail_g0 = s.ntiles * (static_cast<size_t>(U) * kWave);
@@ -192,6 +192,133 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
                 float xv = Elem<DT>::load(x, e0 + i);
                 w |= count_below<NB>(b, xv) << (K * i);
                 Elem<DT>::store(y, e0 + i, Act<FN, kFast>::eval(xv, p0, p1));
+            }
+        }
+        store_state<K>(state, g, w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused forward for 16-bit dtypes with the border search replaced by a table lookup in LDS.
+//
+// A 16-bit input has 65 536 possible bit patterns, so "code of x" is a 64 KiB byte table indexed by the raw pattern.
+// It is built per block in three cheap passes (the code is a step function of the pattern: ascending over
+// 0x0000..0x7fff, descending over 0x8000..0xffff):
+//   1. every thread fills its 64-pattern chunk with the code of the chunk's first pattern (float predicate,
+//      identical to the search kernel's; NaN chunks get `nborders`, torch.searchsorted's rule);
+//   2. wave j corrects, inside the single chunk border j falls into, the patterns that lie beyond it (+1 in the
+//      positive half, -1 in the negative half) with LDS atomics, while the last wave fixes the NaN patterns that
+//      share a chunk with +-inf.
+// After that bucketing costs one ds_read_u8 and a shift-or per element instead of 2^K-1+K narrow-class VALU
+// instructions -- independent of K -- and runs on the otherwise idle LDS unit, which takes the forward from
+// VALU-bound back to memory-bound.  Blocks are 1024 threads (16 waves) so that two of them (2 x 64 KiB of LDS) fill
+// a CU with 32 waves.
+constexpr int kLutBlock = 1024;
+constexpr int kLutWaves = kLutBlock / kWave;
+
+template <int DT> __device__ __forceinline__ float value_of_pattern(uint32_t r) {
+    if constexpr (DT == FEWBIT_BF16) return bits_f32(r << 16);
+    else return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(r)));
+}
+
+template <int FN, int DT, int K, int U>
+__global__ __launch_bounds__(kLutBlock, 8) void quantize_forward_lut_kernel(const void *x, void *y, uint8_t *state,
+                                                                            size_t n, const void *borders,
+                                                                            int nborders, float p0, float p1) {
+    static_assert(DT != FEWBIT_F32, "the pattern table exists for 16-bit dtypes only");
+    constexpr int NBMAX = (1 << K) - 1;
+    constexpr uint32_t kInf = (DT == FEWBIT_BF16) ? 0x7f80u : 0x7c00u;
+    typedef typename GroupIO<DT>::Raw Raw;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[65536];
+    const Span s = make_span<U, kLutWaves>(n);
+
+    // the table's global loads go out FIRST (lane j fetches border j, as a float and as a raw pattern): the build then
+    // waits only for them, not for the first tile of x that pipeline2 issues right after
+    float mine = __builtin_inff();
+    uint32_t mine_raw = 0;
+    if (s.lane < nborders) {
+        mine = Elem<DT>::load(borders, s.lane);
+        mine_raw = static_cast<const uint16_t *>(borders)[s.lane];
+    }
+
+    struct Buf { Raw r[U]; };
+    auto build = [&]() {
+        // wave-uniform copy of the table (padding +inf never satisfies !(b >= x) for a number)
+        float b[NBMAX];
+#pragma unroll
+        for (int j = 0; j < NBMAX; ++j) b[j] = bits_f32(__builtin_amdgcn_readlane(f32_bits(mine), j));
+        // pass 1: chunk of 64 patterns per thread; a chunk that starts on a NaN pattern is all NaN -> nborders
+        const uint32_t r0 = threadIdx.x * 64u;
+        const uint32_t c_first = ((r0 & 0x7fffu) > kInf) ? static_cast<uint32_t>(nborders)
+                                                        : count_below<NBMAX>(b, value_of_pattern<DT>(r0));
+        const uint32_t c0 = c_first * 0x01010101u;
+        u32x4 fill = {c0, c0, c0, c0};
+        u32x4 *dst = reinterpret_cast<u32x4 *>(lut + r0);
+        dst[0] = fill; dst[1] = fill; dst[2] = fill; dst[3] = fill;
+        __syncthreads();
+        // pass 2: wave j corrects border j's chunk, all borders at once: lane l owns the l-th pattern past the border
+        // and adds/subtracts 1 in its byte with an LDS dword atomic (no carry: codes stay within 0..15).  NaN patterns
+        // are never touched here; the last wave rewrites the 63 NaN patterns that share a chunk with +-inf.
+        const int wv = threadIdx.x >> 6;
+        uint32_t *lut32 = reinterpret_cast<uint32_t *>(lut);
+        if (wv < nborders) {
+            const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine_raw), wv));
+            const uint32_t mag = bits & 0x7fffu;
+            const bool neg = (bits >> 15) != 0 && mag != 0;               // -0 behaves as +0
+            if (mag <= kInf) {                                              // a NaN border is counted for every x already
+                // first pattern whose predicate differs from that of its chunk's first pattern
+                const uint32_t first = neg ? 0x8000u + mag : mag + 1u;
+                const uint32_t r = first + s.lane;
+                if ((first & 63u) != 0 && r < ((first | 63u) + 1u) && (r & 0x7fffu) <= kInf) {
+                    const uint32_t one = 1u << (8u * (r & 3u));
+                    if (neg) __hip_atomic_fetch_sub(&lut32[r >> 2], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_fetch_add(&lut32[r >> 2], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        if (wv == kLutWaves - 1 && s.lane > 0) {                           // kInf is chunk aligned for bf16 and fp16
+            lut[kInf + s.lane] = static_cast<uint8_t>(nborders);
+            lut[0x8000u + kInf + s.lane] = static_cast<uint8_t>(nborders);
+        }
+        __syncthreads();
+    };
+
+    pipeline2<Buf>(
+        s, build,
+        [&](size_t t, Buf &buf) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + s.lane);
+        },
+        [&](size_t t, const Buf &buf) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t d = buf.r[u].q[i];
+                    w |= static_cast<uint32_t>(lut[d & 0xffffu]) << (K * 2 * i);
+                    w |= static_cast<uint32_t>(lut[d >> 16]) << (K * (2 * i + 1));
+                }
+                float v[8];
+                GroupIO<DT>::unpack(buf.r[u], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
+                const size_t g = (t * U + u) * kWave + s.lane;
+                GroupIO<DT>::template store<true>(y, g, v);
+                store_state_quad<K, false>(state, g, s.lane, w);
+            }
+        });
+
+    // ---- tail: element-wise through the same table, last wave only
+    if (s.wave != s.nwaves - 1) return;
+    for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
+        const size_t e0 = g << 3;
+        uint32_t w = 0;
+        for (int i = 0; i < 8; ++i) {
+            if (e0 + i < n) {
+                const uint32_t r = static_cast<const uint16_t *>(x)[e0 + i];
+                w |= static_cast<uint32_t>(lut[r]) << (K * i);
+                Elem<DT>::store(y, e0 + i, Act<FN, true>::eval(value_of_pattern<DT>(r), p0, p1));
             }
         }
         store_state<K>(state, g, w);
@@ -465,6 +592,9 @@ inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3
 #ifndef FEWBIT_U16_BWD
 #define FEWBIT_U16_BWD 2
 #endif
+#ifndef FEWBIT_U16_LUT
+#define FEWBIT_U16_LUT 1
+#endif
 // forward: 1 group per lane per stage (VALU-heavy, register budget); backward: 2 (memory-bound, deeper loads:
 // 8192x8192 fp16 backward 47.3 -> 43.0 us, no change at 4096x4096)
 template <int DT> struct Tile {
@@ -514,12 +644,55 @@ template <auto Kern> unsigned tile_grid(size_t n, int U) {
 #define FB_LAUNCH_TILED(KERN, N, U, STREAM, ...) \
     hipLaunchKernelGGL((KERN), dim3(tile_grid<(KERN)>((N), (U))), dim3(kBlock), 0, (STREAM), __VA_ARGS__)
 
+// pattern-table forward: 1024-thread blocks, two resident per CU (LDS), each wave loops over its tiles
+size_t lut_min_elements() {
+    static size_t v = 0;
+    if (v == 0) {
+        const char *e = getenv("FEWBIT_HIP_LUT_MIN");       // tuning hook; a huge value disables the kernel
+        v = e ? static_cast<size_t>(atoll(e)) : (static_cast<size_t>(1) << 21);
+        if (v == 0) v = 1;
+    }
+    return v;
+}
+
+template <auto Kern> unsigned lut_grid(size_t n, int U) {
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kern, kLutBlock, 0) != hipSuccess || nb < 1) nb = 1;
+        per_cu = nb > 2 ? 2 : nb;
+    }
+    const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
+    size_t blocks = (ntiles + kLutWaves - 1) / kLutWaves;
+    const size_t cap = static_cast<size_t>(device_cus()) * per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return static_cast<unsigned>(blocks);
+}
+
+#define FB_LAUNCH_LUT(KERN, N, U, STREAM, ...) \
+    hipLaunchKernelGGL((KERN), dim3(lut_grid<(KERN)>((N), (U))), dim3(kLutBlock), 0, (STREAM), __VA_ARGS__)
+
 unsigned group_grid(size_t n) { return static_cast<unsigned>(((n + 7) / 8 + kBlock - 1) / kBlock); }
 
 template <int FN, int DT>
 int launch_forward(const void *x, void *y, uint8_t *state, size_t n, const void *borders, int nborders, int k,
                    float p0, float p1, hipStream_t s) {
     constexpr int U = Tile<DT>::U;
+    if constexpr (DT != FEWBIT_F32) {
+        constexpr int UL = FEWBIT_U16_LUT;
+        // 16-bit dtypes, any table with k <= 4 (power of two or not): pattern-table kernel once the tensor is big
+        // enough to pay for building the table in every block
+        if (k <= 4 && aligned16(x) && aligned16(y) && aligned4(state) && n >= lut_min_elements()) {
+            switch (k) {
+            case 1: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 1, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
+            case 2: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 2, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
+            case 3: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 3, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
+            default: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 4, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
+            }
+            return check_launch("quantize_forward(lut)");
+        }
+    }
     const bool fast = (nborders == (1 << k) - 1) && k <= 4 && aligned16(x) && aligned16(y) && aligned4(state);
     if (fast) {
         switch (k) {

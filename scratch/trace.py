@@ -33,3 +33,20 @@ for slot in range(6):
 # per-wave durations
 d = rel[:, 1:4] - rel[:, 0:3]
 print('stage durations median (start->init, init->proc1 done, proc1->proc2 done):', np.nanmedian(d, axis=0))
+# who is late? (slot 1 = first data + tables ready)
+late = rel[:, 1] > np.nanpercentile(rel[:, 1], 85)
+wid = np.nonzero(nz)[0]
+blk = wid // 4 if which != 'lut' else wid // 16
+print('late waves:', late.sum(), ' distinct blocks containing late waves:', len(set(blk[late])), 'of', len(set(blk)))
+xcd = blk % 8
+print('late fraction by XCD (block%8):', [round(float(late[xcd == k].mean()), 2) for k in range(8)])
+print('late fraction by wave-in-block:', [round(float(late[(wid % 4) == k].mean()), 2) for k in range(4)])
+# are whole blocks late together?
+import collections
+cnt = collections.Counter(blk[late])
+print('late waves per late block histogram:', sorted(collections.Counter(cnt.values()).items()))
+order = np.argsort(wid)
+seg = late[order].astype(int)
+runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], seg, [0]]))))[::2]
+print('run lengths of consecutive late wave ids: max', runs.max() if len(runs) else 0, 'median', np.median(runs) if len(runs) else 0)
+print('first 40 late wave ids:', wid[late][:40].tolist())

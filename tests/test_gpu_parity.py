@@ -355,3 +355,37 @@ def test_more_than_2_pow_32_elements():
     want = (levels.float()[codes.long()] * gy_tail.float()).to(dtype)
     assert torch.equal(x[tail].view(torch.int16), want.view(torch.int16))
     assert state.numel() == 3 * ((n + 7) // 8)
+
+
+@pytest.mark.parametrize('dt', ('bf16', 'f16'))
+def test_every_16bit_pattern_against_oracle_codes(dt):
+    """All 65 536 input patterns x a set of tables chosen to stress the pattern-table kernel: built-in tables (1..4
+    bits), borders on +-0, on denormals, on +-inf, several borders inside one 64-pattern chunk, negative-only and
+    non power-of-two tables.  The tensor repeats the patterns often enough to take the table kernel (n >= 2^21) and
+    once more ragged and short (search kernel): both must give the oracle's codes for every pattern."""
+    dtype = DTYPES[dt]
+    iv = torch.int16
+    pats = torch.arange(-32768, 32768, dtype=torch.int32).to(iv).view(dtype)
+    def nxt(v, k=1):
+        return (torch.tensor([v]).to(dtype).view(iv) + k).view(dtype).item()
+    tables = [store.get('gelu', k, 'cpu', dtype)[0][1:-1].contiguous() for k in (1, 2, 3, 4)]
+    tables += [store.get('silu', 4, 'cpu', dtype)[0][1:-1].contiguous()]
+    one = 1.0
+    custom = [
+        [0.0], [-0.0], [-1.0, 0.0, 1.0], [float('-inf'), 0.5, float('inf')],
+        [one, nxt(one, 1), nxt(one, 2), nxt(one, 5), nxt(one, 40), nxt(one, 63), nxt(one, 64)],       # one chunk, many borders
+        [-nxt(one, 64), -nxt(one, 63), -nxt(one, 3), -nxt(one, 1), -one],
+        [-2.0, -1.0, -0.5], [0.25, 0.5, 2.0, 8.0, 100.0], [6e-8, 1e-7] if dt == 'f16' else [1e-40, 9e-39],
+        [-3.0, -1.5, -0.1, 0.0, 0.1, 1.5, 3.0, 7.0, 9.0, 11.0, 13.0, 15.0, 17.0],                  # 13 borders -> 4 bits
+    ]
+    tables += [torch.tensor(sorted(set(c))).to(dtype) for c in custom]
+    reps = (1 << 21) // 65536 + 1
+    big = pats.repeat(reps)[torch.randperm(65536 * reps, generator=torch.Generator().manual_seed(0))]
+    for inner in tables:
+        k = oracle.bitwidth(inner.numel() + 1)
+        for x in (big, pats[:65531]):
+            want = oracle.searchsorted(x, inner).to(torch.int32)
+            _, st = cabi.quantize_forward('identity', x.to(DEV), inner.to(DEV))
+            got = cabi.unpack_codes(st, x.numel(), k).cpu()
+            bad = got != want
+            assert not bad.any(), (dt, inner.tolist(), x[bad][:6].float().tolist(), got[bad][:6].tolist(), want[bad][:6].tolist())
