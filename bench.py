@@ -211,7 +211,7 @@ def main():
             'pct_of_hbm_roofline': round(100.0 * (total / elapsed / 1e9) / (HBM_PEAK_GBS * world), 2),
             'fwd_us': round(fwd_us, 2), 'bwd_us': round(bwd_us, 2), 'fwd_in_step_us': round(fwd_in_step_us, 2),
             'fwd_us_event_bracketed': round(fwd_us_ev, 2), 'bwd_us_event_bracketed': round(bwd_us_ev, 2),
-            'roofline': {'bound': 'hbm', 'kernel': 'quantize_forward_kernel<gelu, bf16, 3 bits>', 'achieved': round(achieved, 1),
+            'roofline': {'bound': 'hbm', 'kernel': 'quantize_forward_lut_kernel<gelu, bf16, 3 bits>', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': traffic, 'algorithmic_bytes_per_launch': int(fwd_bytes),
                          'avg_launch_us': round(fwd_in_step_us, 2),

@@ -649,7 +649,7 @@ size_t lut_min_elements() {
     static size_t v = 0;
     if (v == 0) {
         const char *e = getenv("FEWBIT_HIP_LUT_MIN");       // tuning hook; a huge value disables the kernel
-        v = e ? static_cast<size_t>(atoll(e)) : (static_cast<size_t>(1) << 21);
+        v = e ? static_cast<size_t>(atoll(e)) : (static_cast<size_t>(6) << 20);   // measured crossover: 2^22 search wins, 2^23 table wins
         if (v == 0) v = 1;
     }
     return v;

@@ -361,7 +361,7 @@ def test_more_than_2_pow_32_elements():
 def test_every_16bit_pattern_against_oracle_codes(dt):
     """All 65 536 input patterns x a set of tables chosen to stress the pattern-table kernel: built-in tables (1..4
     bits), borders on +-0, on denormals, on +-inf, several borders inside one 64-pattern chunk, negative-only and
-    non power-of-two tables.  The tensor repeats the patterns often enough to take the table kernel (n >= 2^21) and
+    non power-of-two tables.  The tensor repeats the patterns often enough to take the table kernel (n > 6 Mi) and
     once more ragged and short (search kernel): both must give the oracle's codes for every pattern."""
     dtype = DTYPES[dt]
     iv = torch.int16
@@ -379,7 +379,7 @@ def test_every_16bit_pattern_against_oracle_codes(dt):
         [-3.0, -1.5, -0.1, 0.0, 0.1, 1.5, 3.0, 7.0, 9.0, 11.0, 13.0, 15.0, 17.0],                  # 13 borders -> 4 bits
     ]
     tables += [torch.tensor(sorted(set(c))).to(dtype) for c in custom]
-    reps = (1 << 21) // 65536 + 1
+    reps = (1 << 23) // 65536 + 1
     big = pats.repeat(reps)[torch.randperm(65536 * reps, generator=torch.Generator().manual_seed(0))]
     for inner in tables:
         k = oracle.bitwidth(inner.numel() + 1)
