@@ -22,7 +22,7 @@ LIB_PATH = Path(os.environ.get('FEWBIT_HIP_LIB') or Path(__file__).resolve().wit
 
 # enum order of include/fewbit_hip.h
 CONTINUOUS = ('celu', 'elu', 'gelu', 'hardswish', 'logsigmoid', 'mish', 'selu', 'sigmoid', 'silu', 'softplus',
-              'softsign', 'tanh', 'tanhshrink', 'identity')
+              'softsign', 'tanh', 'tanhshrink', 'identity', 'identity_fold')
 STEPWISE1 = ('hardshrink', 'hardsigmoid', 'hardtanh', 'leaky_relu', 'relu', 'relu6', 'softshrink', 'threshold')
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 

@@ -441,6 +441,13 @@ template <int FN, bool FAST> struct Act {
             return x;
         }
     }
+    // the value the border table is searched with: x itself, except for the even-parity fold of a custom table
+    // (FEWBIT_IDENTITY_FOLD, p0 = shift_x), where it is the fp32 distance from the shift
+    static constexpr bool kFolded = (FN == FEWBIT_IDENTITY_FOLD);
+    static __device__ __forceinline__ float key(float x, float p0) {
+        if constexpr (kFolded) return fabsf(x - p0);
+        return x;
+    }
 };
 
 // 1-bit family: value and derivative-branch bit (fewbit/cuda/codec.cu:298-487 for the bit rules)

@@ -165,7 +165,15 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
 #if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 2)
                 const uint32_t w = f32_bits(v[0]) & 0xffffffu;  // ablation: no bucketing
 #else
-                const uint32_t w = pack_group<K>(v, b);
+                uint32_t w;
+                if constexpr (Act<FN, kFast>::kFolded) {
+                    float key[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) key[i] = Act<FN, kFast>::key(v[i], p0);
+                    w = pack_group<K>(key, b);
+                } else {
+                    w = pack_group<K>(v, b);
+                }
 #endif
 #if !(defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 1))
 #pragma unroll
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
         for (int i = 0; i < 8; ++i) {
             if (e0 + i < n) {
                 float xv = Elem<DT>::load(x, e0 + i);
-                w |= count_below<NB>(b, xv) << (K * i);
+                w |= count_below<NB>(b, Act<FN, kFast>::key(xv, p0)) << (K * i);
                 Elem<DT>::store(y, e0 + i, Act<FN, kFast>::eval(xv, p0, p1));
             }
         }
@@ -342,10 +350,11 @@ __global__ __launch_bounds__(kBlock) void quantize_forward_generic_kernel(const 
     for (int i = 0; i < 8; ++i) {
         if (e0 + i < n) {
             float xv = Elem<DT>::load(x, e0 + i);
+            const float key = Act<FN, false>::key(xv, p0);
             int lo = 0, hi = nborders;
             while (lo < hi) {
                 int mid = (lo + hi) >> 1;
-                if (!(sb[mid] >= xv)) lo = mid + 1;
+                if (!(sb[mid] >= key)) lo = mid + 1;
                 else hi = mid;
             }
             w |= static_cast<uint64_t>(lo) << (nbits * i);
@@ -679,7 +688,8 @@ template <int FN, int DT>
 int launch_forward(const void *x, void *y, uint8_t *state, size_t n, const void *borders, int nborders, int k,
                    float p0, float p1, hipStream_t s) {
     constexpr int U = Tile<DT>::U;
-    if constexpr (DT != FEWBIT_F32) {
+    // (a folded key |x - shift| is an fp32 value, not one of the 65 536 input patterns: search kernel only)
+    if constexpr (DT != FEWBIT_F32 && FN != FEWBIT_IDENTITY_FOLD) {
         constexpr int UL = FEWBIT_U16_LUT;
         // 16-bit dtypes, any table with k <= 4 (power of two or not): pattern-table kernel once the tensor is big
         // enough to pay for building the table in every block
@@ -798,7 +808,7 @@ int fewbit_hip_quantize_forward(int fn, int dtype, const void *x, void *y, uint8
         FB_CASE(FEWBIT_CELU) FB_CASE(FEWBIT_ELU) FB_CASE(FEWBIT_GELU) FB_CASE(FEWBIT_HARDSWISH)
         FB_CASE(FEWBIT_LOGSIGMOID) FB_CASE(FEWBIT_MISH) FB_CASE(FEWBIT_SELU) FB_CASE(FEWBIT_SIGMOID)
         FB_CASE(FEWBIT_SILU) FB_CASE(FEWBIT_SOFTPLUS) FB_CASE(FEWBIT_SOFTSIGN) FB_CASE(FEWBIT_TANH)
-        FB_CASE(FEWBIT_TANHSHRINK) FB_CASE(FEWBIT_IDENTITY)
+        FB_CASE(FEWBIT_TANHSHRINK) FB_CASE(FEWBIT_IDENTITY) FB_CASE(FEWBIT_IDENTITY_FOLD)
     default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown continuous fn %d", fn);
     }
 #undef FB_CASE

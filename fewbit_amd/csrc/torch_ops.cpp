@@ -194,14 +194,51 @@ Tensor softsign(const Tensor &self, const Tensor &b, const Tensor &l) { return c
 Tensor tanh(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_TANH, self, b, l); }
 Tensor tanhshrink(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_TANHSHRINK, self, b, l); }
 
-// custom table on the identity: the reference declares this schema without any kernel (fewbit/fewbit.cc:37,
-// NotImplementedError in fewbit/functional/activations.py:137-139).  The plain table works here;
-// parity/shift folding is a later row of SURVEY 8(f).
+// Custom table on the identity.  The reference declares this schema without any kernel (fewbit/fewbit.cc:37,
+// NotImplementedError in fewbit/functional/activations.py:137-139; module fewbit/modules/activations.py:97-134:
+// "parity: whether stepwise function is odd or even under shift transformation; shift: shift of the origin").
+// Semantics defined here, with (sx, sy) = shift and the table (b', l') given on the half line
+// t = |x - sx| >= 0, as fewbit/approx.py:92-101 produces it for `parity=True, domain=(0, x_max)`:
+//   even  g(sx+t) = g(sx-t):            code = #{b' < |x - sx|}, level = l'[code]   -- folded inside the kernel, so
+//                                        k bits address 2^k half-line levels (twice the resolution of a plain table)
+//   odd   g(sx+t)-sy = -(g(sx-t)-sy):   equal to the plain table  borders {sx-b'} u {sx} u {sx+b'},
+//                                        levels {2sy-l'} u {l'}  -- mirrored here (fp32, rounded once to the tensor
+//                                        dtype) and run through the plain kernels; the sign costs the one extra bit
+Tensor stepwise_folded_impl(const Tensor &self, const Tensor &b, const Tensor &l, bool even, double sx, double sy,
+                            bool inplace) {
+    if (even) return ContinuousFunction::apply(self, b, l, FEWBIT_IDENTITY_FOLD, sx, 0.0, inplace);
+    TORCH_CHECK(b.dim() == 1 && l.dim() == 1, "fewbit: `bounds` and `levels` must be one-dimensional");
+    TORCH_CHECK(b.numel() + 1 == l.numel(), "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ",
+                b.numel(), " and ", l.numel());
+    TORCH_CHECK(l.numel() <= 128, "fewbit: an odd-parity table mirrors to twice its size; at most 128 levels, got ", l.numel());
+    const Tensor bf = b.to(torch::kFloat), lf = l.to(torch::kFloat);
+    const Tensor centre = torch::full({1}, sx, bf.options());
+    const Tensor full_b = torch::cat({torch::rsub(bf.flip(0), sx), centre, bf.add(sx)}).to(self.scalar_type());
+    const Tensor full_l = torch::cat({torch::rsub(lf.flip(0), 2.0 * sy), lf}).to(self.scalar_type());
+    return ContinuousFunction::apply(self, full_b, full_l, FEWBIT_IDENTITY, 0.0, 0.0, inplace);
+}
+
+Tensor stepwise_folded(const Tensor &self, const Tensor &b, const Tensor &l, bool even, double sx, double sy) {
+    return stepwise_folded_impl(self, b, l, even, sx, sy, /*inplace=*/true);
+}
+
+Tensor stepwise_folded_out(const Tensor &self, const Tensor &b, const Tensor &l, bool even, double sx, double sy) {
+    return stepwise_folded_impl(self, b, l, even, sx, sy, /*inplace=*/false);
+}
+
+// the reference's schema: integer shift only (fewbit/fewbit.cc:37); `stepwise_folded` takes real shifts
 Tensor stepwise(const Tensor &self, const Tensor &b, const Tensor &l, std::optional<bool> parity,
                 c10::OptionalArrayRef<int64_t> shift) {
-    TORCH_CHECK_NOT_IMPLEMENTED(!parity.has_value() && !shift.has_value(),
-                                "fewbit: stepwise with parity/shift is not implemented");
-    return continuous(FEWBIT_IDENTITY, self, b, l);
+    if (!parity.has_value()) {
+        TORCH_CHECK(!shift.has_value(), "fewbit: stepwise `shift` needs a `parity`");
+        return continuous(FEWBIT_IDENTITY, self, b, l);
+    }
+    double sx = 0.0, sy = 0.0;
+    if (shift.has_value()) {
+        sx = static_cast<double>((*shift)[0]);
+        sy = static_cast<double>((*shift)[1]);
+    }
+    return stepwise_folded_impl(self, b, l, *parity, sx, sy, /*inplace=*/true);
 }
 
 // Out-of-place variants (additions, not in the reference): same kernels writing to a fresh tensor.  The python layer
@@ -262,6 +299,8 @@ TORCH_LIBRARY(fewbit, m) {
     m.def("stepwise   (Tensor(a!) self, Tensor bounds, Tensor levels, bool? parity=None, int[2]? shift=None) -> Tensor(a!)");
 
     // additions of this implementation (not part of the reference's operator set)
+    m.def("stepwise_folded(Tensor(a!) self, Tensor bounds, Tensor levels, bool even, float shift_x = 0.0, float shift_y = 0.0) -> Tensor(a!)");
+    m.def("stepwise_folded_out(Tensor self, Tensor bounds, Tensor levels, bool even, float shift_x = 0.0, float shift_y = 0.0) -> Tensor");
     m.def("continuous_out(Tensor self, Tensor bounds, Tensor levels, int fn, float p0 = 0.0, float p1 = 0.0) -> Tensor");
     m.def("stepwise1_out(Tensor self, int fn, float p0 = 0.0, float p1 = 0.0) -> Tensor");
 }
@@ -291,6 +330,8 @@ TORCH_LIBRARY_IMPL(fewbit, AutogradCUDA, m) {
     m.impl("tanhshrink", fewbit_amd::tanhshrink);
 
     m.impl("stepwise", fewbit_amd::stepwise);
+    m.impl("stepwise_folded", fewbit_amd::stepwise_folded);
+    m.impl("stepwise_folded_out", fewbit_amd::stepwise_folded_out);
     m.impl("continuous_out", fewbit_amd::continuous_out);
     m.impl("stepwise1_out", fewbit_amd::stepwise1_out);
 }

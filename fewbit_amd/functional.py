@@ -81,7 +81,11 @@ class _HostQuantized(torch.autograd.Function):
     def forward(ctx, impl, input, borders, levels, *args):
         if borders.numel() + 1 != levels.numel():
             raise ValueError('Size of `borders` should be lesser than size of `levels` by one.')
-        state = torch.searchsorted(borders.float().contiguous(), input.detach().float().contiguous()).to(torch.uint8)
+        key = input.detach().float().contiguous()
+        fold = getattr(impl, 'fold', None)
+        if fold is not None:                       # even-parity fold of a custom table: search |x - shift_x|
+            key = (key - fold).abs()
+        state = torch.searchsorted(borders.float().contiguous(), key).to(torch.uint8)
         ctx.save_for_backward(state, levels)
         ctx.nargs = 4 + len(args)
         return impl(input, *args)
@@ -90,6 +94,16 @@ class _HostQuantized(torch.autograd.Function):
     def backward(ctx, grad_output):
         state, levels = ctx.saved_tensors
         return (None, levels[state.long()] * grad_output) + (None, ) * (ctx.nargs - 2)
+
+
+class _FoldedIdentity:
+    """Forward of a custom table (identity) that asks the host path to search ``|x - fold|``."""
+
+    def __init__(self, fold: float):
+        self.fold = fold
+
+    def __call__(self, t):
+        return t.clone()
 
 
 def _bind_extra(name: str, args: tuple, kwargs: dict) -> tuple:
@@ -173,9 +187,31 @@ def _make_stepwise1(name: str) -> Callable:
 def stepwise(input: torch.Tensor, borders: torch.Tensor, levels: torch.Tensor, parity: Optional[bool] = None,
              shift: Optional[Tuple[float, float]] = None) -> torch.Tensor:
     """Identity forward with a custom stepwise derivative: ``borders`` are the inner borders (one fewer than
-    ``levels``).  ``parity``/``shift`` are declared by the reference but implemented nowhere (fewbit/fewbit.cc:37)."""
-    if parity is not None or shift is not None:
-        raise NotImplementedError('stepwise with parity/shift is not implemented')
+    ``levels``).
+
+    ``parity``/``shift`` are declared by the reference and implemented nowhere in it (fewbit/fewbit.cc:37,
+    fewbit/functional/activations.py:137-139 raises NotImplementedError); here, with ``shift = (sx, sy)`` and the
+    table given on the half line ``t = |x - sx| >= 0`` (what ``approximate(parity=True, domain=(0, x_max))`` makes):
+
+    * ``parity=True``  -- the step function is even about ``sx``: ``level = levels[#{b < |x - sx|}]``; the fold
+      happens inside the kernel, so k bits address 2^k half-line levels;
+    * ``parity=False`` -- odd about ``(sx, sy)``: ``level = l'`` right of ``sx`` and ``2*sy - l'`` left of it, i.e.
+      the plain table mirrored to twice its size (one more bit: the sign).
+    """
+    if parity is None:
+        if shift is not None:
+            raise ValueError('`shift` needs a `parity`.')
+    else:
+        sx, sy = (0.0, 0.0) if shift is None else (float(shift[0]), float(shift[1]))
+        if input.device.type == 'cuda':
+            op = _native_op('stepwise_folded_out' if input._is_view() else 'stepwise_folded')
+            return op(input, borders.to(input), levels.to(input), bool(parity), sx, sy)
+        if parity:
+            return _HostQuantized.apply(_FoldedIdentity(sx), input, borders.to(input), levels.to(input))
+        bf, lf = borders.float(), levels.float()
+        full_b = torch.cat([sx - bf.flip(0), bf.new_full((1, ), sx), bf + sx]).to(input)
+        full_l = torch.cat([2.0 * sy - lf.flip(0), lf]).to(input)
+        return _HostQuantized.apply(lambda t: t.clone(), input, full_b, full_l)
     if input.device.type == 'cuda':
         if input._is_view():
             _native_op('stepwise')

@@ -27,8 +27,10 @@ class Stepwise(torch.nn.Module):
 
     :param borders: inner borders of the intervals (or with both outer sentinels, which are then dropped).
     :param levels: value of the derivative on every interval.
-    :param parity: declared by the reference, not implemented (must be None).
-    :param shift: declared by the reference, not implemented (must be None).
+    :param parity: ``True``: the table is given on ``t = |x - shift_x| >= 0`` and the step function is even about
+                   ``shift_x``; ``False``: odd about ``(shift_x, shift_y)``; ``None``: plain table.
+                   See :func:`fewbit.functional.stepwise`.
+    :param shift: ``(shift_x, shift_y)``, origin of the symmetry (default ``(0, 0)``).
     """
 
     def __init__(self, borders: torch.Tensor, levels: torch.Tensor, parity: Optional[bool] = None,

@@ -73,7 +73,11 @@ typedef enum fewbit_continuous_fn {
     FEWBIT_TANH = 11,
     FEWBIT_TANHSHRINK = 12,
     FEWBIT_IDENTITY = 13, /* y = x: quantize only (custom `stepwise` tables) */
-    FEWBIT_CONTINUOUS_COUNT = 14
+    /* y = x, code from the FOLDED key |x - p0| (fp32): the even-`parity` form of the custom `stepwise` table that the
+     * reference declares (fewbit/fewbit.cc:37, fewbit/modules/activations.py:97-134) and never implements; the
+     * borders are those of the half line t >= 0 (fewbit/approx.py:92-101, domain (0, x_max)), p0 = shift_x */
+    FEWBIT_IDENTITY_FOLD = 14,
+    FEWBIT_CONTINUOUS_COUNT = 15
 } fewbit_continuous_fn;
 
 /* piecewise-linear activations: exact 1-bit state (fewbit/fewbit.cc:10-18) */

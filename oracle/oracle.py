@@ -21,7 +21,7 @@ HERE = Path(__file__).resolve().parent
 
 # ids shared with include/fewbit_hip.h
 CONTINUOUS = ('celu', 'elu', 'gelu', 'hardswish', 'logsigmoid', 'mish', 'selu', 'sigmoid', 'silu', 'softplus',
-              'softsign', 'tanh', 'tanhshrink')
+              'softsign', 'tanh', 'tanhshrink', 'identity', 'identity_fold')
 STEPWISE1 = ('hardshrink', 'hardsigmoid', 'hardtanh', 'leaky_relu', 'relu', 'relu6', 'softshrink', 'threshold')
 
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 import fewbit
 import fewbit_amd
+import oracle
 from fewbit_amd import cabi
 from helpers import DTYPES, GOLDEN, ROOT, assert_bit_equal
 
@@ -108,8 +109,8 @@ def test_error_behaviour_matches_reference(api):
         fewbit.functional.gelu(x, bits=7)
     with pytest.raises(ValueError):   # size mismatch, fewbit/functional/activations.py:112-114
         fewbit.functional.gelu(x, borders=torch.tensor([-100., 0., 1., 100.]), values=torch.zeros(5))
-    with pytest.raises(NotImplementedError):
-        fewbit.functional.stepwise(x, torch.zeros(1), torch.zeros(2), parity=True)
+    with pytest.raises(ValueError):   # a shift is the origin of a symmetry: meaningless without `parity`
+        fewbit.functional.stepwise(x, torch.zeros(1), torch.zeros(2), shift=(1.0, 0.0))
     with pytest.raises(TypeError):
         fewbit.functional.threshold(x)          # threshold and value are required
     with pytest.raises(ValueError):
@@ -205,3 +206,36 @@ def test_gpu_tensor_without_native_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(fewbit_amd, '_native_error', 'simulated')
     with pytest.raises(RuntimeError, match='native library is not loaded'):
         fewbit_amd.functional._native_op('gelu')
+
+
+def test_host_stepwise_parity_and_shift():
+    """`Stepwise(borders, levels, parity, shift)` (declared by the reference, fewbit/modules/activations.py:97-134,
+    implemented nowhere in it).  Even: level = l'[#{b' < |x - sx|}].  Odd about (sx, sy): the mirrored plain table.
+    The host path must agree with the oracle's codes and with a direct restatement of the definition."""
+    b = torch.tensor([0.5, 1.0, 2.0])
+    l = torch.tensor([1.0, 0.6, 0.3, 0.1])
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(500, generator=g) * 2, torch.tensor([0.0, -0.0, 0.5, -0.5, 1.5, 2.5, -1.0, float('nan'),
+                                                                      float('inf'), -float('inf')])])
+    for sx in (0.0, 1.0, -0.25):
+        xr = x.clone().requires_grad_()
+        y = fewbit.Stepwise(b, l, parity=True, shift=(sx, 7.0))(xr * 1.0)
+        y.backward(torch.ones_like(y))
+        _, st, k = oracle.quantize('identity_fold', x, b, sx)
+        codes = torch.from_numpy(oracle.inflate(st.numpy(), x.numel(), k)).long()
+        assert k == 2 and torch.equal(xr.grad, l[codes])
+        t = (x - sx).abs()
+        want = torch.where(t > 2.0, 0.1, torch.where(t > 1.0, 0.3, torch.where(t > 0.5, 0.6, 1.0)))
+        want[torch.isnan(x)] = 0.1
+        assert torch.equal(xr.grad, want)
+        assert torch.equal(y.detach()[~torch.isnan(x)], x[~torch.isnan(x)])
+        # odd about (sx, 0.5): right of sx the table itself, left of it 2*sy - l'
+        xr = x.clone().requires_grad_()
+        fewbit.functional.stepwise(xr * 1.0, b, l, parity=False, shift=(sx, 0.5)).sum().backward()
+        right = x > sx
+        # a value ON a mirrored border belongs to the bucket further left (plain-table rule "b < x"), i.e. closed
+        # intervals in t on the left side
+        left = torch.where(t >= 2.0, 0.1, torch.where(t >= 1.0, 0.3, torch.where(t >= 0.5, 0.6, 1.0)))
+        want_odd = torch.where(right, want, 1.0 - left)
+        want_odd[torch.isnan(x)] = 0.1
+        assert torch.equal(xr.grad, want_odd)

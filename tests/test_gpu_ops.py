@@ -114,8 +114,8 @@ def test_errors_and_contracts():
         torch.ops.fewbit.gelu(x.double(), b[1:-1].double(), l.double())
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.fewbit.gelu(torch.randn(8), b[1:-1].cpu(), l.cpu())     # no CPU kernel behind the op
-    with pytest.raises(NotImplementedError):
-        torch.ops.fewbit.stepwise(x.clone(), b[1:-1], l, True, None)
+    with pytest.raises(RuntimeError, match='parity'):                     # a shift without a parity means nothing
+        torch.ops.fewbit.stepwise(x.clone(), b[1:-1], l, None, [1, 0])
     leaf = torch.randn(8, device=DEV, requires_grad=True)
     with pytest.raises(RuntimeError):                                     # in-place on a leaf, as in the reference
         fewbit.functional.gelu(leaf)
@@ -186,3 +186,99 @@ def test_view_inputs_run_out_of_place_and_match():
     assert y.data_ptr() != v.data_ptr() and torch.equal(y, F.relu(v))
     y.sum().backward()
     assert torch.equal(r.grad.view(4, 256), (v > 0).float())
+
+
+def test_hip_graph_capture_and_replay():
+    """The launches never synchronise or touch the host, so a whole forward+backward (operator level, autograd
+    included) can be captured into a hipGraph once and replayed on new data: the replay must give the oracle's
+    packed bytes and gradients for the data that is in the static buffers at replay time."""
+    from fewbit_amd import cabi
+    n, k = 40_000 + 3, 3
+    dtype = torch.bfloat16
+    b, l = fewbit.functional.store.get('gelu', k, DEV, dtype)
+    inner = b[1:-1].contiguous()
+    xs = torch.zeros(n, device=DEV, dtype=dtype)             # static graph inputs
+    gs = torch.zeros(n, device=DEV, dtype=dtype)
+    y = torch.empty_like(xs)
+    gx = torch.empty_like(xs)
+    st = torch.empty(cabi.state_nbytes(n, k), dtype=torch.uint8, device=DEV)
+    xa = torch.zeros(n, device=DEV, dtype=dtype, requires_grad=True)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                            # warm-up outside the capture (allocator, lazy init)
+        for _ in range(2):
+            cabi.quantize_forward('gelu', xs, inner, out=y, state=st)
+            cabi.quantize_backward(gs, st, l, out=gx)
+            out = fewbit.functional.gelu(xa * 1.0, bits=k)
+            ga, = torch.autograd.grad(out, xa, gs)
+    torch.cuda.current_stream().wait_stream(side)
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cabi.quantize_forward('gelu', xs, inner, out=y, state=st)       # C-ABI launches on the capturing stream
+        cabi.quantize_backward(gs, st, l, out=gx)
+        out = fewbit.functional.gelu(xa * 1.0, bits=k)                  # operator + autograd node
+        ga, = torch.autograd.grad(out, xa, gs)
+
+    for seed in (1, 2):
+        g = torch.Generator().manual_seed(seed)
+        xh = (torch.randn(n, generator=g) * 2).to(dtype)
+        gh = torch.randn(n, generator=g).to(dtype)
+        xs.copy_(xh)
+        gs.copy_(gh)
+        with torch.no_grad():
+            xa.copy_(xh)
+        graph.replay()
+        torch.cuda.synchronize()
+        y_o, st_o, _ = oracle.quantize('gelu', xh, inner.cpu())
+        gx_o = oracle.quantize_backward(gh, st_o, l.cpu())
+        assert torch.equal(st.cpu(), st_o)
+        assert_bit_equal(gx.cpu(), gx_o)
+        assert_bit_equal(ga.cpu(), gx_o)
+        assert torch.equal(out.detach().cpu().view(torch.int16), y.cpu().view(torch.int16))
+        assert forward_value_ok(xh, y.cpu(), y_o).all()
+
+
+@pytest.mark.parametrize('dt', list(DTYPES))
+def test_stepwise_parity_and_shift_on_gpu(dt):
+    """fewbit.Stepwise(borders, levels, parity, shift) on the GPU against the oracle: even -> folded key, 2 bits for 4
+    half-line levels; odd -> the mirrored plain table (8 levels, 3 bits) built in fp32 and rounded once."""
+    dtype = DTYPES[dt]
+    b = torch.tensor([0.5, 1.0, 2.0]).to(dtype)
+    l = torch.tensor([1.0, 0.6, 0.3, 0.1]).to(dtype)
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(5000, generator=g) * 2,
+                   torch.tensor([0.0, -0.0, 0.5, -0.5, 1.5, 2.5, -1.0, float('inf'), -float('inf')])]).to(dtype)
+    gy = torch.randn(x.numel(), generator=g).to(dtype)
+    for sx, sy in ((0.0, 0.5), (1.0, 0.25)):
+        # even
+        m = fewbit.Stepwise(b, l, parity=True, shift=(sx, sy)).to(DEV)
+        xr = x.to(DEV).requires_grad_()
+        y = m(xr.clone())          # (torch's own fp16 `x * 1.0` turns -0 into +0 in its tail)
+        y.backward(gy.to(DEV))
+        _, st, _ = oracle.quantize('identity_fold', x, b, sx)
+        assert_bit_equal(xr.grad.cpu(), oracle.quantize_backward(gy, st, l), f'even {dt} {sx}')
+        assert_bit_equal(y.detach().cpu(), x, f'even y {dt}')
+        # odd
+        full_b = torch.cat([sx - b.float().flip(0), torch.tensor([sx]), b.float() + sx]).to(dtype)
+        full_l = torch.cat([2.0 * sy - l.float().flip(0), l.float()]).to(dtype)
+        xr = x.to(DEV).requires_grad_()
+        y = fewbit.functional.stepwise(xr.clone(), b.to(DEV), l.to(DEV), parity=False, shift=(sx, sy))
+        y.backward(gy.to(DEV))
+        _, st, k = oracle.quantize('identity', x, full_b)
+        assert k == 3
+        assert_bit_equal(xr.grad.cpu(), oracle.quantize_backward(gy, st, full_l), f'odd {dt} {sx}')
+        # the reference's own schema (integer shift)
+        xr2 = x.to(DEV).requires_grad_()
+        y2 = torch.ops.fewbit.stepwise(xr2.clone(), b.to(DEV), l.to(DEV), True, [int(sx), 0])
+        y2.backward(gy.to(DEV))
+        _, st, _ = oracle.quantize('identity_fold', x, b, float(int(sx)))
+        assert_bit_equal(xr2.grad.cpu(), oracle.quantize_backward(gy, st, l), f'schema {dt}')
+    # view input -> out-of-place operator
+    base = torch.randn(4, 64, device=DEV, dtype=dtype, requires_grad=True)
+    v = (base * 1.0).view(256)
+    out = fewbit.functional.stepwise(v, b.to(DEV), l.to(DEV), parity=True)
+    assert out.data_ptr() != v.data_ptr()
+    out.sum().backward()
+    assert base.grad.shape == base.shape

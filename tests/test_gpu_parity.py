@@ -133,7 +133,7 @@ def test_forward_backward_vs_oracle(name, dt, k):
         assert_bit_equal(cabi.unpack_codes(state, n, k).cpu(), oracle.searchsorted(x, inner).to(torch.int32), tag + ' codes')
 
 
-@pytest.mark.parametrize('name', [f for f in cabi.CONTINUOUS if f not in ('gelu', 'silu', 'identity')])
+@pytest.mark.parametrize('name', [f for f in cabi.CONTINUOUS if f not in ('gelu', 'silu', 'identity', 'identity_fold')])
 @pytest.mark.parametrize('dt', list(DTYPES))
 def test_remaining_continuous_functions(name, dt):
     dtype = DTYPES[dt]
@@ -389,3 +389,51 @@ def test_every_16bit_pattern_against_oracle_codes(dt):
             got = cabi.unpack_codes(st, x.numel(), k).cpu()
             bad = got != want
             assert not bad.any(), (dt, inner.tolist(), x[bad][:6].float().tolist(), got[bad][:6].tolist(), want[bad][:6].tolist())
+
+
+@pytest.mark.parametrize('dt', list(DTYPES))
+@pytest.mark.parametrize('nlev', (2, 4, 7, 8, 16, 40))
+def test_folded_custom_table_vs_oracle(dt, nlev):
+    """Even-parity fold (FEWBIT_IDENTITY_FOLD): the key searched is |x - shift_x| in fp32.  Tables of 1..4 bits take the
+    streaming search kernel, wider/ragged/misaligned ones the generic kernel; all must give the oracle's bytes."""
+    dtype = DTYPES[dt]
+    g = torch.Generator().manual_seed(nlev)
+    half = torch.sort(torch.rand(nlev - 1, generator=g) * 3 + 0.01).values.to(dtype)
+    half = torch.unique(half)
+    levels = torch.rand(half.numel() + 1, generator=g).to(dtype)
+    for sx in (0.0, 0.75, -1.25):
+        for n in (1, 9, 513, 4097, 100_003):
+            x, gy = make_x(n, dtype, torch.cat([sx - half.float(), sx + half.float()]), seed=n)
+            y_o, s_o, k = oracle.quantize('identity_fold', x, half, sx)
+            y, state = cabi.quantize_forward('identity_fold', x.to(DEV), half.to(DEV), sx)
+            tag = f'fold {dt} nlev={nlev} sx={sx} n={n}'
+            assert_bit_equal(state.cpu(), s_o, tag + ' state')
+            fin = ~torch.isnan(x)
+            assert_bit_equal(y.cpu()[fin], x[fin], tag + ' y')
+            assert_bit_equal(cabi.quantize_backward(gy.to(DEV), state, levels.to(DEV)).cpu(),
+                             oracle.quantize_backward(gy, s_o, levels), tag + ' gx')
+    # misaligned pointers -> generic kernel
+    x, _ = make_x(4099, dtype, half, seed=5)
+    xd = torch.empty(4099 + 8, dtype=dtype, device=DEV)[3:3 + 4099]
+    xd.copy_(x)
+    _, s_o, _ = oracle.quantize('identity_fold', x, half, 0.5)
+    _, state = cabi.quantize_forward('identity_fold', xd, half.to(DEV), 0.5)
+    assert_bit_equal(state.cpu(), s_o, 'fold misaligned')
+
+
+def test_folded_full_size_properties():
+    """4096x4096 bf16, even fold at 3 bits: codes == bucketize(|x - sx|) computed with torch on the GPU in fp32, and an
+    oracle window."""
+    dtype = torch.bfloat16
+    n = 4096 * 4096
+    half = torch.tensor([0.2, 0.5, 0.9, 1.4, 2.0, 2.7, 3.5]).to(dtype)
+    sx = 0.125
+    x = (torch.randn(n, generator=torch.Generator().manual_seed(11)) * 2).to(dtype)
+    xd = x.to(DEV)
+    _, state = cabi.quantize_forward('identity_fold', xd, half.to(DEV), sx)
+    codes = cabi.unpack_codes(state, n, 3)
+    want = torch.bucketize((xd.float() - sx).abs(), half.to(DEV).float())
+    assert torch.equal(codes.long(), want)
+    w = slice(8 * 70_001, 8 * 70_001 + 80_000)
+    _, s_o, _ = oracle.quantize('identity_fold', x[w], half, sx)
+    assert torch.equal(state[3 * 70_001:3 * 70_001 + 30_000].cpu(), s_o)

@@ -160,7 +160,7 @@ def _torch_fn(name):
     return getattr(torch, name) if name in ('sigmoid', 'tanh') else getattr(F, name)
 
 
-@pytest.mark.parametrize('name', oracle.CONTINUOUS)
+@pytest.mark.parametrize('name', [f for f in oracle.CONTINUOUS if not f.startswith('identity')])
 def test_continuous_forward_tracks_torch(name):
     """Reference test bar (fewbit/functional/activations_test.py:81-89): ||fewbit(x) - F(x)||_2 <= 1e-6
     on linspace(-5, 5, 101); here additionally max 2 fp32 steps relative to max(|y|, tiny)."""
@@ -195,3 +195,22 @@ def test_stepwise1_tracks_torch(name, args):
     # only leaky_relu's backward takes a parameter (its slope)
     gx = oracle.stepwise1_backward(name, torch.ones(101), state, *(p[:1] if name == 'leaky_relu' else ()))
     assert torch.linalg.norm(gx - x.grad).item() < 1e-6
+
+
+@pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16, torch.float16))
+def test_folded_key_is_the_fp32_distance_from_the_shift(dtype):
+    """FEWBIT_IDENTITY_FOLD (include/fewbit_hip.h): code = #{b' < |x - sx|}, the subtraction in fp32.  No reference
+    behaviour exists (declared only, fewbit/fewbit.cc:37): pinned against a numpy restatement of the definition."""
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4099, generator=g) * 2).to(dtype)
+    x[:4] = torch.tensor([float('nan'), float('inf'), -float('inf'), -0.0]).to(dtype)
+    b = torch.tensor([0.25, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0]).to(dtype)
+    for sx in (0.0, 0.3, -1.0):
+        y, st, k = oracle.quantize('identity_fold', x, b, sx)
+        codes = oracle.inflate(st.numpy(), x.numel(), k)
+        key = np.abs(x.float().numpy() - np.float32(sx))
+        want = np.searchsorted(b.float().numpy(), key, side='left')
+        want[np.isnan(key)] = b.numel()
+        assert k == 3 and np.array_equal(codes, want)
+        iv = torch.int32 if dtype == torch.float32 else torch.int16
+        assert torch.equal(y[1:].view(iv), x[1:].view(iv)) and torch.isnan(y[0])          # identity forward
