@@ -30,4 +30,8 @@ for name, k, dtype, n in (('gelu', 3, torch.bfloat16, 4096 * 4096), ('silu', 2, 
     fc, bc = timeit(F, it), timeit(B, it)
     byts = n * (2 * es + k / 8)
     print(f'{tag} {name} k={k} {str(dtype)[6:]} n={n}: warm fwd {fw:.1f} bwd {bw:.1f} us ({2*byts/(fw+bw)/1e6:.2f} TB/s = {2*byts/(fw+bw)/8e4:.1f}%) | cold fwd {fc:.1f} bwd {bc:.1f} us ({2*byts/(fc+bc)/1e6:.2f} TB/s = {2*byts/(fc+bc)/8e4:.1f}%)')
-    del sets, F, B
+    C = [(lambda a=x, b=y: b.copy_(a)) for x, y, st in sets]
+    cw, cc = timeit([C[0]], 300), timeit(C, it)
+    cb = n * 2 * es
+    print(f'    torch copy_ of the same tensor: warm {cw:.1f} us ({cb/cw/1e6:.2f} TB/s) | cold {cc:.1f} us ({cb/cc/1e6:.2f} TB/s)')
+    del sets, F, B, C
