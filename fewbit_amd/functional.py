@@ -226,3 +226,8 @@ for _name in STEPWISE:
     if _name != 'stepwise':
         globals()[_name] = _make_stepwise1(_name)
 del _name
+
+# Randomized linear layers and gradient-capture helpers live in the same namespace in the reference
+# (fewbit/functional/__init__.py:14-18).
+from .linear import linear_crs, linear_grp, linear_randomized  # noqa: E402,F401
+from .variance import GradientStorage, catch_gradients  # noqa: E402,F401

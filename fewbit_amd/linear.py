@@ -1,0 +1,262 @@
+"""Linear layers that keep a *compressed* copy of their input for the weight gradient.
+
+Counterpart of the reference's randomized layers (``fewbit/functional/linear.py``, ``fewbit/modules/linear.py``;
+paper: "Memory-Efficient Backpropagation through Large Linear Layers", arXiv:2201.13195).  Same public names
+(``linear_crs``, ``linear_grp``, ``linear_randomized``; ``LinearCRS``, ``LinearGRP``, ``RandomizedLinear``) and
+constructor / call signatures; the implementation is this repository's own:
+
+* forward is exactly ``F.linear``; the input gradient is exact; only ``dL/dW = G^T X`` (G, X: rows x features) is
+  estimated, from a sketch ``S`` (p x rows, ``E[S^T S] = I``): saved for backward is ``S X`` (p rows instead of
+  ``rows``), backward recomputes ``S`` from the saved generator state and forms ``(S G)^T (S X)``;
+* the sketch is drawn in the *input's dtype*, so with bf16/fp16 activations both sketch GEMMs run on the matrix
+  cores (hipBLASLt through ``torch.matmul``) -- the reference draws fp32 and cannot multiply it with 16-bit inputs;
+* every sketch is unbiased.  The reference's ``'dct'``/``'dft'`` branches scale the sampled rows by ``p * rows``
+  (``fewbit/functional/linear.py:124-137``) where unbiasedness needs ``rows / p``, and its ``'dft'`` backward drops
+  the imaginary part before the product (:189-197, :214-216); neither defect is reproduced (they are not covered by
+  the reference's tests, which only run the default ``'gaussian'``, ``fewbit/modules/linear_test.py``);
+* without a user generator the sketch seed comes from the host default generator (so ``torch.manual_seed`` makes
+  runs reproducible) and never reads back from the device -- no stream synchronisation in forward or backward.
+
+This is PyTorch-level code (GEMM- and FFT-bound); it is outside the quantized-activation hot path that the HIP
+kernels of this package implement.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .fft import dct
+
+__all__ = ('MATMUL_TYPES', 'projection_dim', 'linear_crs', 'linear_grp', 'linear_randomized', 'LinearCRS', 'LinearGRP',
+           'RandomizedLinear')
+
+MATMUL_TYPES = ('dct', 'dft', 'gaussian', 'rademacher')
+
+
+def projection_dim(rows: int, proj_dim_ratio: Optional[float] = None, proj_dim: Optional[int] = None,
+                   proj_dim_max: Optional[int] = None, proj_dim_min: Optional[int] = None) -> int:
+    """Number of sketch rows for an input of ``rows`` rows: ``proj_dim``, else ``int(ratio * rows)``, clamped to
+    ``[proj_dim_min, proj_dim_max]`` (reference: ``LinearGRPFunc.calc_proj_dim``, fewbit/functional/linear.py:73-83)."""
+    if proj_dim:
+        p = int(proj_dim)
+    elif proj_dim_ratio:
+        p = int(proj_dim_ratio * rows)
+    else:
+        p = int(rows)
+    if proj_dim_min:
+        p = max(int(proj_dim_min), p)
+    if proj_dim_max:
+        p = min(int(proj_dim_max), p)
+    return max(p, 1)
+
+
+# ---- random state that can be replayed in backward ------------------------------------------------------------------
+
+def _capture_rng(generator: Optional[torch.Generator], device: torch.device):
+    """-> (token, generator to draw from now).  The token rebuilds an identical generator later."""
+    if generator is not None:
+        return ('state', generator.device, generator.get_state()), generator
+    seed = int(torch.randint(0, 2**62, (), dtype=torch.int64).item())          # host generator: no device round trip
+    gen_device = device if device.type == 'cuda' else torch.device('cpu')
+    return ('seed', gen_device, seed), torch.Generator(device=gen_device).manual_seed(seed)
+
+
+def _replay_rng(token) -> torch.Generator:
+    kind, device, payload = token
+    gen = torch.Generator(device=device)
+    if kind == 'seed':
+        gen.manual_seed(payload)
+    else:
+        gen.set_state(payload)
+    return gen
+
+
+def _dense_sketch(kind: str, p: int, rows: int, like: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
+    if kind == 'gaussian':
+        return torch.randn((p, rows), generator=gen, device=gen.device, dtype=like.dtype).to(like.device)
+    signs = torch.randint(0, 2, (p, rows), generator=gen, device=gen.device, dtype=torch.int8).to(like.device)
+    return (signs.to(like.dtype) * 2) - 1                                       # Rademacher: +-1
+
+
+def _sampled_rows(p: int, rows: int, like: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
+    return torch.randint(0, rows, (p, ), generator=gen, device=gen.device).to(like.device)
+
+
+def _sketch(kind: str, mat: torch.Tensor, p: int, gen: torch.Generator) -> torch.Tensor:
+    """``S @ mat`` for the unscaled sketch (``E[S^T S] = p * I`` dense, ``(p / rows) * I`` for sampled transforms)."""
+    rows = mat.shape[0]
+    if kind in ('gaussian', 'rademacher'):
+        return _dense_sketch(kind, p, rows, mat, gen) @ mat
+    idx = _sampled_rows(p, rows, mat, gen)
+    if kind == 'dct':
+        return dct(mat, dim=0, norm='ortho')[idx]
+    work = mat if mat.dtype in (torch.float32, torch.float64) else mat.float()
+    return torch.fft.fft(work, dim=0, norm='ortho')[idx]                        # complex
+
+
+class _LinearGRP(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, p: int, kind: str, generator):
+        flat = input.reshape(-1, input.shape[-1])
+        token, gen = _capture_rng(generator, input.device)
+        rows = flat.shape[0]
+        scale = 1.0 / p if kind in ('gaussian', 'rademacher') else rows / p
+        sketch = _sketch(kind, flat.detach(), p, gen) * scale
+        ctx.save_for_backward(sketch, weight)
+        ctx.token, ctx.p, ctx.kind = token, p, kind
+        ctx.has_bias = bias is not None
+        return F.linear(input, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        sketch, weight = ctx.saved_tensors
+        grad_input = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            grad_input = grad_output @ weight
+        flat = grad_output.reshape(-1, grad_output.shape[-1])
+        if ctx.needs_input_grad[1]:
+            proj = _sketch(ctx.kind, flat, ctx.p, _replay_rng(ctx.token))
+            if proj.is_complex():                                               # Re((F G)^H (F X))
+                grad_weight = (proj.real.T @ sketch.real + proj.imag.T @ sketch.imag).to(weight.dtype)
+            else:
+                grad_weight = (proj.T @ sketch).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = flat.sum(dim=0)
+        return grad_input, grad_weight, grad_bias, None, None, None
+
+
+def linear_grp(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               proj_dim_ratio: Optional[float] = None, proj_dim: Optional[int] = None,
+               proj_dim_max: Optional[int] = None, proj_dim_min: Optional[int] = None, matmul: str = 'gaussian',
+               generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """``F.linear(input, weight, bias)`` whose weight gradient is estimated through a random projection of the rows
+    (argument order of the reference's ``linear_grp``, fewbit/functional/linear.py:85-90)."""
+    if proj_dim_ratio is None and proj_dim is None:
+        raise ValueError('Either proj_dim or proj_dim_ratio should be specified.')
+    if proj_dim_min is not None and proj_dim_min <= 0:
+        raise ValueError('Param proj_dim_min should be strictly positive.')
+    if proj_dim_min and proj_dim_max and proj_dim_max < proj_dim_min:
+        raise ValueError('Param proj_dim_min should be not greater than param proj_dim_max.')
+    if matmul not in MATMUL_TYPES:
+        raise ValueError(f'Unexpected matmul type: {matmul}.')
+    rows = input.numel() // input.shape[-1] if input.numel() else 0
+    p = projection_dim(rows, proj_dim_ratio, proj_dim, proj_dim_max, proj_dim_min)
+    return _LinearGRP.apply(input, weight, bias, p, matmul, generator)
+
+
+linear_randomized = linear_grp
+
+
+class _LinearCRS(torch.autograd.Function):
+    """Column sampling of the weight gradient: ``nopairs`` draws (with replacement) from the ``in_features`` columns;
+    only the drawn columns of the input are kept, each scaled by ``count / (nopairs / in_features)`` so that the
+    estimate is unbiased (behaviour of fewbit/functional/linear.py:28-62)."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, nopairs: int):
+        in_features = weight.shape[1]
+        draws = torch.randint(0, in_features, (nopairs, ), device=input.device)
+        counts = torch.bincount(draws, minlength=in_features)
+        scale = counts.to(input.dtype) * (in_features / nopairs)
+        flat = input.detach().reshape(-1, in_features)
+        # a dense (rows x in_features) product with a mostly-zero scale would save nothing: keep the hit columns only.
+        # nonzero() has a data-dependent size and therefore reads back from the device -- inherent to this estimator.
+        cols = torch.nonzero(counts, as_tuple=True)[0]
+        ctx.save_for_backward(flat[:, cols] * scale[cols], weight, cols)
+        ctx.has_bias = bias is not None
+        return F.linear(input, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        kept, weight, cols = ctx.saved_tensors
+        grad_input = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            grad_input = grad_output @ weight
+        flat = grad_output.reshape(-1, grad_output.shape[-1])
+        if ctx.needs_input_grad[1]:
+            grad_weight = torch.zeros_like(weight)
+            grad_weight[:, cols] = (flat.T @ kept).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = flat.sum(dim=0)
+        return grad_input, grad_weight, grad_bias, None
+
+
+def linear_crs(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], nopairs: int) -> torch.Tensor:
+    """``F.linear`` with a column-sampled weight gradient (reference: ``linear_crs``, fewbit/functional/linear.py:65)."""
+    if nopairs < 1:
+        raise ValueError('Number of sampled pairs should be strictly positive.')
+    return _LinearCRS.apply(input, weight, bias, int(nopairs))
+
+
+# ---- modules ---------------------------------------------------------------------------------------------------------
+
+class LinearCRS(torch.nn.Linear):
+    """:class:`torch.nn.Linear` whose weight gradient is estimated from ``proj_dim`` sampled input columns
+    (default ``out_features // 2``, as in fewbit/modules/linear.py:22-36; the reference's constructor forwards
+    ``proj_dim`` into the ``bias`` slot of ``nn.Linear`` and its ``extra_repr`` reads an undefined attribute --
+    both fixed here)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 proj_dim: Optional[int] = None) -> None:
+        super().__init__(in_features, out_features, bias, device, dtype)
+        self.proj_dim: int = proj_dim or max(out_features // 2, 1)
+
+    @property
+    def nopairs(self) -> int:
+        return self.proj_dim
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return linear_crs(input, self.weight, self.bias, self.proj_dim)
+
+    def extra_repr(self) -> str:
+        return f'{super().extra_repr()}, nopairs={self.nopairs}'
+
+
+class LinearGRP(torch.nn.Linear):
+    r"""Drop-in :class:`torch.nn.Linear` (:math:`y = xA^T + b`) that stores a random projection of its input along
+    the batch dimension instead of the input itself and estimates the weight gradient from it.
+
+    Parameters (after those of ``nn.Linear``; either ``proj_dim_ratio`` or ``proj_dim`` is required)
+    ----------
+    proj_dim_ratio : float, optional
+        ``proj_dim`` as a fraction of the number of input rows.
+    proj_dim : int, optional
+        Exact number of rows of the projection.
+    proj_dim_min, proj_dim_max : int, optional
+        Bounds on the number of rows.
+    matmul : {'dct', 'dft', 'gaussian', 'rademacher'}, default='gaussian'
+        Kind of random projection.
+    generator : torch.Generator, optional
+        Source of randomness; without it the host default generator seeds every call.
+
+    Examples:
+
+        >>> m = fewbit.RandomizedLinear(20, 30, proj_dim_ratio=0.5)
+        >>> m(torch.randn(128, 20)).size()
+        torch.Size([128, 30])
+    """
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 proj_dim_ratio: Optional[float] = None, proj_dim: Optional[int] = None,
+                 proj_dim_min: Optional[int] = None, proj_dim_max: Optional[int] = None, matmul: str = 'gaussian',
+                 generator: Optional[torch.Generator] = None) -> None:
+        super().__init__(in_features, out_features, bias, device, dtype)
+        self.generator = generator
+        self.matmul = matmul
+        self.proj_dim_ratio = proj_dim_ratio
+        self.proj_dim = proj_dim
+        self.proj_dim_max = proj_dim_max
+        self.proj_dim_min = proj_dim_min
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return linear_grp(input, self.weight, self.bias, self.proj_dim_ratio, self.proj_dim, self.proj_dim_max,
+                          self.proj_dim_min, self.matmul, self.generator)
+
+    def extra_repr(self) -> str:
+        return ', '.join([super().extra_repr(), f'matmul={self.matmul}', f'proj_dim={self.proj_dim}',
+                          f'proj_dim_ratio={self.proj_dim_ratio}', f'proj_dim_max={self.proj_dim_max}',
+                          f'proj_dim_min={self.proj_dim_min}'])
+
+
+RandomizedLinear = LinearGRP

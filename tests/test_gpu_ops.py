@@ -282,3 +282,36 @@ def test_stepwise_parity_and_shift_on_gpu(dt):
     assert out.data_ptr() != v.data_ptr()
     out.sum().backward()
     assert base.grad.shape == base.shape
+
+
+@pytest.mark.parametrize('matmul', ('gaussian', 'rademacher', 'dct', 'dft'))
+def test_randomized_linear_on_gpu(matmul):
+    """RandomizedLinear on the GPU in bf16: forward == nn.Linear, exact input gradient, weight-gradient estimate
+    correlated with the exact one, and only the projected rows are kept for backward (with a little activation stack
+    on top: fewbit.GELU saves 3 bits per element)."""
+    torch.manual_seed(0)
+    dtype = torch.bfloat16
+    lin = fewbit.RandomizedLinear(256, 512, proj_dim_ratio=0.25, matmul=matmul, device=DEV, dtype=dtype)
+    ref = torch.nn.Linear(256, 512, device=DEV, dtype=dtype)
+    ref.load_state_dict(lin.state_dict())
+    x = torch.randn(2048, 256, device=DEV, dtype=dtype, requires_grad=True)
+    y = lin(x)
+    assert torch.equal(y, ref(x))
+    kept = [t for t in y.grad_fn.saved_tensors if t.dim() == 2 and t.shape == (512, 256) and t.data_ptr() != lin.weight.data_ptr()]
+    assert kept, [t.shape for t in y.grad_fn.saved_tensors]
+    g = torch.randn_like(y)
+    acc = torch.zeros_like(lin.weight, dtype=torch.float32)
+    for _ in range(64):
+        lin.zero_grad()
+        x.grad = None
+        lin(x).backward(g)
+        acc += lin.weight.grad.float()
+    gi = x.grad.clone()
+    x.grad = None
+    ref(x).backward(g)
+    assert torch.equal(gi, x.grad)
+    exact = ref.weight.grad.float()
+    rel = (torch.linalg.norm(acc / 64 - exact) / torch.linalg.norm(exact)).item()
+    assert rel < 0.35, rel                                   # one draw: ~sqrt(rows/p) = 2; mean of 64: ~0.25
+    out = fewbit.GELU(bits=3)(lin(x))
+    out.sum().backward()

@@ -1,0 +1,116 @@
+"""Randomized linear layers, DCT and variance utilities -- the reference's own checks restated
+(fewbit/modules/linear_test.py, fewbit/fft_test.py): forward equals nn.Linear, the input and bias gradients are exact,
+the weight gradient is an unbiased estimate (mean over repeats within 10 % of the exact one)."""
+import itertools
+
+import numpy as np
+import pytest
+import scipy.fft
+import torch
+
+import fewbit
+from fewbit.fft import dct, idct
+from fewbit.functional import catch_gradients, GradientStorage, linear_crs, linear_grp, linear_randomized
+from fewbit.modules.linear import LinearCRS, LinearGRP, RandomizedLinear
+
+
+def reference_linear(module):
+    clone = torch.nn.Linear(module.in_features, module.out_features, module.bias is not None)
+    clone.load_state_dict({k: v.clone() for k, v in module.state_dict().items()})
+    return clone
+
+
+def mean_grads(module, xs, repeat):
+    acc_w = torch.zeros_like(module.weight)
+    acc_b = torch.zeros_like(module.bias) if module.bias is not None else None
+    for _ in range(repeat):
+        module.zero_grad()
+        xs.grad = None
+        ys = module(xs)
+        ys.backward(torch.ones_like(ys))
+        acc_w += module.weight.grad
+        if acc_b is not None:
+            acc_b += module.bias.grad
+    return xs.grad, acc_w / repeat, None if acc_b is None else acc_b / repeat
+
+
+@pytest.mark.parametrize('ctor', (LinearCRS, LinearGRP))
+@pytest.mark.parametrize('bias', (False, True))
+def test_forward_equals_linear(ctor, bias):
+    torch.manual_seed(42)
+    module = ctor(8, 4, bias, proj_dim=64)
+    xs = torch.randn(128, 8)
+    with torch.no_grad():
+        rel = torch.linalg.norm(module(xs) - reference_linear(module)(xs)) / torch.linalg.norm(module(xs))
+    assert rel.item() <= 1e-6
+
+
+@pytest.mark.parametrize('ctor,kwargs', [(LinearCRS, {}), (LinearGRP, {}), (LinearGRP, {'matmul': 'rademacher'}),
+                                         (LinearGRP, {'matmul': 'dct'}), (LinearGRP, {'matmul': 'dft'})])
+@pytest.mark.parametrize('bias', (False, True))
+def test_backward_is_unbiased(ctor, kwargs, bias):
+    torch.manual_seed(42)
+    module = ctor(in_features=64, out_features=32, bias=bias, proj_dim=32, **kwargs)
+    exact = reference_linear(module)
+    xs = torch.randn(128, 64, requires_grad=True)
+    gi, gw, gb = mean_grads(module, xs, 1500)
+    ri, rw, rb = mean_grads(exact, xs, 1)
+    assert (torch.linalg.norm(gi - ri) / torch.linalg.norm(ri)).item() <= 1e-6
+    assert (torch.linalg.norm(gw - rw) / torch.linalg.norm(rw)).item() <= 1e-1
+    if bias:
+        assert (torch.linalg.norm(gb - rb) / torch.linalg.norm(rb)).item() <= 1e-6
+
+
+def test_saved_tensor_is_the_projection_and_generator_replays():
+    torch.manual_seed(0)
+    gen = torch.Generator().manual_seed(7)
+    m = RandomizedLinear(16, 8, proj_dim_ratio=0.25, generator=gen)
+    assert RandomizedLinear is LinearGRP and linear_randomized is linear_grp
+    x = torch.randn(4, 10, 16, requires_grad=True)            # 40 rows -> 10 projected rows
+    y = m(x)
+    saved = [t for t in y.grad_fn.saved_tensors if t.shape[-1] == 16 and t.shape[0] != 8]
+    assert saved and saved[0].shape == (10, 16)
+    y.sum().backward()
+    g1 = m.weight.grad.clone()
+    # same generator state -> same sketch -> same estimate
+    m.zero_grad()
+    gen.manual_seed(7)
+    m(x).sum().backward()
+    assert torch.equal(g1, m.weight.grad)
+    assert 'matmul=gaussian' in repr(m) and 'nopairs=' in repr(LinearCRS(4, 4))
+    with pytest.raises(ValueError):
+        linear_grp(x, m.weight, m.bias)                                   # neither proj_dim nor ratio
+    with pytest.raises(ValueError):
+        linear_grp(x, m.weight, m.bias, 0.5, None, None, None, 'haar')    # unknown projection
+    with pytest.raises(ValueError):
+        linear_grp(x, m.weight, m.bias, 0.5, None, 2, 4)                  # max < min
+    assert linear_crs(x, m.weight, m.bias, 5).shape == (4, 10, 8)
+
+
+def test_dct_matches_scipy():
+    x = np.random.default_rng(0).standard_normal((3, 37, 4))
+    for kind, norm, dim, n in itertools.product((2, 3), ('backward', 'forward', 'ortho'), (0, 1, -1), (None, 20, 50)):
+        assert np.abs(dct(torch.tensor(x), kind, n, dim, norm).numpy() - scipy.fft.dct(x, kind, n, dim, norm)).max() < 1e-10
+        assert np.abs(idct(torch.tensor(x), kind, n, dim, norm).numpy() - scipy.fft.idct(x, kind, n, dim, norm)).max() < 1e-10
+    x32 = torch.tensor(x, dtype=torch.float32)
+    assert torch.allclose(idct(dct(x32, norm='ortho', dim=1), norm='ortho', dim=1), x32, atol=1e-5)
+    with pytest.raises(ValueError):
+        dct(x32, norm='unitary')
+
+
+def test_gradient_catcher_and_variance_estimator():
+    torch.manual_seed(1)
+    store = GradientStorage()
+    x = torch.randn(6, 3, requires_grad=True)
+    store.forward(x)
+    (catch_gradients(x * 2.0, store) * torch.arange(3.0)).sum().backward()
+    assert torch.equal(store.input, x.detach()) and torch.equal(store.grad_output, torch.arange(3.0).expand(6, 3))
+    seen = []
+    est = fewbit.variance.VarianceEstimator(LinearGRP(8, 4, proj_dim=5), lambda *a: seen.append(a))
+    inp = torch.randn(20, 8)
+    est(inp).square().sum().backward()
+    corr, var_sgd, var_rmm = est.variance
+    assert len(seen) == 1 and seen[0][3] == 0 and 0.0 <= corr.item() <= 1.0 and var_rmm.item() >= 0.0
+    g = est.state.grad_output
+    want = (torch.linalg.norm(inp)**2 * torch.linalg.norm(g)**2 - torch.linalg.norm(inp.T @ g)**2) / 5
+    assert torch.allclose(var_rmm, want, rtol=1e-5)
