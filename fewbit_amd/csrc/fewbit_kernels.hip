@@ -221,6 +221,9 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
 // instructions -- independent of K -- and runs on the otherwise idle LDS unit, which takes the forward from
 // VALU-bound back to memory-bound.  Blocks are 1024 threads (16 waves) so that two of them (2 x 64 KiB of LDS) fill
 // a CU with 32 waves.
+#ifndef FEWBIT_LUT_WPS
+#define FEWBIT_LUT_WPS 8      // waves per SIMD the table kernel is compiled for (two 16-wave blocks per CU)
+#endif
 constexpr int kLutBlock = 1024;
 constexpr int kLutWaves = kLutBlock / kWave;
 
@@ -230,7 +233,7 @@ template <int DT> __device__ __forceinline__ float value_of_pattern(uint32_t r) 
 }
 
 template <int FN, int DT, int K, int U>
-__global__ __launch_bounds__(kLutBlock, 8) void quantize_forward_lut_kernel(const void *x, void *y, uint8_t *state,
+__global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lut_kernel(const void *x, void *y, uint8_t *state,
                                                                             size_t n, const void *borders,
                                                                             int nborders, float p0, float p1) {
     static_assert(DT != FEWBIT_F32, "the pattern table exists for 16-bit dtypes only");
@@ -670,6 +673,10 @@ template <auto Kern> unsigned lut_grid(size_t n, int U) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kern, kLutBlock, 0) != hipSuccess || nb < 1) nb = 1;
         per_cu = nb > 2 ? 2 : nb;
+        if (const char *e = getenv("FEWBIT_HIP_LUT_BLOCKS_PER_CU")) {   // tuning hook
+            const int v = atoi(e);
+            if (v >= 1 && v < per_cu) per_cu = v;
+        }
     }
     const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
     size_t blocks = (ntiles + kLutWaves - 1) / kLutWaves;

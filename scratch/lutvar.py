@@ -1,0 +1,25 @@
+"""forward (pattern-table kernel) time at the headline config for the build selected by FEWBIT_HIP_LIB"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); os.chdir(ROOT)
+import torch
+from fewbit_amd import cabi
+from fewbit_amd.store import store
+dev='cuda'
+def timeit(f, iters=2000):
+    for _ in range(50): f()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)*1000/iters
+tag = os.path.basename(os.environ.get('FEWBIT_HIP_LIB', 'default')) + ' bpc=' + os.environ.get('FEWBIT_HIP_LUT_BLOCKS_PER_CU', '-')
+out = []
+for name, k, dtype, n in (('gelu', 3, torch.bfloat16, 4096*4096), ('silu', 4, torch.float16, 8192*8192)):
+    b, l = store.get(name, k, dev, dtype); b = b[1:-1].contiguous()
+    x = torch.randn(n, device=dev).to(dtype); y = torch.empty_like(x); st = torch.empty(cabi.state_nbytes(n, k), dtype=torch.uint8, device=dev)
+    gy = torch.randn(n, device=dev).to(dtype); gx = torch.empty_like(x)
+    f = cabi.bind_forward(name, x, b, out=y, state=st); bw = cabi.bind_backward(gy, st, l, out=gx)
+    def step(): f(); bw()
+    out.append(f'{name}{k} fwd {timeit(f):.2f} step {timeit(step):.2f}')
+print(tag, ' | '.join(out), flush=True)
