@@ -337,32 +337,53 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
 }
 
 // Generic forward: any table size up to 255 borders (K up to 8), any pointer alignment.
-// One thread per group, borders staged in LDS, lower_bound per element.
+// One thread per group; the borders sit in LDS padded with +inf to a full tree of 2^nbits - 1 nodes, so the search
+// is a fixed nbits-step branch-free descent (NaN runs off the padded end and is clamped to nborders, the
+// torch.searchsorted rule).  `vec`: x and y are 16-byte aligned -> whole groups move as lane-contiguous 16 B pieces.
 template <int FN, int DT>
-__global__ __launch_bounds__(kBlock) void quantize_forward_generic_kernel(const void *__restrict__ x, void *y,
+__global__ __launch_bounds__(kBlock) void quantize_forward_generic_kernel(const void *x, void *y,
                                                                           uint8_t *__restrict__ state, size_t n,
                                                                           const void *__restrict__ borders,
-                                                                          int nborders, int nbits, float p0, float p1) {
+                                                                          int nborders, int nbits, float p0, float p1,
+                                                                          bool vec) {
+    constexpr bool kFast = (DT != FEWBIT_F32);
     __shared__ float sb[256];
-    for (int j = threadIdx.x; j < nborders; j += kBlock) sb[j] = Elem<DT>::load(borders, j);
+    for (int j = threadIdx.x; j < 256; j += kBlock) sb[j] = j < nborders ? Elem<DT>::load(borders, j) : __builtin_inff();
     __syncthreads();
     const size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     const size_t e0 = g << 3;
     if (e0 >= n) return;
-    uint64_t w = 0;
-    for (int i = 0; i < 8; ++i) {
-        if (e0 + i < n) {
-            float xv = Elem<DT>::load(x, e0 + i);
-            const float key = Act<FN, false>::key(xv, p0);
-            int lo = 0, hi = nborders;
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (!(sb[mid] >= key)) lo = mid + 1;
-                else hi = mid;
-            }
-            w |= static_cast<uint64_t>(lo) << (nbits * i);
-            Elem<DT>::store(y, e0 + i, Act<FN, (DT != FEWBIT_F32)>::eval(xv, p0, p1));
+    const bool full = vec && e0 + 8 <= n;
+    float v[8];
+    if (full) {
+        GroupIO<DT>::unpack(GroupIO<DT>::load_raw(x, g), v);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = e0 + i < n ? Elem<DT>::load(x, e0 + i) : 0.0f;
+    }
+    uint32_t pos[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pos[i] = 0;
+    for (uint32_t step = 1u << (nbits - 1); step != 0; step >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float key = Act<FN, kFast>::key(v[i], p0);
+            pos[i] += !(sb[pos[i] + step - 1] >= key) ? step : 0u;
         }
+    }
+    uint64_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t code = e0 + i < n ? min(pos[i], static_cast<uint32_t>(nborders)) : 0u;   // padding codes are 0
+        w |= static_cast<uint64_t>(code) << (nbits * i);
+        v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
+    }
+    if (full) {
+        GroupIO<DT>::store(y, g, v);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (e0 + i < n) Elem<DT>::store(y, e0 + i, v[i]);
     }
     uint8_t *p = state + static_cast<size_t>(nbits) * g;
     for (int j = 0; j < nbits; ++j) p[j] = static_cast<uint8_t>(w >> (8 * j));
@@ -422,11 +443,11 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kerne
 }
 
 template <int DT>
-__global__ __launch_bounds__(kBlock) void quantize_backward_generic_kernel(const void *__restrict__ gy,
+__global__ __launch_bounds__(kBlock) void quantize_backward_generic_kernel(const void *gy,
                                                                            const uint8_t *__restrict__ state,
                                                                            void *gx, size_t n,
                                                                            const void *__restrict__ levels,
-                                                                           int nlevels, int nbits) {
+                                                                           int nlevels, int nbits, bool vec) {
     __shared__ float lut[256];
     for (int j = threadIdx.x; j < 256; j += kBlock) lut[j] = j < nlevels ? Elem<DT>::load(levels, j) : 0.0f;
     __syncthreads();
@@ -437,6 +458,14 @@ __global__ __launch_bounds__(kBlock) void quantize_backward_generic_kernel(const
     uint64_t w = 0;
     for (int j = 0; j < nbits; ++j) w |= static_cast<uint64_t>(p[j]) << (8 * j);
     const uint32_t mask = (1u << nbits) - 1u;
+    if (vec && e0 + 8 <= n) {
+        float v[8];
+        GroupIO<DT>::unpack(GroupIO<DT>::load_raw(gy, g), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = mul_f32(lut[static_cast<uint32_t>(w >> (nbits * i)) & mask], v[i]);
+        GroupIO<DT>::store(gx, g, v);
+        return;
+    }
     for (int i = 0; i < 8; ++i)
         if (e0 + i < n)
             Elem<DT>::store(gx, e0 + i, mul_f32(lut[static_cast<uint32_t>(w >> (nbits * i)) & mask], Elem<DT>::load(gy, e0 + i)));
@@ -720,7 +749,7 @@ int launch_forward(const void *x, void *y, uint8_t *state, size_t n, const void 
         }
     } else {
         hipLaunchKernelGGL((quantize_forward_generic_kernel<FN, DT>), dim3(group_grid(n)), dim3(kBlock), 0, s, x, y,
-                           state, n, borders, nborders, k, p0, p1);
+                           state, n, borders, nborders, k, p0, p1, aligned16(x) && aligned16(y));
     }
     return check_launch("quantize_forward");
 }
@@ -750,7 +779,7 @@ int launch_backward(const void *gy, const uint8_t *state, void *gx, size_t n, co
         }
     } else {
         hipLaunchKernelGGL((quantize_backward_generic_kernel<DT>), dim3(group_grid(n)), dim3(kBlock), 0, s, gy, state,
-                           gx, n, levels, nlevels, k);
+                           gx, n, levels, nlevels, k, aligned16(gy) && aligned16(gx));
     }
     return check_launch("quantize_backward");
 }
