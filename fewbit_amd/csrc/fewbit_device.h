@@ -78,10 +78,13 @@ template <> struct Elem<FEWBIT_BF16> {
 // form and only unpacks to 8 floats when the tile is computed.
 template <int DT> struct GroupIO;
 
-// Stores take an NT flag: the forward kernel writes y and the state with nontemporal stores (they are
-// not read again by this kernel and, written normally, push the still-to-be-read input out of L2 /
-// Infinity Cache: measured -1.2 us on the 4096x4096 bf16 forward); loads are always plain
-// (nontemporal loads measured +2 us).
+// Stores take an NT flag.  What the kernels use (all measured on MI355X, 4096x4096):
+//   y of a 16-bit forward : nontemporal -- not read again by this path; written normally it pushes the
+//                           still-to-be-read input out of L2 / Infinity Cache (-1.2 us)
+//   fp32 y, gx            : plain -- fp32 groups are two 16 B pieces at a 32 B lane stride, holes that only L2
+//                           write-combining fills (nontemporal: +4 us)
+//   packed state          : plain -- it is what backward reads next (-0.9 us per step)
+// Loads are always plain (nontemporal loads measured +2 us).
 #define FEWBIT_LD(p) (*(p))
 template <bool NT, typename T> __device__ __forceinline__ void store_as(T *p, T v) {
     if constexpr (NT) __builtin_nontemporal_store(v, p);

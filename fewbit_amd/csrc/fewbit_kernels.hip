@@ -2,15 +2,23 @@
 // quantized-activation path.  From-scratch CDNA4 design; what each kernel replaces in the reference
 // (skolai/fewbit) is cited at its definition.
 //
-// Work decomposition (see DESIGN.md "kernels"):
+// Work decomposition:
 //   group      = 8 consecutive elements  <-> exactly K bytes of packed state
 //   wave tile  = 64 lanes x U groups; load u of a wave covers 64 lane-contiguous groups, so every
 //                wave-level memory instruction on x / y / gy / gx touches one contiguous span
 //                (1 KiB for 16-bit dtypes)
-//   block      = 4 waves = 4 consecutive wave tiles; grid = ceil(#tiles / 4): one tile per wave,
-//                no loop, all loads of a tile issued before the first use
-// Tables: the 2^K-1 borders live in SGPRs (one v_readlane each, loaded by lanes 0..2^K-2);
-// the 2^K levels are staged in LDS and gathered per element in backward.
+//   grid       = ONE resident generation of waves (occupancy API x #CUs); wave w loops over tiles
+//                w, w + W, w + 2W, ... with a two-buffer software pipeline (pipeline2): the loads of
+//                the next tile are in flight while the current one is processed
+// Kernels:
+//   quantize_forward_lut_kernel   fp16/bf16, K <= 4, large tensors: code = byte table in LDS indexed by
+//                                 the raw 16-bit pattern (built per 1024-thread block)
+//   quantize_forward_kernel       fp32, and 16-bit below the table threshold: borders in wave-uniform
+//                                 VGPRs (v_readlane), MSB-first search in hand-scheduled asm
+//   quantize_backward_kernel      levels staged in LDS, one gather + one multiply per element
+//   stepwise1_*_kernel            the exact 1-bit family
+//   *_generic_kernel              tables wider than 4 bits, misaligned pointers
+//   pack/unpack_codes_kernel      codec seam used by the tests
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
