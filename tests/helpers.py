@@ -81,3 +81,12 @@ def forward_value_ok(x: torch.Tensor, y: torch.Tensor, y_ref: torch.Tensor, tigh
     nan_ok = torch.isnan(xf) & torch.isnan(yf)
     skip = torch.isinf(xf)
     return step_ok | abs_ok | nan_ok | skip
+
+
+# Input data of the reference's CUDA smoke test (fewbit/cuda/codec_test.cu: TestCodecBlock :62-64, TestGelu :93-98).
+# The reference only prints the results; the two vectors pin each other: with the built-in 3-bit GELU table the 16
+# inputs fall into exactly the 16 codes of the codec smoke test.
+REF_SMOKE_CODES = (6, 5, 6, 1, 7, 0, 4, 2, 2, 3, 0, 4, 5, 5, 6, 7)
+REF_SMOKE_GELU_INPUTS = (2.29811567e+00, 6.10855860e-01, 2.29811567e+00, -8.11248159e-01, 9.99900000e+02, -2.49798704e+00,
+                         2.26182064e-01, -4.26290283e-01, -4.26290283e-01, -1.00155338e-01, -2.49798704e+00, 2.26182064e-01,
+                         6.10855860e-01, 6.10855860e-01, 2.29811567e+00, 9.99900000e+02)

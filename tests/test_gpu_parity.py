@@ -437,3 +437,25 @@ def test_folded_full_size_properties():
     w = slice(8 * 70_001, 8 * 70_001 + 80_000)
     _, s_o, _ = oracle.quantize('identity_fold', x[w], half, sx)
     assert torch.equal(state[3 * 70_001:3 * 70_001 + 30_000].cpu(), s_o)
+
+
+@pytest.mark.parametrize('dt', list(DTYPES))
+def test_reference_smoke_vectors(dt):
+    """Inputs of the reference's CUDA smoke test (fewbit/cuda/codec_test.cu:62-64, :93-98) through the kernels: the GELU
+    inputs give the codec test's 16 codes, DeflateBlock/InflateBlock round-trip them, unit gradients return the levels."""
+    from helpers import REF_SMOKE_CODES, REF_SMOKE_GELU_INPUTS
+    dtype = DTYPES[dt]
+    x = torch.tensor(REF_SMOKE_GELU_INPUTS).to(dtype)
+    borders, levels = store.get('gelu', 3, 'cpu', dtype)
+    want = oracle.searchsorted(x, borders[1:-1]).tolist()
+    if dt == 'f32':
+        assert want == list(REF_SMOKE_CODES)
+    y, state = cabi.quantize_forward('gelu', x.to(DEV), borders[1:-1].contiguous().to(DEV))
+    assert cabi.unpack_codes(state, 16, 3).tolist() == want
+    codes = torch.tensor(REF_SMOKE_CODES, dtype=torch.int32, device=DEV)
+    packed = cabi.pack_codes(codes, 3)
+    assert packed.cpu().numpy().tobytes() == oracle.deflate(np.array(REF_SMOKE_CODES, dtype=np.int32), 3).tobytes()
+    assert cabi.unpack_codes(packed, 16, 3).tolist() == list(REF_SMOKE_CODES)
+    gx = cabi.quantize_backward(torch.ones(16, dtype=dtype, device=DEV), state, levels.to(DEV))
+    assert_bit_equal(gx.cpu(), levels[torch.tensor(want)], 'smoke gx')
+    assert y[4].item() == pytest.approx(999.9, rel=1e-2)

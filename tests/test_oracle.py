@@ -214,3 +214,18 @@ def test_folded_key_is_the_fp32_distance_from_the_shift(dtype):
         assert k == 3 and np.array_equal(codes, want)
         iv = torch.int32 if dtype == torch.float32 else torch.int16
         assert torch.equal(y[1:].view(iv), x[1:].view(iv)) and torch.isnan(y[0])          # identity forward
+
+
+def test_reference_smoke_vectors_pin_each_other():
+    """fewbit/cuda/codec_test.cu: the 16 GELU inputs of TestGelu land, with the built-in 3-bit table, on the 16 codes of
+    TestCodecBlock; their packed form round-trips and the backward with unit gradients returns the table levels."""
+    from helpers import REF_SMOKE_CODES, REF_SMOKE_GELU_INPUTS
+    from fewbit_amd.store import store
+    x = torch.tensor(REF_SMOKE_GELU_INPUTS, dtype=torch.float32)
+    borders, levels = store.get('gelu', 3, 'cpu', torch.float32)
+    y, state, k = oracle.quantize('gelu', x, borders[1:-1])
+    assert k == 3 and state.numel() == 6
+    assert oracle.inflate(state.numpy(), 16, 3).tolist() == list(REF_SMOKE_CODES)
+    assert np.array_equal(oracle.deflate(np.array(REF_SMOKE_CODES, dtype=np.int32), 3), state.numpy())
+    assert torch.equal(oracle.quantize_backward(torch.ones(16), state, levels), levels[torch.tensor(REF_SMOKE_CODES)])
+    assert y[4].item() == pytest.approx(999.9) and y[15].item() == pytest.approx(999.9)
