@@ -239,3 +239,29 @@ def test_host_stepwise_parity_and_shift():
         want_odd = torch.where(right, want, 1.0 - left)
         want_odd[torch.isnan(x)] = 0.1
         assert torch.equal(xr.grad, want_odd)
+
+
+def test_graph_accounting_like_reference_util_test():
+    """fewbit/util_test.py restated: traverse/teniter/estimate_memory_usage/memory_usage_hooks on two tiny MLPs."""
+    from fewbit.util import convert_linear, estimate_memory_usage, memory_usage_hooks, teniter, traverse
+    torch.manual_seed(0)
+    m1 = torch.nn.Sequential(torch.nn.Linear(8, 4), torch.nn.Linear(4, 1))
+    m2 = torch.nn.Sequential(torch.nn.Linear(8, 4), torch.nn.ReLU(), torch.nn.Linear(4, 1))
+    xs = torch.randn(3, 8)
+    traverse(m1(xs.requires_grad_()), lambda node, ten, saved: None)
+    n1 = len(list(teniter(m1(xs.requires_grad_()), False, True)))
+    n2 = len(list(teniter(m2(xs.requires_grad_()), False, True)))
+    assert n1 + 1 == n2
+    assert estimate_memory_usage(m1(xs.requires_grad_())) == 4 * (3 * 8 + 4 * 8 + 4 + 1 * 4 + 1)
+    size = 3 * 4 * 4                                              # the ReLU output, saved for its backward
+    assert estimate_memory_usage(m2(xs.requires_grad_()), True) - estimate_memory_usage(m1(xs.requires_grad_()), True) == size
+    with memory_usage_hooks() as lhs:
+        m1(torch.randn(3, 8).requires_grad_())
+    with memory_usage_hooks() as rhs:
+        x2 = torch.randn(3, 8)
+        m2(x2.requires_grad_()).backward(torch.ones(3, 1))
+    assert rhs.value - lhs.value == size
+    # Linear -> RandomizedLinear through map_module + convert_linear, parameters shared
+    net = fewbit.map_module(m2, lambda m, p: convert_linear(m, fewbit.RandomizedLinear, proj_dim_ratio=0.5))
+    assert isinstance(net[0], fewbit.RandomizedLinear) and isinstance(net[1], torch.nn.ReLU)
+    assert net(torch.randn(6, 8)).shape == (6, 1)
