@@ -254,6 +254,28 @@ template <int K> __device__ __forceinline__ uint32_t load_state_quad_fix(uint32_
     } else return raw;
 }
 
+// ------------------------------------------------------------------ packed state access, wide codes
+// Tables of 5..8 bits: a group's word is 8K <= 64 bits at byte offset K*g, which is not dword aligned in general.
+// gfx950 global accesses need no alignment (hipcc emits single dword / dwordx2 instructions for these), so a lane
+// reads its word with ONE 8-byte load -- which also fetches up to 3 bytes of the next group: callers keep one group
+// of slack before the end of the buffer -- and writes it as a dword plus K-4 single bytes.
+__device__ __forceinline__ uint64_t load_state_wide(const uint8_t *state, size_t g, int nbits) {
+    uint64_t w;
+    __builtin_memcpy(&w, state + static_cast<size_t>(nbits) * g, 8);
+    return w;
+}
+
+__device__ __forceinline__ void store_state_wide(uint8_t *state, size_t g, int nbits, uint64_t w) {
+    uint8_t *p = state + static_cast<size_t>(nbits) * g;
+    const uint32_t lo = static_cast<uint32_t>(w);
+    __builtin_memcpy(p, &lo, 4);
+    uint32_t hi = static_cast<uint32_t>(w >> 32);
+    for (int j = 4; j < nbits; ++j) {
+        p[j] = static_cast<uint8_t>(hi);
+        hi >>= 8;
+    }
+}
+
 // ------------------------------------------------------------------ activation math (fp32)
 // Two accuracy classes, chosen by the I/O dtype (see DESIGN.md "forward values"):
 //   precise : fp32 I/O.  GELU as ATen's x*0.5*(1+erf(x*sqrt(1/2))) with erf_precise (~1 ulp); ocml for the rest.

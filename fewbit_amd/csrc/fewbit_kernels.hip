@@ -62,13 +62,15 @@ struct Span {
     int lane;
 };
 
-template <int U, int WPB = kWavesPerBlock> __device__ __forceinline__ Span make_span(size_t n) {
+// `slack`: full groups that must remain after the last tile (the wide-code backward over-reads a few bytes)
+template <int U, int WPB = kWavesPerBlock> __device__ __forceinline__ Span make_span(size_t n, size_t slack = 0) {
     Span s;
     s.lane = threadIdx.x & (kWave - 1);
     s.nwaves = static_cast<size_t>(gridDim.x) * WPB;
     s.wave = static_cast<size_t>(blockIdx.x) * WPB +
              static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
-    s.ntiles = (n >> 3) / (static_cast<size_t>(U) * kWave);
+    const size_t full = n >> 3;
+    s.ntiles = (full > slack ? full - slack : 0) / (static_cast<size_t>(U) * kWave);
     s.tail_g0 = s.ntiles * (static_cast<size_t>(U) * kWave);
     s.ngroups = (n + 7) >> 3;
     return s;
@@ -341,6 +343,199 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
             }
         }
         store_state<K>(state, g, w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide tables (17..256 levels, 5..8 bits per code), 16-byte aligned data: the same streaming structure with the
+// bit width as a run-time (wave-uniform) value, so that one instantiation per functor/dtype serves all four widths.
+
+// code of `key` against the padded border tree in LDS: fixed nbits-step descent, NaN -> nborders
+__device__ __forceinline__ uint32_t tree_code(const float *sb, float key, int nbits, uint32_t nborders) {
+    uint32_t pos = 0;
+    for (uint32_t step = 1u << (nbits - 1); step != 0; step >>= 1) pos += !(sb[pos + step - 1] >= key) ? step : 0u;
+    return min(pos, nborders);
+}
+
+// element-wise tail shared by the wide forward kernels (last wave only)
+template <int FN, int DT, typename Code>
+__device__ __forceinline__ void wide_forward_tail(const Span &s, const void *x, void *y, uint8_t *state, size_t n, int nbits,
+                                                  float p0, float p1, Code &&code_of) {
+    constexpr bool kFast = (DT != FEWBIT_F32);
+    for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
+        const size_t e0 = g << 3;
+        uint64_t w = 0;
+        for (int i = 0; i < 8; ++i) {
+            if (e0 + i < n) {
+                w |= static_cast<uint64_t>(code_of(e0 + i)) << (nbits * i);
+                Elem<DT>::store(y, e0 + i, Act<FN, kFast>::eval(Elem<DT>::load(x, e0 + i), p0, p1));
+            }
+        }
+        uint8_t *p = state + static_cast<size_t>(nbits) * g;
+        for (int j = 0; j < nbits; ++j) p[j] = static_cast<uint8_t>(w >> (8 * j));
+    }
+}
+
+// forward, borders searched in LDS (fp32 tensors; 16-bit tensors below the pattern-table threshold)
+template <int FN, int DT>
+__global__ __launch_bounds__(kBlock, 6) void quantize_forward_wide_kernel(const void *x, void *y, uint8_t *state, size_t n,
+                                                                          const void *borders, int nborders, int nbits,
+                                                                          float p0, float p1) {
+    constexpr bool kFast = (DT != FEWBIT_F32);
+    typedef typename GroupIO<DT>::Raw Raw;
+    __shared__ float sb[256];
+    const Span s = make_span<1>(n);
+    struct Buf { Raw r; };
+    pipeline2<Buf>(
+        s,
+        [&]() {
+            sb[threadIdx.x] = static_cast<int>(threadIdx.x) < nborders ? Elem<DT>::load(borders, threadIdx.x) : __builtin_inff();
+            __syncthreads();
+        },
+        [&](size_t t, Buf &buf) { buf.r = GroupIO<DT>::load_raw(x, t * kWave + s.lane); },
+        [&](size_t t, const Buf &buf) {
+            float v[8];
+            GroupIO<DT>::unpack(buf.r, v);
+            uint32_t pos[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pos[i] = 0;
+            for (uint32_t step = 1u << (nbits - 1); step != 0; step >>= 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pos[i] += !(sb[pos[i] + step - 1] >= Act<FN, kFast>::key(v[i], p0)) ? step : 0u;
+            }
+            uint64_t w = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                w |= static_cast<uint64_t>(min(pos[i], static_cast<uint32_t>(nborders))) << (nbits * i);
+                v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
+            }
+            const size_t g = t * kWave + s.lane;
+            GroupIO<DT>::template store<kFast>(y, g, v);
+            store_state_wide(state, g, nbits, w);
+        });
+    if (s.wave != s.nwaves - 1) return;
+    wide_forward_tail<FN, DT>(s, x, y, state, n, nbits, p0, p1, [&](size_t e) {
+        return tree_code(sb, Act<FN, kFast>::key(Elem<DT>::load(x, e), p0), nbits, static_cast<uint32_t>(nborders));
+    });
+}
+
+// forward for 16-bit tensors through the 64 KiB pattern table, any number of borders up to 255: the borders are
+// staged in LDS (float for the tree descent of pass 1, raw pattern for the fix-up of pass 2, which loops over them
+// 16 waves at a time); everything else as in quantize_forward_lut_kernel.
+template <int FN, int DT>
+__global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lut_wide_kernel(const void *x, void *y,
+                                                                                 uint8_t *state, size_t n,
+                                                                                 const void *borders, int nborders,
+                                                                                 int nbits, float p0, float p1) {
+    static_assert(DT != FEWBIT_F32, "the pattern table exists for 16-bit dtypes only");
+    constexpr uint32_t kInf = (DT == FEWBIT_BF16) ? 0x7f80u : 0x7c00u;
+    typedef typename GroupIO<DT>::Raw Raw;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[65536];
+    __shared__ float sb[256];
+    __shared__ uint16_t sr[256];
+    const Span s = make_span<1, kLutWaves>(n);
+    float mine = __builtin_inff();
+    uint32_t mine_raw = 0;
+    if (static_cast<int>(threadIdx.x) < nborders) {
+        mine = Elem<DT>::load(borders, threadIdx.x);
+        mine_raw = static_cast<const uint16_t *>(borders)[threadIdx.x];
+    }
+    struct Buf { Raw r; };
+    auto build = [&]() {
+        if (threadIdx.x < 256) {
+            sb[threadIdx.x] = mine;
+            sr[threadIdx.x] = static_cast<uint16_t>(mine_raw);
+        }
+        __syncthreads();
+        const uint32_t r0 = threadIdx.x * 64u;
+        const uint32_t c_first = ((r0 & 0x7fffu) > kInf) ? static_cast<uint32_t>(nborders)
+                                                        : tree_code(sb, value_of_pattern<DT>(r0), nbits, static_cast<uint32_t>(nborders));
+        const uint32_t c0 = c_first * 0x01010101u;
+        u32x4 fill = {c0, c0, c0, c0};
+        u32x4 *dst = reinterpret_cast<u32x4 *>(lut + r0);
+        dst[0] = fill; dst[1] = fill; dst[2] = fill; dst[3] = fill;
+        __syncthreads();
+        uint32_t *lut32 = reinterpret_cast<uint32_t *>(lut);
+        for (int j = threadIdx.x >> 6; j < nborders; j += kLutWaves) {     // wave-uniform loop
+            const uint32_t bits = sr[j];
+            const uint32_t mag = bits & 0x7fffu;
+            const bool neg = (bits >> 15) != 0 && mag != 0;
+            if (mag <= kInf) {
+                const uint32_t first = neg ? 0x8000u + mag : mag + 1u;
+                const uint32_t r = first + s.lane;
+                if ((first & 63u) != 0 && r < ((first | 63u) + 1u) && (r & 0x7fffu) <= kInf) {
+                    const uint32_t one = 1u << (8u * (r & 3u));
+                    if (neg) __hip_atomic_fetch_sub(&lut32[r >> 2], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_fetch_add(&lut32[r >> 2], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        __syncthreads();      // (the NaN rewrite below must follow every fix-up of the +-inf chunks)
+        if ((threadIdx.x >> 6) == kLutWaves - 1 && s.lane > 0) {
+            lut[kInf + s.lane] = static_cast<uint8_t>(nborders);
+            lut[0x8000u + kInf + s.lane] = static_cast<uint8_t>(nborders);
+        }
+        __syncthreads();
+    };
+    pipeline2<Buf>(
+        s, build, [&](size_t t, Buf &buf) { buf.r = GroupIO<DT>::load_raw(x, t * kWave + s.lane); },
+        [&](size_t t, const Buf &buf) {
+            uint64_t w = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t d = buf.r.q[i];
+                w |= static_cast<uint64_t>(lut[d & 0xffffu]) << (nbits * (2 * i));
+                w |= static_cast<uint64_t>(lut[d >> 16]) << (nbits * (2 * i + 1));
+            }
+            float v[8];
+            GroupIO<DT>::unpack(buf.r, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
+            const size_t g = t * kWave + s.lane;
+            GroupIO<DT>::template store<true>(y, g, v);
+            store_state_wide(state, g, nbits, w);
+        });
+    if (s.wave != s.nwaves - 1) return;
+    wide_forward_tail<FN, DT>(s, x, y, state, n, nbits, p0, p1,
+                              [&](size_t e) { return static_cast<uint32_t>(lut[static_cast<const uint16_t *>(x)[e]]); });
+}
+
+// backward for wide tables: one unaligned 8-byte state load per group (one group of slack kept before the end)
+template <int DT>
+__global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_kernel(const void *gy, const uint8_t *state,
+                                                                                  void *gx, size_t n, const void *levels,
+                                                                                  int nlevels, int nbits) {
+    typedef typename GroupIO<DT>::Raw Raw;
+    __shared__ float lut[256];
+    const Span s = make_span<1>(n, 1);
+    const uint32_t mask = (1u << nbits) - 1u;
+    struct Buf { Raw r; uint64_t w; };
+    pipeline2<Buf>(
+        s,
+        [&]() {
+            lut[threadIdx.x] = static_cast<int>(threadIdx.x) < nlevels ? Elem<DT>::load(levels, threadIdx.x) : 0.0f;
+            __syncthreads();
+        },
+        [&](size_t t, Buf &buf) {
+            buf.r = GroupIO<DT>::load_raw(gy, t * kWave + s.lane);
+            buf.w = load_state_wide(state, t * kWave + s.lane, nbits);
+        },
+        [&](size_t t, const Buf &buf) {
+            float v[8];
+            GroupIO<DT>::unpack(buf.r, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = lut[static_cast<uint32_t>(buf.w >> (nbits * i)) & mask] * v[i];
+            GroupIO<DT>::store(gx, t * kWave + s.lane, v);
+        });
+    if (s.wave != s.nwaves - 1) return;
+    for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
+        const size_t e0 = g << 3;
+        const uint8_t *p = state + static_cast<size_t>(nbits) * g;
+        uint64_t w = 0;
+        for (int j = 0; j < nbits; ++j) w |= static_cast<uint64_t>(p[j]) << (8 * j);
+        for (int i = 0; i < 8; ++i)
+            if (e0 + i < n)
+                Elem<DT>::store(gx, e0 + i, mul_f32(lut[static_cast<uint32_t>(w >> (nbits * i)) & mask], Elem<DT>::load(gy, e0 + i)));
     }
 }
 
@@ -746,8 +941,19 @@ int launch_forward(const void *x, void *y, uint8_t *state, size_t n, const void 
             }
             return check_launch("quantize_forward(lut)");
         }
+        if (k > 4 && aligned16(x) && aligned16(y) && n >= lut_min_elements()) {
+            hipLaunchKernelGGL((quantize_forward_lut_wide_kernel<FN, DT>),
+                               dim3(lut_grid<(quantize_forward_lut_wide_kernel<FN, DT>)>(n, 1)), dim3(kLutBlock), 0, s, x, y,
+                               state, n, borders, nborders, k, p0, p1);
+            return check_launch("quantize_forward(lut, wide)");
+        }
     }
-    const bool fast = (nborders == (1 << k) - 1) && k <= 4 && aligned16(x) && aligned16(y) && aligned4(state);
+    const bool pow2 = nborders == (1 << k) - 1;
+    if ((k > 4 || (k == 4 && !pow2)) && aligned16(x) && aligned16(y)) {      // wide or ragged 4-bit tables: LDS search
+        FB_LAUNCH_TILED((quantize_forward_wide_kernel<FN, DT>), n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
+        return check_launch("quantize_forward(wide)");
+    }
+    const bool fast = pow2 && k <= 4 && aligned16(x) && aligned16(y) && aligned4(state);
     if (fast) {
         switch (k) {
         case 1: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 1, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
@@ -778,7 +984,9 @@ int launch_backward(const void *gy, const uint8_t *state, void *gx, size_t n, co
                     hipStream_t s) {
     constexpr int U = Tile<DT>::UB;
     const bool fast = k <= 4 && aligned16(gy) && aligned16(gx) && aligned4(state);
-    if (fast) {
+    if (k > 4 && aligned16(gy) && aligned16(gx)) {
+        FB_LAUNCH_TILED((quantize_backward_wide_kernel<DT>), n, 1, s, gy, state, gx, n, levels, nlevels, k);
+    } else if (fast) {
         switch (k) {
         case 1: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 1, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
         case 2: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 2, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;

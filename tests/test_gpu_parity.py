@@ -379,6 +379,11 @@ def test_every_16bit_pattern_against_oracle_codes(dt):
         [-3.0, -1.5, -0.1, 0.0, 0.1, 1.5, 3.0, 7.0, 9.0, 11.0, 13.0, 15.0, 17.0],                  # 13 borders -> 4 bits
     ]
     tables += [torch.tensor(sorted(set(c))).to(dtype) for c in custom]
+    # wide tables (5..8 bits): pattern table with the borders staged in LDS / LDS tree search
+    gw = torch.Generator().manual_seed(5)
+    for nlev in (17, 40, 100, 256):
+        wide = torch.cat([torch.randn(nlev - 4, generator=gw) * 2, torch.tensor([0.0, float('inf'), -float('inf')])]).to(dtype)
+        tables.append(torch.unique(wide[~torch.isnan(wide)]))
     reps = (1 << 23) // 65536 + 1
     big = pats.repeat(reps)[torch.randperm(65536 * reps, generator=torch.Generator().manual_seed(0))]
     for inner in tables:
@@ -459,3 +464,36 @@ def test_reference_smoke_vectors(dt):
     gx = cabi.quantize_backward(torch.ones(16, dtype=dtype, device=DEV), state, levels.to(DEV))
     assert_bit_equal(gx.cpu(), levels[torch.tensor(want)], 'smoke gx')
     assert y[4].item() == pytest.approx(999.9, rel=1e-2)
+
+
+@pytest.mark.parametrize('dt', list(DTYPES))
+@pytest.mark.parametrize('nlev', (17, 33, 100, 256, 12))
+def test_wide_tables_full_size(dt, nlev):
+    """Tables of 5..8 bits (and a ragged 4-bit one) at 4096x4096 through the streaming wide kernels: codes ==
+    torch.bucketize, gradients == levels[codes] * gy, an oracle window of packed bytes, and the ragged end."""
+    dtype = DTYPES[dt]
+    g = torch.Generator().manual_seed(nlev)
+    inner = torch.unique((torch.randn(nlev - 1, generator=g) * 1.5).to(dtype))
+    levels = torch.rand(inner.numel() + 1, generator=g).to(dtype)
+    k = oracle.bitwidth(inner.numel() + 1)
+    for n in (4096 * 4096, 4096 * 4096 - 8 * 64 - 3, 1 << 19):
+        x = (torch.randn(n, generator=g) * 2).to(dtype)
+        x[:6] = torch.tensor([float('nan'), float('inf'), -float('inf'), 0.0, -0.0, 1e-30]).to(dtype)
+        gy = torch.randn(n, generator=g).to(dtype)
+        xd, gyd = x.to(DEV), gy.to(DEV)
+        y, state = cabi.quantize_forward('silu', xd, inner.to(DEV))
+        codes = cabi.unpack_codes(state, n, k).long()
+        want = torch.bucketize(xd.float(), inner.to(DEV).float())
+        want[0] = inner.numel()                                  # NaN -> last bucket (torch.searchsorted CPU rule)
+        assert torch.equal(codes, want), (dt, nlev, n)
+        gx = cabi.quantize_backward(gyd, state, levels.to(DEV))
+        assert torch.equal(gx.view(torch.int32 if dt == 'f32' else torch.int16),
+                           (levels.to(DEV).float()[codes] * gyd.float()).to(dtype).view(torch.int32 if dt == 'f32' else torch.int16))
+        g0 = 70_001 if n > (1 << 20) else 1_001
+        w = slice(8 * g0, 8 * g0 + 40_000)
+        y_o, s_o, _ = oracle.quantize('silu', x[w], inner)
+        assert torch.equal(state[k * g0:k * g0 + k * 5_000].cpu(), s_o)
+        assert forward_value_ok(x[w], y[w].cpu(), y_o).all()
+        tail = slice(n - 1000, n)
+        _, s_t, _ = oracle.quantize('silu', x[(n - 1000) // 8 * 8:], inner)
+        assert torch.equal(state[k * ((n - 1000) // 8):].cpu(), s_t)
