@@ -85,17 +85,26 @@ template <int DT> struct GroupIO;
 //                           write-combining fills (nontemporal: +4 us)
 //   packed state          : plain -- it is what backward reads next (-0.9 us per step)
 // Loads are always plain (nontemporal loads measured +2 us).
-#define FEWBIT_LD(p) (*(p))
-template <bool NT, typename T> __device__ __forceinline__ void store_as(T *p, T v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
+//
+// Alignment: gfx950 global memory instructions take any byte address (hipcc itself emits global_load_dwordx4 for
+// an align-1 vector), so every access below goes through a typedef that only promises the element's own alignment
+// (fp32 data: 4, 16-bit data: 2, state: 1).  The instructions are the same as for 16-byte aligned pointers, and a
+// tensor view that starts at an odd element offset takes the same kernels at the same speed.
+template <typename T, int A> struct Unaligned { typedef T type __attribute__((aligned(A))); };
+template <int A, typename T> __device__ __forceinline__ T load_as(const void *p) {
+    return *static_cast<const typename Unaligned<T, A>::type *>(p);
+}
+template <bool NT, int A, typename T> __device__ __forceinline__ void store_as(void *p, T v) {
+    typename Unaligned<T, A>::type *q = static_cast<typename Unaligned<T, A>::type *>(p);
+    if constexpr (NT) __builtin_nontemporal_store(v, q);
+    else *q = v;
 }
 
 template <> struct GroupIO<FEWBIT_F32> {
     struct Raw { f32x4 a, b; };
     static __device__ __forceinline__ Raw load_raw(const void *base, size_t g) {
-        const f32x4 *p = static_cast<const f32x4 *>(base) + 2 * g;
-        return Raw{FEWBIT_LD(p), FEWBIT_LD(p + 1)};
+        const float *p = static_cast<const float *>(base) + 8 * g;
+        return Raw{load_as<4, f32x4>(p), load_as<4, f32x4>(p + 4)};
     }
     static __device__ __forceinline__ void unpack(const Raw &r, float (&v)[8]) {
         v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w;
@@ -103,17 +112,17 @@ template <> struct GroupIO<FEWBIT_F32> {
     }
     template <bool NT = false>
     static __device__ __forceinline__ void store(void *base, size_t g, const float (&v)[8]) {
-        f32x4 *p = static_cast<f32x4 *>(base) + 2 * g;
+        float *p = static_cast<float *>(base) + 8 * g;
         f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-        store_as<NT>(p, a);
-        store_as<NT>(p + 1, b);
+        store_as<NT, 4>(p, a);
+        store_as<NT, 4>(p + 4, b);
     }
 };
 
 template <> struct GroupIO<FEWBIT_BF16> {
     struct Raw { u32x4 q; };
     static __device__ __forceinline__ Raw load_raw(const void *base, size_t g) {
-        return Raw{FEWBIT_LD(static_cast<const u32x4 *>(base) + g)};
+        return Raw{load_as<2, u32x4>(static_cast<const uint16_t *>(base) + 8 * g)};
     }
     static __device__ __forceinline__ void unpack(const Raw &r, float (&v)[8]) {
 #pragma unroll
@@ -130,14 +139,14 @@ template <> struct GroupIO<FEWBIT_BF16> {
             f32x2 f = {v[2 * i], v[2 * i + 1]};
             w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));  // v_cvt_pk_bf16_f32
         }
-        store_as<NT>(static_cast<u32x4 *>(base) + g, w);
+        store_as<NT, 2>(static_cast<uint16_t *>(base) + 8 * g, w);
     }
 };
 
 template <> struct GroupIO<FEWBIT_F16> {
     struct Raw { u32x4 q; };
     static __device__ __forceinline__ Raw load_raw(const void *base, size_t g) {
-        return Raw{FEWBIT_LD(static_cast<const u32x4 *>(base) + g)};
+        return Raw{load_as<2, u32x4>(static_cast<const uint16_t *>(base) + 8 * g)};
     }
     static __device__ __forceinline__ void unpack(const Raw &r, float (&v)[8]) {
 #pragma unroll
@@ -154,29 +163,23 @@ template <> struct GroupIO<FEWBIT_F16> {
             f32x2 f = {v[2 * i], v[2 * i + 1]};
             w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));  // v_cvt_pk_f16_f32, RNE
         }
-        store_as<NT>(static_cast<u32x4 *>(base) + g, w);
+        store_as<NT, 2>(static_cast<uint16_t *>(base) + 8 * g, w);
     }
 };
 
 // ------------------------------------------------------------------ packed state access, one group
-// K bytes at byte offset K*g.  Written/read with the widest naturally aligned pieces.
+// K bytes at byte offset K*g.
 template <int K> __device__ __forceinline__ void store_state(uint8_t *state, size_t g, uint32_t w) {
     uint8_t *p = state + static_cast<size_t>(K) * g;
     if constexpr (K == 1) {
         p[0] = static_cast<uint8_t>(w);
     } else if constexpr (K == 2) {
-        *reinterpret_cast<uint16_t *>(p) = static_cast<uint16_t>(w);
+        store_as<false, 1>(p, static_cast<uint16_t>(w));
     } else if constexpr (K == 3) {
-        // 3*g is even for even g: one ushort + one ubyte either way, in aligned order
-        if (g & 1) {
-            p[0] = static_cast<uint8_t>(w);
-            *reinterpret_cast<uint16_t *>(p + 1) = static_cast<uint16_t>(w >> 8);
-        } else {
-            *reinterpret_cast<uint16_t *>(p) = static_cast<uint16_t>(w);
-            p[2] = static_cast<uint8_t>(w >> 16);
-        }
+        store_as<false, 1>(p, static_cast<uint16_t>(w));
+        p[2] = static_cast<uint8_t>(w >> 16);
     } else {
-        *reinterpret_cast<uint32_t *>(p) = w;
+        store_as<false, 1>(p, w);
     }
 }
 
@@ -185,12 +188,11 @@ template <int K> __device__ __forceinline__ uint32_t load_state(const uint8_t *s
     if constexpr (K == 1) {
         return p[0];
     } else if constexpr (K == 2) {
-        return *reinterpret_cast<const uint16_t *>(p);
+        return load_as<1, uint16_t>(p);
     } else if constexpr (K == 3) {
-        if (g & 1) return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(*reinterpret_cast<const uint16_t *>(p + 1)) << 8);
-        return static_cast<uint32_t>(*reinterpret_cast<const uint16_t *>(p)) | (static_cast<uint32_t>(p[2]) << 16);
+        return static_cast<uint32_t>(load_as<1, uint16_t>(p)) | (static_cast<uint32_t>(p[2]) << 16);
     } else {
-        return *reinterpret_cast<const uint32_t *>(p);
+        return load_as<1, uint32_t>(p);
     }
 }
 
@@ -216,29 +218,29 @@ __device__ __forceinline__ void store_state_quad(uint8_t *state, size_t g, int l
     if constexpr (K == 1) {
         uint32_t t = quad_perm<FEWBIT_QUAD_PERM(0, 0, 2, 2)>(w) | (quad_perm<FEWBIT_QUAD_PERM(1, 1, 3, 3)>(w) << 8);
         uint32_t d = quad_perm<FEWBIT_QUAD_PERM(0, 0, 0, 0)>(t) | (quad_perm<FEWBIT_QUAD_PERM(2, 2, 2, 2)>(t) << 16);
-        store_as<NT>(reinterpret_cast<uint32_t *>(quad), d);
+        store_as<NT, 1>(quad, d);
     } else if constexpr (K == 2) {
         uint32_t d = quad_perm<FEWBIT_QUAD_PERM(0, 0, 2, 2)>(w) | (quad_perm<FEWBIT_QUAD_PERM(1, 1, 3, 3)>(w) << 16);
-        store_as<NT>(reinterpret_cast<uint32_t *>(quad + 4 * (i >> 1)), d);
+        store_as<NT, 1>(quad + 4 * (i >> 1), d);
     } else if constexpr (K == 3) {
         // C = w0 | w1<<24 | w2<<48 | w3<<72;  dword j = (w_j >> 8j) | (w_{j+1} << (24-8j)),  j = min(i,2)
         const int j = i < 2 ? i : 2;
         const uint32_t lo = quad_perm<FEWBIT_QUAD_PERM(0, 1, 2, 2)>(w);
         const uint32_t hi = quad_perm<FEWBIT_QUAD_PERM(1, 2, 3, 3)>(w);
         const uint32_t d = (lo >> (8 * j)) | (hi << (24 - 8 * j));
-        store_as<NT>(reinterpret_cast<uint32_t *>(quad + 4 * j), d);
+        store_as<NT, 1>(quad + 4 * j, d);
     } else {
-        store_as<NT>(reinterpret_cast<uint32_t *>(state + 4 * g), w);
+        store_as<NT, 1>(state + 4 * g, w);
     }
 }
 
 template <int K> __device__ __forceinline__ uint32_t load_state_quad_raw(const uint8_t *state, size_t g, int lane) {
     const int i = lane & 3;
     const uint8_t *quad = state + static_cast<size_t>(K) * (g - i);
-    if constexpr (K == 1) return *reinterpret_cast<const uint32_t *>(quad);
-    else if constexpr (K == 2) return *reinterpret_cast<const uint32_t *>(quad + 4 * (i >> 1));
-    else if constexpr (K == 3) return *reinterpret_cast<const uint32_t *>(quad + 4 * (i < 2 ? i : 2));
-    else return *reinterpret_cast<const uint32_t *>(state + 4 * g);
+    if constexpr (K == 1) return load_as<1, uint32_t>(quad);
+    else if constexpr (K == 2) return load_as<1, uint32_t>(quad + 4 * (i >> 1));
+    else if constexpr (K == 3) return load_as<1, uint32_t>(quad + 4 * (i < 2 ? i : 2));
+    else return load_as<1, uint32_t>(state + 4 * g);
 }
 
 // turn the dword fetched by load_state_quad_raw into this lane's 8K-bit word (bits above 8K are junk)
@@ -260,15 +262,16 @@ template <int K> __device__ __forceinline__ uint32_t load_state_quad_fix(uint32_
 // reads its word with ONE 8-byte load -- which also fetches up to 3 bytes of the next group: callers keep one group
 // of slack before the end of the buffer -- and writes it as a dword plus K-4 single bytes.
 __device__ __forceinline__ uint64_t load_state_wide(const uint8_t *state, size_t g, int nbits) {
-    uint64_t w;
-    __builtin_memcpy(&w, state + static_cast<size_t>(nbits) * g, 8);
-    return w;
+    return load_as<1, uint64_t>(state + static_cast<size_t>(nbits) * g);
 }
 
 __device__ __forceinline__ void store_state_wide(uint8_t *state, size_t g, int nbits, uint64_t w) {
     uint8_t *p = state + static_cast<size_t>(nbits) * g;
-    const uint32_t lo = static_cast<uint32_t>(w);
-    __builtin_memcpy(p, &lo, 4);
+    if (nbits < 4) {               // ragged narrow tables (3, 5..7 levels): bytes only
+        for (int j = 0; j < nbits; ++j) p[j] = static_cast<uint8_t>(w >> (8 * j));
+        return;
+    }
+    store_as<false, 1>(p, static_cast<uint32_t>(w));
     uint32_t hi = static_cast<uint32_t>(w >> 32);
     for (int j = 4; j < nbits; ++j) {
         p[j] = static_cast<uint8_t>(hi);

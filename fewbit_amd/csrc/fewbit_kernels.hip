@@ -17,7 +17,8 @@
 //                                 VGPRs (v_readlane), MSB-first search in hand-scheduled asm
 //   quantize_backward_kernel      levels staged in LDS, one gather + one multiply per element
 //   stepwise1_*_kernel            the exact 1-bit family
-//   *_generic_kernel              tables wider than 4 bits, misaligned pointers
+//   quantize_*_wide_kernel        tables of 5..8 bits and tables that do not fill their bit width
+// No kernel needs aligned pointers: gfx950 global accesses take any address (see fewbit_device.h).
 //   pack/unpack_codes_kernel      codec seam used by the tests
 #include <hip/hip_runtime.h>
 
@@ -347,7 +348,8 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
 }
 
 // ------------------------------------------------------------------------------------------------
-// Wide tables (17..256 levels, 5..8 bits per code), 16-byte aligned data: the same streaming structure with the
+// Wide tables (17..256 levels, 5..8 bits per code) and tables that do not fill their bit width (3, 5..7, 9..15
+// levels): the same streaming structure with the
 // bit width as a run-time (wave-uniform) value, so that one instantiation per functor/dtype serves all four widths.
 
 // code of `key` against the padded border tree in LDS: fixed nbits-step descent, NaN -> nborders
@@ -539,59 +541,6 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_
     }
 }
 
-// Generic forward: any table size up to 255 borders (K up to 8), any pointer alignment.
-// One thread per group; the borders sit in LDS padded with +inf to a full tree of 2^nbits - 1 nodes, so the search
-// is a fixed nbits-step branch-free descent (NaN runs off the padded end and is clamped to nborders, the
-// torch.searchsorted rule).  `vec`: x and y are 16-byte aligned -> whole groups move as lane-contiguous 16 B pieces.
-template <int FN, int DT>
-__global__ __launch_bounds__(kBlock) void quantize_forward_generic_kernel(const void *x, void *y,
-                                                                          uint8_t *__restrict__ state, size_t n,
-                                                                          const void *__restrict__ borders,
-                                                                          int nborders, int nbits, float p0, float p1,
-                                                                          bool vec) {
-    constexpr bool kFast = (DT != FEWBIT_F32);
-    __shared__ float sb[256];
-    for (int j = threadIdx.x; j < 256; j += kBlock) sb[j] = j < nborders ? Elem<DT>::load(borders, j) : __builtin_inff();
-    __syncthreads();
-    const size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    const size_t e0 = g << 3;
-    if (e0 >= n) return;
-    const bool full = vec && e0 + 8 <= n;
-    float v[8];
-    if (full) {
-        GroupIO<DT>::unpack(GroupIO<DT>::load_raw(x, g), v);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = e0 + i < n ? Elem<DT>::load(x, e0 + i) : 0.0f;
-    }
-    uint32_t pos[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) pos[i] = 0;
-    for (uint32_t step = 1u << (nbits - 1); step != 0; step >>= 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float key = Act<FN, kFast>::key(v[i], p0);
-            pos[i] += !(sb[pos[i] + step - 1] >= key) ? step : 0u;
-        }
-    }
-    uint64_t w = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t code = e0 + i < n ? min(pos[i], static_cast<uint32_t>(nborders)) : 0u;   // padding codes are 0
-        w |= static_cast<uint64_t>(code) << (nbits * i);
-        v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
-    }
-    if (full) {
-        GroupIO<DT>::store(y, g, v);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (e0 + i < n) Elem<DT>::store(y, e0 + i, v[i]);
-    }
-    uint8_t *p = state + static_cast<size_t>(nbits) * g;
-    for (int j = 0; j < nbits; ++j) p[j] = static_cast<uint8_t>(w >> (8 * j));
-}
-
 // ------------------------------------------------------------------------------------------------
 // Fused backward: unpack + level gather (LDS) + multiply, same software pipeline.
 // Replaces StepwiseBackwardKernel + InflateWarpKernel (fewbit/cuda/codec.cu:655-663, :184-203).
@@ -645,48 +594,15 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kerne
     }
 }
 
-template <int DT>
-__global__ __launch_bounds__(kBlock) void quantize_backward_generic_kernel(const void *gy,
-                                                                           const uint8_t *__restrict__ state,
-                                                                           void *gx, size_t n,
-                                                                           const void *__restrict__ levels,
-                                                                           int nlevels, int nbits, bool vec) {
-    __shared__ float lut[256];
-    for (int j = threadIdx.x; j < 256; j += kBlock) lut[j] = j < nlevels ? Elem<DT>::load(levels, j) : 0.0f;
-    __syncthreads();
-    const size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    const size_t e0 = g << 3;
-    if (e0 >= n) return;
-    const uint8_t *p = state + static_cast<size_t>(nbits) * g;
-    uint64_t w = 0;
-    for (int j = 0; j < nbits; ++j) w |= static_cast<uint64_t>(p[j]) << (8 * j);
-    const uint32_t mask = (1u << nbits) - 1u;
-    if (vec && e0 + 8 <= n) {
-        float v[8];
-        GroupIO<DT>::unpack(GroupIO<DT>::load_raw(gy, g), v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = mul_f32(lut[static_cast<uint32_t>(w >> (nbits * i)) & mask], v[i]);
-        GroupIO<DT>::store(gx, g, v);
-        return;
-    }
-    for (int i = 0; i < 8; ++i)
-        if (e0 + i < n)
-            Elem<DT>::store(gx, e0 + i, mul_f32(lut[static_cast<uint32_t>(w >> (nbits * i)) & mask], Elem<DT>::load(gy, e0 + i)));
-}
-
 // ------------------------------------------------------------------------------------------------
 // 1-bit family (ReLU & co): exact derivative, one bit per element.
 // Replaces the eight <Name>Kernel / <Name>BackwardKernel pairs, fewbit/cuda/codec.cu:298-487.
 template <int FN, int DT, int U>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kernel(const void *x, void *y,
                                                                    uint8_t *__restrict__ state, size_t n, float p0,
-                                                                   float p1, bool aligned) {
+                                                                   float p1) {
     typedef typename GroupIO<DT>::Raw Raw;
-    Span s = make_span<U>(n);
-    if (!aligned) {  // everything through the element-wise tail
-        s.ntiles = 0;
-        s.tail_g0 = 0;
-    }
+    const Span s = make_span<U>(n);
     struct Buf { Raw r[U]; };
     pipeline2<Buf>(
         s, []() {},
@@ -711,11 +627,8 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kerne
                 store_state_quad<1, false>(state, g, s.lane, w);
             }
         });
-    if (aligned && s.wave != s.nwaves - 1) return;
-    // tail (or the whole range when misaligned: every wave strides over the groups)
-    const size_t first = aligned ? s.tail_g0 + s.lane : s.wave * kWave + s.lane;
-    const size_t step = aligned ? kWave : s.nwaves * kWave;
-    for (size_t g = first; g < s.ngroups; g += step) {
+    if (s.wave != s.nwaves - 1) return;
+    for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
         const size_t e0 = g << 3;
         uint32_t w = 0;
         for (int i = 0; i < 8; ++i) {
@@ -732,13 +645,9 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kerne
 template <int DT, int U>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_backward_kernel(const void *gy,
                                                                     const uint8_t *state, void *gx,
-                                                                    size_t n, float m0, float m1, bool aligned) {
+                                                                    size_t n, float m0, float m1) {
     typedef typename GroupIO<DT>::Raw Raw;
-    Span s = make_span<U>(n);
-    if (!aligned) {
-        s.ntiles = 0;
-        s.tail_g0 = 0;
-    }
+    const Span s = make_span<U>(n);
     struct Buf { Raw r[U]; uint32_t w[U]; };
     pipeline2<Buf>(
         s, []() {},
@@ -760,10 +669,8 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_backward_kern
                 GroupIO<DT>::store(gx, (t * U + u) * kWave + s.lane, v);
             }
         });
-    if (aligned && s.wave != s.nwaves - 1) return;
-    const size_t first = aligned ? s.tail_g0 + s.lane : s.wave * kWave + s.lane;
-    const size_t step = aligned ? kWave : s.nwaves * kWave;
-    for (size_t g = first; g < s.ngroups; g += step) {
+    if (s.wave != s.nwaves - 1) return;
+    for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
         const size_t e0 = g << 3;
         const uint32_t w = load_state<1>(state, g);
         for (int i = 0; i < 8; ++i)
@@ -822,8 +729,6 @@ int check_launch(const char *what) {
     return FEWBIT_OK;
 }
 
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
 // groups per lane per pipeline stage (tunable, FEWBIT_HIP_U) and resident waves per CU the grid is
 // sized for (FEWBIT_HIP_WAVES_PER_CU); defaults from measurements on MI355X, see DESIGN.md
@@ -927,43 +832,35 @@ template <int FN, int DT>
 int launch_forward(const void *x, void *y, uint8_t *state, size_t n, const void *borders, int nborders, int k,
                    float p0, float p1, hipStream_t s) {
     constexpr int U = Tile<DT>::U;
-    // (a folded key |x - shift| is an fp32 value, not one of the 65 536 input patterns: search kernel only)
+    const bool pow2 = nborders == (1 << k) - 1;
+    // (a folded key |x - shift| is an fp32 value, not one of the 65 536 input patterns: search kernels only)
     if constexpr (DT != FEWBIT_F32 && FN != FEWBIT_IDENTITY_FOLD) {
-        constexpr int UL = FEWBIT_U16_LUT;
-        // 16-bit dtypes, any table with k <= 4 (power of two or not): pattern-table kernel once the tensor is big
-        // enough to pay for building the table in every block
-        if (k <= 4 && aligned16(x) && aligned16(y) && aligned4(state) && n >= lut_min_elements()) {
+        // 16-bit dtypes, any table (power of two or not): pattern-table kernel once the tensor is big enough to pay for
+        // building the table in every block
+        if (n >= lut_min_elements()) {
+            constexpr int UL = FEWBIT_U16_LUT;
             switch (k) {
             case 1: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 1, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
             case 2: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 2, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
             case 3: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 3, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
-            default: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 4, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
+            case 4: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 4, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
+            default:
+                hipLaunchKernelGGL((quantize_forward_lut_wide_kernel<FN, DT>),
+                                   dim3(lut_grid<(quantize_forward_lut_wide_kernel<FN, DT>)>(n, 1)), dim3(kLutBlock), 0, s, x,
+                                   y, state, n, borders, nborders, k, p0, p1);
             }
             return check_launch("quantize_forward(lut)");
         }
-        if (k > 4 && aligned16(x) && aligned16(y) && n >= lut_min_elements()) {
-            hipLaunchKernelGGL((quantize_forward_lut_wide_kernel<FN, DT>),
-                               dim3(lut_grid<(quantize_forward_lut_wide_kernel<FN, DT>)>(n, 1)), dim3(kLutBlock), 0, s, x, y,
-                               state, n, borders, nborders, k, p0, p1);
-            return check_launch("quantize_forward(lut, wide)");
-        }
     }
-    const bool pow2 = nborders == (1 << k) - 1;
-    if ((k > 4 || (k == 4 && !pow2)) && aligned16(x) && aligned16(y)) {      // wide or ragged 4-bit tables: LDS search
-        FB_LAUNCH_TILED((quantize_forward_wide_kernel<FN, DT>), n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
-        return check_launch("quantize_forward(wide)");
-    }
-    const bool fast = pow2 && k <= 4 && aligned16(x) && aligned16(y) && aligned4(state);
-    if (fast) {
+    if (pow2 && k <= 4) {          // full 1..4-bit tables: borders in registers
         switch (k) {
         case 1: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 1, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
         case 2: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 2, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
         case 3: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 3, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
         default: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 4, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
         }
-    } else {
-        hipLaunchKernelGGL((quantize_forward_generic_kernel<FN, DT>), dim3(group_grid(n)), dim3(kBlock), 0, s, x, y,
-                           state, n, borders, nborders, k, p0, p1, aligned16(x) && aligned16(y));
+    } else {                       // 5..8-bit tables and tables that do not fill their bit width: borders in LDS
+        FB_LAUNCH_TILED((quantize_forward_wide_kernel<FN, DT>), n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
     }
     return check_launch("quantize_forward");
 }
@@ -983,19 +880,12 @@ template <int DT>
 int launch_backward(const void *gy, const uint8_t *state, void *gx, size_t n, const void *levels, int nlevels, int k,
                     hipStream_t s) {
     constexpr int U = Tile<DT>::UB;
-    const bool fast = k <= 4 && aligned16(gy) && aligned16(gx) && aligned4(state);
-    if (k > 4 && aligned16(gy) && aligned16(gx)) {
-        FB_LAUNCH_TILED((quantize_backward_wide_kernel<DT>), n, 1, s, gy, state, gx, n, levels, nlevels, k);
-    } else if (fast) {
-        switch (k) {
-        case 1: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 1, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
-        case 2: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 2, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
-        case 3: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 3, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
-        default: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 4, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
-        }
-    } else {
-        hipLaunchKernelGGL((quantize_backward_generic_kernel<DT>), dim3(group_grid(n)), dim3(kBlock), 0, s, gy, state,
-                           gx, n, levels, nlevels, k, aligned16(gy) && aligned16(gx));
+    switch (k) {
+    case 1: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 1, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
+    case 2: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 2, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
+    case 3: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 3, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
+    case 4: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 4, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
+    default: FB_LAUNCH_TILED((quantize_backward_wide_kernel<DT>), n, 1, s, gy, state, gx, n, levels, nlevels, k);
     }
     return check_launch("quantize_backward");
 }
@@ -1003,8 +893,7 @@ int launch_backward(const void *gy, const uint8_t *state, void *gx, size_t n, co
 template <int FN, int DT>
 int launch_step1_forward(const void *x, void *y, uint8_t *state, size_t n, float p0, float p1, hipStream_t s) {
     constexpr int U = Tile<DT>::U;
-    FB_LAUNCH_TILED((stepwise1_forward_kernel<FN, DT, U>), n, U, s, x, y, state, n, p0, p1,
-                    aligned16(x) && aligned16(y) && aligned4(state));
+    FB_LAUNCH_TILED((stepwise1_forward_kernel<FN, DT, U>), n, U, s, x, y, state, n, p0, p1);
     return check_launch("stepwise1_forward");
 }
 
@@ -1101,20 +990,19 @@ int fewbit_hip_stepwise1_backward(int fn, int dtype, const void *gy, const uint8
     if (fn < 0 || fn >= FEWBIT_STEPWISE_COUNT) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown stepwise fn %d", fn);
     if (n == 0) return FEWBIT_OK;
     if (!gy || !gx || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
-    const bool al = aligned16(gy) && aligned16(gx) && aligned4(state);
     float m0 = 0.0f, m1 = 1.0f;
     if (fn == FEWBIT_HARDSIGMOID) m1 = 1.0f / 6.0f;
     if (fn == FEWBIT_LEAKY_RELU) { m0 = 1.0f; m1 = static_cast<float>(p0); }
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (dtype) {
     case FEWBIT_F32:
-        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_F32, Tile<FEWBIT_F32>::UB>), n, Tile<FEWBIT_F32>::UB, s, gy, state, gx, n, m0, m1, al);
+        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_F32, Tile<FEWBIT_F32>::UB>), n, Tile<FEWBIT_F32>::UB, s, gy, state, gx, n, m0, m1);
         break;
     case FEWBIT_F16:
-        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_F16, Tile<FEWBIT_F16>::UB>), n, Tile<FEWBIT_F16>::UB, s, gy, state, gx, n, m0, m1, al);
+        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_F16, Tile<FEWBIT_F16>::UB>), n, Tile<FEWBIT_F16>::UB, s, gy, state, gx, n, m0, m1);
         break;
     case FEWBIT_BF16:
-        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_BF16, Tile<FEWBIT_BF16>::UB>), n, Tile<FEWBIT_BF16>::UB, s, gy, state, gx, n, m0, m1, al);
+        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_BF16, Tile<FEWBIT_BF16>::UB>), n, Tile<FEWBIT_BF16>::UB, s, gy, state, gx, n, m0, m1);
         break;
     default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
     }

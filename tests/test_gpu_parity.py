@@ -200,7 +200,7 @@ def test_empty_input_and_in_place_and_misaligned():
     gyd = gy.to(DEV)
     gx = cabi.quantize_backward(gyd, st, levels, out=gyd)
     assert_bit_equal(gyd.cpu(), oracle.quantize_backward(gy, s_o, levels.cpu()), 'in-place gx')
-    # misaligned views: data / state pointers that are not 16 / 4 byte aligned take the generic kernels
+    # misaligned views: data / state pointers that are not 16 / 4 byte aligned (same kernels: no alignment needed)
     base = torch.zeros(20011 + 8, dtype=dtype, device=DEV)
     for off in (1, 3):
         xv = base[off:off + 20011]
@@ -222,7 +222,7 @@ def test_empty_input_and_in_place_and_misaligned():
 
 @pytest.mark.parametrize('nlevels', (2, 3, 5, 8, 9, 17, 33, 100, 256))
 def test_custom_tables_any_size(nlevels):
-    """Non power-of-two level counts and wide codes (up to 8 bits) go through the generic kernels."""
+    """Non power-of-two level counts and wide codes (up to 8 bits) go through the wide (LDS-search) kernels."""
     g = torch.Generator().manual_seed(nlevels)
     for dtype in (torch.float32, torch.bfloat16):
         inner = torch.sort(torch.randn(nlevels - 1, generator=g) * 1.5).values.to(dtype).unique()
@@ -400,7 +400,7 @@ def test_every_16bit_pattern_against_oracle_codes(dt):
 @pytest.mark.parametrize('nlev', (2, 4, 7, 8, 16, 40))
 def test_folded_custom_table_vs_oracle(dt, nlev):
     """Even-parity fold (FEWBIT_IDENTITY_FOLD): the key searched is |x - shift_x| in fp32.  Tables of 1..4 bits take the
-    streaming search kernel, wider/ragged/misaligned ones the generic kernel; all must give the oracle's bytes."""
+    streaming search kernel, wider/ragged ones the LDS-search kernel; all must give the oracle's bytes."""
     dtype = DTYPES[dt]
     g = torch.Generator().manual_seed(nlev)
     half = torch.sort(torch.rand(nlev - 1, generator=g) * 3 + 0.01).values.to(dtype)
@@ -417,7 +417,7 @@ def test_folded_custom_table_vs_oracle(dt, nlev):
             assert_bit_equal(y.cpu()[fin], x[fin], tag + ' y')
             assert_bit_equal(cabi.quantize_backward(gy.to(DEV), state, levels.to(DEV)).cpu(),
                              oracle.quantize_backward(gy, s_o, levels), tag + ' gx')
-    # misaligned pointers -> generic kernel
+    # misaligned pointers (same kernels)
     x, _ = make_x(4099, dtype, half, seed=5)
     xd = torch.empty(4099 + 8, dtype=dtype, device=DEV)[3:3 + 4099]
     xd.copy_(x)
