@@ -373,21 +373,21 @@ __device__ __forceinline__ float log1p_pos_fast(float e) {
     return e < 0.0078125f ? ser : l;
 }
 
-__device__ __forceinline__ float tanh_fast(float x) {
-    const float a = __builtin_fabsf(x);
-    const float e2 = __builtin_amdgcn_exp2f(a * (2.0f * kLog2e));
-    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e2 + 1.0f);   // exp overflow -> rcp(inf) = 0 -> 1
-    const float s = a * a;
-    // |x| < 1/4: x*(1 - s/3 + 2 s^2/15 - 17 s^3/315 + 62 s^4/2835), truncation < 2e-8 relative
-    float p = 0.021869488f;
-    p = __builtin_fmaf(p, s, -0.053968254f);
-    p = __builtin_fmaf(p, s, 0.13333334f);
-    p = __builtin_fmaf(p, s, -0.33333334f);
-    const float small = __builtin_fmaf(p * s, a, a);
-    return __builtin_copysignf(a < 0.25f ? small : big, x);
+// tanh(a) for a >= 0 as (1 - e)/(1 + e), e = exp(-2a) in (0, 1]: no overflow, NaN propagates, and the cancellation in
+// 1 - e costs 2^-24/(2a) relative -- below 2^-14 from a = 2^-11 up, which is all a 16-bit result can see.
+__device__ __forceinline__ float tanh_pos_fast(float a) {
+    const float e = __builtin_amdgcn_exp2f(a * (-2.0f * kLog2e));
+    return (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// x - tanh(x): series x^3/3 - 2x^5/15 + 17x^7/315 - 62x^9/2835 + 1382 x^11/155925 below 1/2 (no cancellation)
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float a = __builtin_fabsf(x);
+    const float t = tanh_pos_fast(a);
+    return __builtin_copysignf(a < 0x1p-11f ? a : t, x);       // tanh(a) = a (1 - a^2/3 + ...): a itself below 2^-11
+}
+
+// x - tanh(x): series x^3/3 - 2x^5/15 + 17x^7/315 - 62x^9/2835 + 1382 x^11/155925 below 1/2 (no cancellation),
+// a - tanh(a) above (>= 0.038 there, so the 2^-24 absolute error of tanh is 2^-19 relative at worst)
 __device__ __forceinline__ float tanhshrink_fast(float x) {
     const float a = __builtin_fabsf(x);
     const float s = a * a;
@@ -397,7 +397,7 @@ __device__ __forceinline__ float tanhshrink_fast(float x) {
     p = __builtin_fmaf(p, s, -0.13333334f);
     p = __builtin_fmaf(p, s, 0.33333334f);
     const float small = p * s * a;
-    const float big = a - tanh_fast(a);
+    const float big = a - tanh_pos_fast(a);
     return __builtin_copysignf(a < 0.5f ? small : big, x);
 }
 
