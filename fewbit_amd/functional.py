@@ -146,9 +146,10 @@ def _make_continuous(name: str) -> Callable:
         if use_builtin and use_custom:
             raise ValueError('Either `bits` or `borders` and `values` should be scpecifed not both.')
         if use_builtin or not use_custom:
-            borders, values = store.get(name, bits or BITS_DEFAULT, input.device, input.dtype)
-        inner = borders[1:-1].to(input)
-        levels = values.to(input)
+            inner, levels = store.get_inner(name, bits or BITS_DEFAULT, input.device, input.dtype)
+        else:
+            inner = borders[1:-1].to(input)
+            levels = values.to(input)
         if input.device.type == 'cuda':
             return _gpu_continuous(name, input, inner, levels, extra)
         return _HostQuantized.apply(impl, input, inner, levels, *extra)

@@ -23,6 +23,7 @@ class StepwiseStore:
     def __init__(self):
         self._store: Dict[Tuple[str, int], Table] = {}
         self._cache: Dict[Tuple[str, int, torch.device, torch.dtype], Table] = {}
+        self._inner: Dict[Tuple[str, int, torch.device, torch.dtype], Table] = {}
 
     def __len__(self) -> int:
         return len(self._store)
@@ -40,8 +41,9 @@ class StepwiseStore:
         entry = (borders, values.to(borders))
         self._store[(name, int(bits))] = entry
         # drop stale casts of a replaced table
-        for key in [k for k in self._cache if k[:2] == (name, int(bits))]:
-            del self._cache[key]
+        for cache in (self._cache, self._inner):
+            for key in [k for k in cache if k[:2] == (name, int(bits))]:
+                del cache[key]
         self._cache[(name, int(bits), borders.device, borders.dtype)] = entry
 
     def get(self, name: str, bits: int, device: Union[None, str, torch.device] = None,
@@ -60,6 +62,16 @@ class StepwiseStore:
         cast = tuple(el.to(device, dtype) for el in leaf)
         self._cache[key] = cast
         return cast
+
+    def get_inner(self, name: str, bits: int, device: torch.device, dtype: torch.dtype) -> Table:
+        """``(borders[1:-1], levels)`` of :meth:`get`, contiguous and cached: what the kernels take, without a slice and
+        two ``.to`` calls on every forward (the per-call overhead SURVEY 8a2 points at)."""
+        key = (name, bits, device, dtype)
+        hit = self._inner.get(key)
+        if hit is None:
+            borders, levels = self.get(name, bits, device, dtype)
+            hit = self._inner[key] = (borders[1:-1].contiguous(), levels)
+        return hit
 
     def items(self, cached: bool = False) -> Iterator:
         yield from (self._cache if cached else self._store).items()
