@@ -315,3 +315,15 @@ def test_randomized_linear_on_gpu(matmul):
     assert rel < 0.35, rel                                   # one draw: ~sqrt(rows/p) = 2; mean of 64: ~0.25
     out = fewbit.GELU(bits=3)(lin(x))
     out.sum().backward()
+
+
+def test_torch_free_host_program_on_the_c_abi():
+    """examples/cabi_demo.cpp: plain C++ + the HIP runtime + libfewbit_hip.so (no torch, no python) -- forward and
+    backward of one million elements checked on the host by the program itself."""
+    import subprocess
+    from helpers import ROOT
+    exe = ROOT / 'examples' / 'cabi_demo'
+    assert exe.exists(), 'build it with `make -C fewbit_amd/csrc demo`'
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'mismatches: codes 0, gradients 0, forward 0' in out.stdout
