@@ -114,3 +114,17 @@ def test_gradient_catcher_and_variance_estimator():
     g = est.state.grad_output
     want = (torch.linalg.norm(inp)**2 * torch.linalg.norm(g)**2 - torch.linalg.norm(inp.T @ g)**2) / 5
     assert torch.allclose(var_rmm, want, rtol=1e-5)
+
+
+def test_sketch_dtype_keeps_the_estimate_unbiased():
+    """sketch_dtype=bfloat16 (the MI355X choice for fp32 layers): same forward, exact input gradient, and the mean of
+    the weight-gradient estimates still converges to the exact gradient."""
+    torch.manual_seed(3)
+    module = LinearGRP(64, 32, proj_dim=32, sketch_dtype=torch.bfloat16)
+    exact = reference_linear(module)
+    xs = torch.randn(128, 64, requires_grad=True)
+    gi, gw, gb = mean_grads(module, xs, 1500)
+    ri, rw, rb = mean_grads(exact, xs, 1)
+    assert (torch.linalg.norm(gi - ri) / torch.linalg.norm(ri)).item() <= 1e-6
+    assert (torch.linalg.norm(gw - rw) / torch.linalg.norm(rw)).item() <= 1e-1
+    assert gw.dtype == torch.float32

@@ -44,6 +44,22 @@ def swap_gelu(model, bits):
     return n[0]
 
 
+def swap_linear(model, ratio, sketch_dtype=None):
+    """Every nn.Linear of the encoder -> fewbit.RandomizedLinear(proj_dim_ratio=ratio) sharing its parameters (the
+    README's `convert_linear` recipe); the classification head stays exact."""
+    from fewbit.util import convert_linear
+    n = [0]
+
+    def fn(mod, path):
+        if type(mod) is torch.nn.Linear and '/encoder/' in path:
+            n[0] += 1
+            return convert_linear(mod, fewbit.RandomizedLinear, proj_dim_ratio=ratio, sketch_dtype=sketch_dtype)
+        return mod
+
+    fewbit.map_module(model, fn)
+    return n[0]
+
+
 def run(model, ids, labels, steps, warmup=3):
     opt = torch.optim.SGD(model.parameters(), lr=1e-4)
     dev = ids.device
@@ -80,12 +96,37 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--seq', type=int, default=128)
     ap.add_argument('--only', default=None, choices=(None, 'vanilla', 'fewbit'), help='run a single variant (profiling)')
+    ap.add_argument('--table', action='store_true',
+                    help="the four rows of the reference README's table: GELU {vanilla, 3-bit} x linear {vanilla, randomized}")
+    ap.add_argument('--linear-ratio', type=float, default=0.2, help='proj_dim_ratio of the randomized linear layers')
+    ap.add_argument('--sketch-bf16', action='store_true', help='run the sketch GEMMs of fp32 layers in bf16')
     args = ap.parse_args()
     dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[args.dtype]
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(1)
     ids = torch.randint(5, 50000, (args.batch, args.seq), generator=g).to(dev)
     labels = torch.randint(0, 2, (args.batch,), generator=g).to(dev)
+
+    if args.table:
+        rows = []
+        for gelu, linear in ((False, False), (True, False), (False, True), (True, True)):
+            model = build(dtype, dev)
+            ng = swap_gelu(model, args.bits) if gelu else 0
+            nl = swap_linear(model, args.linear_ratio, torch.bfloat16 if args.sketch_bf16 else None) if linear else 0
+            r = run(model, ids, labels, args.steps)
+            rows.append({'gelu': f'{args.bits}-bit' if gelu else 'vanilla', 'linear': 'randomized' if linear else 'vanilla',
+                         'gelu_modules_swapped': ng, 'linear_modules_swapped': nl, 'ms_per_step': round(r['ms_per_step'], 2),
+                         'peak_gib': round(r['peak_bytes'] / 2**30, 3), 'loss': r['loss']})
+            del model
+            torch.cuda.empty_cache()
+        for r in rows:
+            r['saving_pct'] = round(100.0 * (1.0 - r['peak_gib'] / rows[0]['peak_gib']), 1)
+            r['step_time_ratio'] = round(r['ms_per_step'] / rows[0]['ms_per_step'], 3)
+        print(json.dumps({'config': f'RoBERTa-base (random init) batch {args.batch} x seq {args.seq}, {args.dtype}, '
+                                    f'fwd+bwd+SGD step; randomized linear proj_dim_ratio={args.linear_ratio}'
+                                    + (', sketch GEMMs in bf16' if args.sketch_bf16 else ''),
+                          'rows': rows}))
+        return
 
     res = {}
     for name in ('vanilla', 'fewbit'):
