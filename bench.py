@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- forward+backward throughput of the 3-bit GELU hot path on MI355X.
+"""bench.py -- forward+backward throughput of the few-bit activation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4] [--no-extras] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config c4]
 
 One "step" = one pass of the hot path over one batch: the fused quantize+pack forward and the fused unpack+mul
-backward of fewbit.gelu(bits=3) over a 4096x4096 bf16 activation (BASELINE.json configs[1]), both through the C-ABI
-(include/fewbit_hip.h) on HBM-resident synthetic tensors.  With N > 1 every rank runs the same per-GPU workload on
-its own shard (weak scaling, no collectives on the data path; torch.distributed is only used for the barrier and
-the max-over-ranks of the elapsed time).  Rank 0 prints ONE JSON line.
+backward of fewbit.gelu(bits=3), both through the C-ABI (include/fewbit_hip.h) on HBM-resident synthetic tensors.
+  --config c2 (default)  4096x4096 bf16 per GPU              (BASELINE.json configs[1], the headline metric)
+  --config c4            8192x4096 bf16 per GPU = the shard one GPU owns of BASELINE.json configs[3]
+                         (4 x (16384x4096) bf16 over 8 GPUs, cut by fewbit_amd.sharding.shard_range)
+With N > 1 every rank runs the same per-GPU workload on its own shard (weak scaling, no collective on the data
+path; torch.distributed carries only the barrier before and the max-over-ranks after the timed region).
 
-metric = algorithmic bytes / time, algorithmic bytes per element = 4*s + k/4 (fwd: read x, write y, write state;
+Timed region: W warm-up steps, barrier + synchronize, a short untimed pre-roll that fills the launch queue,
+then EXACTLY K steps between two HIP events recorded on the launch stream, synchronize (+ barrier).  ms_per_step is
+the event time / K (max over ranks); the host wall clock around the same region is reported beside it.
+
+metric = algorithmic bytes / time; algorithmic bytes per element = 4*s + k/4 (fwd: read x, write y, write state;
 bwd: read gy, read state, write gx; s = element size, k = bits) -- SURVEY.md 8(d).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries (N = 1, unless --no-extras):
+  cold       the same workload rotating through > 1 GiB of independent buffer sets (Infinity Cache out of the picture)
+  configs    every other BASELINE config on one GPU (c1 relu fp32 1024^2, c3 silu k=2/k=4 fp16 8192^2, c4 shard,
+             c2 in fp32), each cache-warm and cache-cold: us_fwd / us_bwd / us_step / GiB_s / frac of 8 TB/s
+  cpu_baseline, cpu_baseline_1thread   the reference's own CPU path (oracle/_ref) on the host cores
 """
 import argparse
 import json
@@ -29,53 +41,169 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-ROWS, COLS, BITS = 4096, 4096, 3
-DTYPE, DTYPE_NAME = torch.bfloat16, 'bf16'
+INFINITY_CACHE_BYTES = 256 << 20
+DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}
+
+# BASELINE.json configs.  `kind`: continuous = k-bit table kernels, stepwise1 = exact 1-bit family
+CONFIGS = {
+    'c2': dict(fn='gelu', bits=3, rows=4096, cols=4096, dtype='bf16', kind='continuous',
+               label='fewbit.gelu bits=3 on 4096x4096 bf16'),
+    'c4': dict(fn='gelu', bits=3, rows=8192, cols=4096, dtype='bf16', kind='continuous',
+               label='fewbit.gelu bits=3 on 8192x4096 bf16 = one GPU\'s shard of 4x(16384x4096) over 8 GPUs'),
+    'c1': dict(fn='relu', bits=1, rows=1024, cols=1024, dtype='f32', kind='stepwise1',
+               label='fewbit.relu 1-bit on 1024x1024 fp32'),
+    'c3_k2': dict(fn='silu', bits=2, rows=8192, cols=8192, dtype='f16', kind='continuous',
+                  label='fewbit.silu bits=2 on 8192x8192 fp16'),
+    'c3_k4': dict(fn='silu', bits=4, rows=8192, cols=8192, dtype='f16', kind='continuous',
+                  label='fewbit.silu bits=4 on 8192x8192 fp16'),
+    'c2_fp32': dict(fn='gelu', bits=3, rows=4096, cols=4096, dtype='f32', kind='continuous',
+                    label='fewbit.gelu bits=3 on 4096x4096 fp32'),
+}
 
 
-def load_tables(device):
+def load_tables(cfg, device):
+    dt = DTYPES[cfg['dtype']]
     with np.load(ROOT / 'fewbit_amd' / 'data' / 'builtin.npz') as z:
-        borders = torch.tensor(z[f'gelu{BITS:02d}-borders']).to(DTYPE)[1:-1].contiguous().to(device)
-        levels = torch.tensor(z[f'gelu{BITS:02d}-levels']).to(DTYPE).to(device)
+        key = f"{cfg['fn']}{cfg['bits']:02d}"
+        borders = torch.tensor(z[f'{key}-borders']).to(dt)[1:-1].contiguous().to(device)
+        levels = torch.tensor(z[f'{key}-levels']).to(dt).to(device)
     return borders, levels
 
 
-def cpu_baseline():
+def step_bytes(cfg):
+    es = torch.empty(0, dtype=DTYPES[cfg['dtype']]).element_size()
+    n = cfg['rows'] * cfg['cols']
+    return n * (4 * es + cfg['bits'] / 4), n * (2 * es + cfg['bits'] / 8)
+
+
+class Workload:
+    """`nsets` independent buffer sets (x, y, gy, gx, state) of one config with pre-resolved launches per set."""
+
+    def __init__(self, cfg, device, nsets=1, seed=0, host_seeded=True):
+        from fewbit_amd import cabi
+        dt = DTYPES[cfg['dtype']]
+        n = cfg['rows'] * cfg['cols']
+        self.cfg, self.n, self.nsets = cfg, n, nsets
+        self.fwd, self.bwd, self.keep = [], [], []
+        if cfg['kind'] == 'continuous':
+            borders, levels = load_tables(cfg, device)
+        for i in range(nsets):
+            if host_seeded:     # synthetic shard (SURVEY 8d): seeded on the host, then resident in HBM
+                g = torch.Generator().manual_seed(2 * seed + 1000 * i)
+                x = torch.randn(cfg['rows'], cfg['cols'], generator=g).to(dt).to(device)
+                g = torch.Generator().manual_seed(2 * seed + 1 + 1000 * i)
+                gy = torch.randn(cfg['rows'], cfg['cols'], generator=g).to(dt).to(device)
+            else:               # the extra measurements: same distribution, drawn on the device
+                g = torch.Generator(device=device).manual_seed(2 * seed + 1000 * i)
+                x = torch.randn(cfg['rows'], cfg['cols'], generator=g, device=device).to(dt)
+                gy = torch.randn(cfg['rows'], cfg['cols'], generator=g, device=device).to(dt)
+            y, gx = torch.empty_like(x), torch.empty_like(x)
+            state = torch.empty(cabi.state_nbytes(n, cfg['bits']), dtype=torch.uint8, device=device)
+            if cfg['kind'] == 'continuous':
+                self.fwd.append(cabi.bind_forward(cfg['fn'], x, borders, out=y, state=state))
+                self.bwd.append(cabi.bind_backward(gy, state, levels, out=gx))
+            else:
+                self.fwd.append(cabi.bind_stepwise1_forward(cfg['fn'], x, out=y, state=state))
+                self.bwd.append(cabi.bind_stepwise1_backward(cfg['fn'], gy, state, out=gx))
+            self.keep.append((x, y, gy, gx, state))
+        self.set_bytes = sum(t.numel() * t.element_size() for t in self.keep[0])
+
+    def steps(self):
+        """launch list of one rotation: fwd(set 0), bwd(set 0), fwd(set 1), ..."""
+        out = []
+        for f, b in zip(self.fwd, self.bwd):
+            out += [f, b]
+        return out
+
+
+def event_time_us(launches, rounds, preroll=1):
+    """Average GPU time of one pass over `launches`, between two events on the launch stream; the queue is filled by
+    `preroll` untimed passes first so the first timed launch does not wait for the host."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    for _ in range(preroll):
+        for f in launches:
+            f()
+    e0.record()
+    for _ in range(rounds):
+        for f in launches:
+            f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / rounds
+
+
+def nsets_for_cold(cfg):
+    """buffer sets so that a rotation touches > 1 GiB and > 4x the Infinity Cache between two uses of a set"""
+    es = torch.empty(0, dtype=DTYPES[cfg['dtype']]).element_size()
+    n = cfg['rows'] * cfg['cols']
+    per_set = n * (4 * es + cfg['bits'] / 8)
+    return max(3, int(max(1.25 * 2**30, 4.5 * INFINITY_CACHE_BYTES) / per_set) + 1)
+
+
+def measure_config(cfg, device, cold):
+    """us_fwd / us_bwd: K back-to-back launches of one kernel (rotating over the sets when cold); us_step: fwd+bwd
+    alternating, which is what the headline metric is defined on."""
+    nsets = nsets_for_cold(cfg) if cold else 1
+    w = Workload(cfg, device, nsets=nsets, seed=7, host_seeded=False)
+    total = max(200, 3 * nsets)                        # launches per measurement
+    rounds = max(1, total // nsets)
+    for f in w.steps():                                # touch everything once (first-use page mapping, table casts)
+        f()
+    us_fwd = event_time_us(w.fwd, rounds) / nsets
+    us_bwd = event_time_us(w.bwd, rounds) / nsets
+    us_step = event_time_us(w.steps(), rounds) / nsets
+    sb, _ = step_bytes(cfg)
+    out = {'us_fwd': round(us_fwd, 2), 'us_bwd': round(us_bwd, 2), 'us_step': round(us_step, 2),
+           'GiB_s': round(sb / (us_step * 1e-6) / 2**30, 1), 'frac': round(sb / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+           'buffer_sets': nsets, 'footprint_MiB': round(nsets * w.set_bytes / 2**20, 1)}
+    del w
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(cfg, threads=None):
     """Reference CPU path (oracle/_ref, kind 'reference') or, without it, the C restatement (kind 'port')."""
     tables = str(ROOT / 'fewbit_amd' / 'data' / 'builtin.npz')
     ref = ROOT / 'oracle' / '_ref' / 'libfewbit_ref.so'
-    n = ROWS * COLS
-    nbytes = n * (4 * 2 + BITS / 4)
+    rows, cols, bits, dname = cfg['rows'], cfg['cols'], cfg['bits'], cfg['dtype']
+    nbytes, _ = step_bytes(cfg)
     if ref.exists():
-        reps = 10
+        reps = 8 if threads == 1 else 20
         try:
-            out = subprocess.run([sys.executable, str(ROOT / 'oracle' / 'ref_bench.py'), str(ROWS), str(COLS), DTYPE_NAME,
-                                  str(BITS), str(reps), tables], capture_output=True, text=True, timeout=600, check=True)
+            cmd = [sys.executable, str(ROOT / 'oracle' / 'ref_bench.py'), str(rows), str(cols), dname, str(bits), str(reps), tables]
+            if threads:
+                cmd.append(str(threads))
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True)
             r = json.loads(out.stdout.strip().splitlines()[-1])
             return {'value': round(r['gib_per_s'], 4), 'unit': 'GiB/s', 'cores': r['threads'], 'kind': 'reference',
-                    'sample': f'{reps} x (quantize + quantize_backward) of the full {ROWS}x{COLS} {DTYPE_NAME} tensor, median; '
-                              f'reference fewbit/cpu path built with g++ against libtorch, {r["threads"]} intra-op threads '
-                              f'(pack/unpack loops are single-threaded in the reference)',
+                    'host_cpus': r['cores'],
+                    'sample': f'{reps} x (quantize + quantize_backward) of the full {rows}x{cols} {dname} tensor, median; '
+                              f'reference fewbit/cpu path built with g++ against libtorch, {r["threads"]} intra-op thread(s) '
+                              f'(the pack/unpack loops are single-threaded in the reference)',
                     'ms_per_step': round(r['seconds_per_step'] * 1e3, 2)}
         except Exception as e:  # noqa: BLE001
             sys.stderr.write(f'[bench] reference CPU baseline failed ({e}); falling back to the C port\n')
-    import oracle
-    borders, levels = load_tables('cpu')
+    import oracle  # the checker, timed as the CPU baseline only
+    dt = DTYPES[dname]
+    with np.load(tables) as z:
+        borders = torch.tensor(z[f"{cfg['fn']}{bits:02d}-borders"]).to(dt)[1:-1].contiguous()
+        levels = torch.tensor(z[f"{cfg['fn']}{bits:02d}-levels"]).to(dt)
     torch.manual_seed(0)
-    x = torch.randn(ROWS, COLS).to(DTYPE)
+    x = torch.randn(rows, cols).to(dt)
     torch.manual_seed(1)
-    gy = torch.randn(ROWS, COLS).to(DTYPE)
+    gy = torch.randn(rows, cols).to(dt)
     times = []
     for i in range(4):
         t0 = time.perf_counter()
-        _, state, _ = oracle.quantize('gelu', x, borders)
+        _, state, _ = oracle.quantize(cfg['fn'], x, borders)
         oracle.quantize_backward(gy, state, levels)
         t1 = time.perf_counter()
         if i:
             times.append(t1 - t0)
     best = float(np.median(times))
     return {'value': round(nbytes / best / 2**30, 4), 'unit': 'GiB/s', 'cores': 1, 'kind': 'port',
-            'sample': f'3 x (quantize + quantize_backward) of the full {ROWS}x{COLS} {DTYPE_NAME} tensor, median; '
+            'sample': f'3 x (quantize + quantize_backward) of the full {rows}x{cols} {dname} tensor, median; '
                       'oracle/fewbit_oracle.c, scalar, 1 thread', 'ms_per_step': round(best * 1e3, 2)}
 
 
@@ -84,7 +212,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--config', choices=('c2', 'c4'), default='c2', help='headline workload per GPU (see module docstring)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='timed region only (what the rocprofv3 passes run)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -109,26 +239,16 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from fewbit_amd import cabi   # raises if libfewbit_hip.so is missing: there is no fallback
+    from fewbit_amd.sharding import shard_range
     cabi.lib()
 
-    n = ROWS * COLS
-    borders, levels = load_tables(device)
-    # synthetic shard of this rank: seeded on the host, then resident in HBM
-    torch.manual_seed(2 * rank)
-    x = torch.randn(ROWS, COLS).to(DTYPE).to(device)
-    torch.manual_seed(2 * rank + 1)
-    gy = torch.randn(ROWS, COLS).to(DTYPE).to(device)
-    y = torch.empty_like(x)
-    gx = torch.empty_like(x)
-    state = torch.empty(cabi.state_nbytes(n, BITS), dtype=torch.uint8, device=device)
-
-    # pre-resolved launches: the loop below only pays ctypes + hipLaunchKernel per kernel
-    fwd = cabi.bind_forward('gelu', x, borders, out=y, state=state)
-    bwd = cabi.bind_backward(gy, state, levels, out=gx)
-
-    def step():
-        fwd()
-        bwd()
+    cfg = CONFIGS[args.config]
+    n = cfg['rows'] * cfg['cols']
+    # which elements of the (weak-scaled) global tensor this rank owns: documentation of the cut, the data is synthetic
+    begin, end = shard_range(n * world, world, rank)
+    assert end - begin == n
+    w = Workload(cfg, device, nsets=1, seed=rank)
+    fwd, bwd = w.fwd[0], w.bwd[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -137,89 +257,99 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
-    # ---- the timed region: exactly K steps, nothing but the two launches per step on the stream
+        fwd()
+        bwd()
+    # ---- the timed region.  barrier + synchronize; an untimed pre-roll keeps the GPU busy while the host runs ahead,
+    # so that the K timed steps execute from a filled queue (without it the first launch's host latency, ~5 us, is
+    # 1 % of a 20-step region); then exactly K steps between two events on the launch stream.  No collective and no
+    # host synchronisation inside.
+    preroll = min(8, max(args.warmup, 1))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
+    for _ in range(preroll):
+        fwd()
+        bwd()
+    e0.record()
     for _ in range(args.steps):
         fwd()
         bwd()
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = e0.elapsed_time(e1) * 1e-3                # seconds of GPU time for the K steps on this rank
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+        t = torch.tensor([elapsed, wall], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- per-kernel launch durations, HIP events on the launch stream.  Two views:
-    #  (a) K back-to-back launches of one kernel between two events -> average duration per launch in a saturated
-    #      queue (what roofline.achieved uses; rocprofv3's per-dispatch average in profiles/ is the cross-check);
-    #  (b) the K fwd/bwd steps again with an event between every launch -> includes the few us a barrier packet
-    #      plus an un-overlapped dispatch cost, reported as *_us_event_bracketed for reference only.
-    def back_to_back(launch):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(args.steps):
-            launch()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / args.steps
-
-    fwd_us, bwd_us = back_to_back(fwd), back_to_back(bwd)
-    nb = min(args.steps, 500)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(nb)]
-    torch.cuda.synchronize()
-    for i in range(nb):
-        ev[i][0].record()
-        fwd()
-        ev[i][1].record()
-        bwd()
-        ev[i][2].record()
-    torch.cuda.synchronize()
-    fwd_us_ev = float(np.median([e[0].elapsed_time(e[1]) for e in ev])) * 1e3
-    bwd_us_ev = float(np.median([e[1].elapsed_time(e[2]) for e in ev])) * 1e3
+        elapsed, wall = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
-        es = x.element_size()
-        step_bytes = n * (4 * es + BITS / 4)            # 146 800 640 B
-        fwd_bytes = n * (2 * es + BITS / 8)             # 73 400 320 B per forward launch
-        total = step_bytes * args.steps * world
+        sb, fb = step_bytes(cfg)
+        total = sb * args.steps * world
         value = total / elapsed / 2**30
-        # forward's duration inside the timed region: the measured step time split in the ratio of the two kernels'
-        # stand-alone (back-to-back) durations; agrees with rocprofv3's per-dispatch average of the same command
         step_us = elapsed / args.steps * 1e6
+        # per-kernel durations: K back-to-back launches of one kernel between two events (saturated queue)
+        reps = max(200, min(args.steps, 2000))
+        fwd_us, bwd_us = event_time_us([fwd], reps), event_time_us([bwd], reps)
+        # forward's duration inside the timed region: the measured step time split in the ratio of the two kernels'
+        # stand-alone durations; rocprofv3's per-dispatch average of the same command (profiles/) is the cross-check
         fwd_in_step_us = step_us * fwd_us / (fwd_us + bwd_us)
-        achieved = fwd_bytes / (fwd_in_step_us * 1e-6) / 1e9
-        traffic = None
+        achieved = fb / (fwd_in_step_us * 1e-6) / 1e9
+        traffic, traffic_source = None, None
         tf = ROOT / 'profiles' / 'traffic_forward.json'
-        if tf.exists():
+        if args.config == 'c2' and tf.exists():
             try:
-                traffic = json.loads(tf.read_text()).get('hbm_bytes_per_launch')
+                doc = json.loads(tf.read_text())
+                traffic = doc.get('hbm_bytes_per_launch')
+                traffic_source = (f"replayed from {doc.get('source', 'profiles/traffic_forward.json')}: rocprofv3 --pmc FETCH_SIZE / "
+                                  "WRITE_SIZE passes over `bench.py --no-extras` (tools/profile_round.sh), NOT measured in this run")
             except Exception:  # noqa: BLE001
                 traffic = None
+        kernel = 'quantize_forward_lut_kernel<gelu, bf16, 3 bits>'
         line = {
-            'metric': 'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4096x4096 bf16',
+            'metric': 'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4096x4096 bf16' if args.config == 'c2' else
+                      'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4x(16384x4096) bf16 sharded over 8 GPUs (per-GPU shard 8192x4096)',
             'value': round(value, 2), 'unit': 'GiB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'fewbit.gelu bits={BITS} on {ROWS}x{COLS} {DTYPE_NAME} per GPU, fused quantize+pack fwd / '
-                                   f'unpack+mul bwd via the C-ABI, inputs resident in HBM',
-                       'elements_per_gpu': n, 'bytes_per_step_per_gpu': int(step_bytes),
-                       'parallelism': f'{world} independent shard(s), no collectives'},
+            'config': {'workload': f"{cfg['label']} per GPU, fused quantize+pack fwd / unpack+mul bwd via the C-ABI, inputs resident in HBM",
+                       'name': args.config, 'elements_per_gpu': n, 'bytes_per_step_per_gpu': int(sb),
+                       'parallelism': f'{world} independent shard(s) of {n} elements, cut by sharding.shard_range, no collectives',
+                       'working_set_MiB_per_gpu': round(w.set_bytes / 2**20, 1),
+                       'cache_state': 'warm: one buffer set re-used every step; it fits the 256 MiB Infinity Cache (see `cold`)'
+                                      if w.set_bytes < INFINITY_CACHE_BYTES else 'one buffer set, larger than the 256 MiB Infinity Cache'},
+            'timing': {'method': 'two HIP events on the launch stream around exactly K steps, after barrier+synchronize and an '
+                                 f'untimed {preroll}-step pre-roll; max over ranks',
+                       'wall_ms_per_step': round(wall / (args.steps + preroll) * 1e3, 5),
+                       'wall_note': f'host perf_counter from the barrier to the final synchronize over K+{preroll} steps'},
             'pct_of_hbm_roofline': round(100.0 * (total / elapsed / 1e9) / (HBM_PEAK_GBS * world), 2),
             'fwd_us': round(fwd_us, 2), 'bwd_us': round(bwd_us, 2), 'fwd_in_step_us': round(fwd_in_step_us, 2),
-            'fwd_us_event_bracketed': round(fwd_us_ev, 2), 'bwd_us_event_bracketed': round(bwd_us_ev, 2),
-            'roofline': {'bound': 'hbm', 'kernel': 'quantize_forward_lut_kernel<gelu, bf16, 3 bits>', 'achieved': round(achieved, 1),
+            'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': traffic, 'algorithmic_bytes_per_launch': int(fwd_bytes),
+                         'traffic': traffic, 'traffic_source': traffic_source, 'algorithmic_bytes_per_launch': int(fb),
                          'avg_launch_us': round(fwd_in_step_us, 2),
-                         'avg_launch_us_method': 'timed-region step time x fwd/(fwd+bwd) of the back-to-back per-kernel '
-                                                 'HIP-event timings (fwd_us, bwd_us)'},
+                         'avg_launch_us_method': 'timed-region step time (HIP events) x fwd/(fwd+bwd) of the back-to-back '
+                                                 'per-kernel HIP-event timings (fwd_us, bwd_us)',
+                         'cache_state': 'warm (x and gy are served from the Infinity Cache; writes go to HBM)'},
         }
+        if world == 1 and not args.no_extras:
+            cold = measure_config(cfg, device, cold=True)
+            line['cold'] = dict(cold, note='same workload, rotating through independent buffer sets so nothing is re-used '
+                                           'from L2 / Infinity Cache; frac = fwd+bwd algorithmic bytes / us_step / 8 TB/s')
+            line['roofline']['frac_cold'] = round(fb / (cold['us_fwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            line['roofline']['avg_launch_us_cold'] = cold['us_fwd']
+            others = {}
+            for name, c in CONFIGS.items():
+                if name == args.config:
+                    continue
+                others[name] = {'workload': c['label'], 'bytes_per_step': int(step_bytes(c)[0]),
+                                'warm': measure_config(c, device, cold=False), 'cold': measure_config(c, device, cold=True)}
+            line['configs'] = others
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            line['cpu_baseline'] = cpu_baseline(cfg)
+            line['cpu_baseline_1thread'] = cpu_baseline(cfg, threads=1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -12,7 +12,8 @@ import torch
 
 __all__ = [
     'CONTINUOUS', 'STEPWISE1', 'LIB_PATH', 'lib', 'loaded', 'bitwidth', 'state_nbytes', 'quantize_forward',
-    'quantize_backward', 'bind_forward', 'bind_backward', 'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError',
+    'quantize_backward', 'bind_forward', 'bind_backward', 'bind_stepwise1_forward', 'bind_stepwise1_backward',
+    'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError',
 ]
 
 import os
@@ -169,6 +170,40 @@ def bind_backward(gy: torch.Tensor, state: torch.Tensor, levels: torch.Tensor, o
         if f(*args):
             _check(-1)
     launch.keepalive = (gy, state, levels, out)
+    return launch
+
+
+def bind_stepwise1_forward(fn: str, x: torch.Tensor, out: torch.Tensor, state: torch.Tensor, p0: float = 0.0,
+                           p1: float = 0.0, stream: Optional[int] = None):
+    """Pre-resolved launch of a 1-bit forward, see bind_forward."""
+    x, out, state = _dev(x, 'x'), _dev(out, 'out'), _dev(state, 'state')
+    if out.dtype != x.dtype or out.numel() != x.numel() or state.numel() < state_nbytes(x.numel(), 1):
+        raise FewbitHipError('out/state buffers do not match the input')
+    f = lib().fewbit_hip_stepwise1_forward
+    args = (STEPWISE1.index(fn), DTYPES[x.dtype], x.data_ptr(), out.data_ptr(), state.data_ptr(), x.numel(), p0, p1,
+            _stream(stream))
+
+    def launch():
+        if f(*args):
+            _check(-1)
+    launch.keepalive = (x, out, state)
+    return launch
+
+
+def bind_stepwise1_backward(fn: str, gy: torch.Tensor, state: torch.Tensor, out: torch.Tensor, p0: float = 0.0,
+                            stream: Optional[int] = None):
+    """Pre-resolved launch of a 1-bit backward, see bind_forward."""
+    gy, state, out = _dev(gy, 'gy'), _dev(state, 'state'), _dev(out, 'out')
+    if out.dtype != gy.dtype or out.numel() != gy.numel() or state.numel() < state_nbytes(gy.numel(), 1):
+        raise FewbitHipError('out/state buffers do not match the gradient')
+    f = lib().fewbit_hip_stepwise1_backward
+    args = (STEPWISE1.index(fn), DTYPES[gy.dtype], gy.data_ptr(), state.data_ptr(), out.data_ptr(), gy.numel(), p0,
+            _stream(stream))
+
+    def launch():
+        if f(*args):
+            _check(-1)
+    launch.keepalive = (gy, state, out)
     return launch
 
 

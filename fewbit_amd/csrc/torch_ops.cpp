@@ -11,9 +11,22 @@
 // Differences, all deliberate: bit width is ceil(log2(#levels)) (defect 1 not reproduced),
 // kernels run on the current stream and launch errors surface as exceptions (defect 9), fp16/bf16 are
 // accepted besides fp32, inputs are checked (contiguity, device, dtype) instead of silently mis-indexed.
-// There is no CPU implementation behind these ops: a CPU tensor raises from the dispatcher.
+//
+// Dispatch keys:
+//   AutogradCUDA  all activations: autograd Function around the gfx950 kernels (as the reference)
+//   CUDA          the same launches without an autograd node (torch.inference_mode(), where the Autograd keys are
+//                 excluded); quantize / quantize_backward
+//   AutogradCPU   host tensors: this file's own ATen-level implementation with the same PACKED state (section "host
+//                 tensors" below).  The reference registers `gelu` only, as an autograd Function under the CPU key
+//                 (fewbit/cpu/gelu.cc:47-76), plus quantize / quantize_backward (fewbit/fewbit.cc:6-7); here every
+//                 operator has one.  Product code; it never touches oracle/.
+//   CPU           the same without an autograd node (plain activation), quantize / quantize_backward
+#include <ATen/OpMathType.h>
+#include <ATen/Parallel.h>
 #include <torch/library.h>
 #include <torch/torch.h>
+
+#include <cmath>
 
 // ROCm builds of PyTorch expose HIP devices as device type `cuda`; these are the matching guard / stream types
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
@@ -157,42 +170,273 @@ struct Stepwise1Function : public torch::autograd::Function<Stepwise1Function> {
     }
 };
 
-Tensor continuous(int fn, const Tensor &self, const Tensor &bounds, const Tensor &levels, double p0 = 0.0, double p1 = 0.0) {
-    return ContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, /*inplace=*/true);
+// ---- host tensors (CPU dispatch key) ---------------------------------------------------------------
+// Own ATen-level implementation of the same path for host tensors, with the same PACKED state as the kernels (k
+// bytes per group of 8 elements, k*ceil(n/8) bytes, padding codes zero) -- so a state produced on the host can be
+// moved to the GPU and consumed there, and the reverse.  Structure after fewbit/cpu/gelu.cc:7-65 (activation by
+// ATen, codes by torch::searchsorted -- NaN -> last code --, pack, {state, levels} saved, unpack + gather + multiply in
+// backward); the pack/unpack loops are this file's own (per group, parallel over groups) instead of the reference's
+// serial bit-stream walk (fewbit/cpu/codec.h:33-83), with identical bytes.
+
+int bitwidth_of(int64_t nlevels) { return fewbit_hip_bitwidth(static_cast<int>(nlevels)); }
+
+// int32 codes (one per element) -> packed state
+Tensor host_pack(const Tensor &codes, int nbits) {
+    const int64_t n = codes.numel(), groups = (n + 7) / 8;
+    Tensor state = torch::empty({static_cast<int64_t>(nbits) * groups}, torch::TensorOptions().dtype(torch::kUInt8));
+    const int32_t *c = codes.data_ptr<int32_t>();
+    uint8_t *out = state.data_ptr<uint8_t>();
+    const uint64_t mask = (1ull << nbits) - 1ull;
+    at::parallel_for(0, groups, 2048, [&](int64_t g0, int64_t g1) {
+        for (int64_t g = g0; g < g1; ++g) {
+            const int64_t e0 = g * 8, m = std::min<int64_t>(8, n - e0);
+            uint64_t w = 0;
+            for (int64_t i = 0; i < m; ++i) w |= (static_cast<uint64_t>(static_cast<uint32_t>(c[e0 + i])) & mask) << (nbits * i);
+            for (int j = 0; j < nbits; ++j) out[nbits * g + j] = static_cast<uint8_t>(w >> (8 * j));
+        }
+    });
+    return state;
 }
 
-Tensor stepwise1(int fn, const Tensor &self, double p0 = 0.0, double p1 = 0.0) {
-    return Stepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, /*inplace=*/true);
+// gx[i] = table[code_i] * gy[i]: product in the op-math type (fp32 for 16-bit tensors), rounded once to nearest even
+// (`pair`: the two fp32 multipliers of the 1-bit family instead of a level table in the tensor dtype)
+Tensor host_unpack_mul(const Tensor &grad, const Tensor &state, const Tensor &table, int nbits, const float *pair = nullptr) {
+    const Tensor gy = grad.contiguous();
+    TORCH_CHECK(state.device().is_cpu() && state.scalar_type() == torch::kUInt8 && state.is_contiguous(),
+                "fewbit: state must be a contiguous uint8 host tensor");
+    const int64_t n = gy.numel(), groups = (n + 7) / 8;
+    TORCH_CHECK(state.numel() >= (static_cast<int64_t>(nbits) * n + 7) / 8, "fewbit: state buffer too small for ", n,
+                " elements at ", nbits, " bits");
+    const int64_t nstate = state.numel();
+    Tensor gx = torch::empty_like(gy);
+    const uint8_t *in = state.data_ptr<uint8_t>();
+    const uint64_t mask = (1ull << nbits) - 1ull;
+    AT_DISPATCH_FLOATING_TYPES_AND2(torch::kHalf, torch::kBFloat16, gy.scalar_type(), "fewbit_host_backward", [&] {
+        using acc_t = at::opmath_type<scalar_t>;
+        const scalar_t *g = gy.data_ptr<scalar_t>(), *lv = pair ? nullptr : table.data_ptr<scalar_t>();
+        scalar_t *o = gx.data_ptr<scalar_t>();
+        at::parallel_for(0, groups, 2048, [&](int64_t g0, int64_t g1) {
+            for (int64_t gr = g0; gr < g1; ++gr) {
+                uint64_t w = 0;
+                for (int j = 0; j < nbits; ++j)     // (a reference-sized state, ceil(k*n/8) bytes, ends inside the last group)
+                    if (nbits * gr + j < nstate) w |= static_cast<uint64_t>(in[nbits * gr + j]) << (8 * j);
+                const int64_t e0 = gr * 8, m = std::min<int64_t>(8, n - e0);
+                for (int64_t i = 0; i < m; ++i) {
+                    const auto code = (w >> (nbits * i)) & mask;
+                    const acc_t level = pair ? static_cast<acc_t>(pair[code]) : static_cast<acc_t>(lv[code]);
+                    o[e0 + i] = static_cast<scalar_t>(level * static_cast<acc_t>(g[e0 + i]));
+                }
+            }
+        });
+    });
+    return gx;
+}
+
+// the plain ATen activation behind each continuous id (what the reference's fallback meant to call,
+// fewbit/functional/activations.py:107,253-261; for gelu what its native CPU op calls, fewbit/cpu/gelu.cc:12-16)
+Tensor host_activation(int fn, const Tensor &x, double p0, double p1) {
+    switch (fn) {
+    case FEWBIT_CELU: return torch::celu(x, p0);
+    case FEWBIT_ELU: return torch::elu(x, p0);
+    case FEWBIT_GELU: return torch::gelu(x);
+    case FEWBIT_HARDSWISH: return torch::hardswish(x);
+    case FEWBIT_LOGSIGMOID: return torch::log_sigmoid(x);
+    case FEWBIT_MISH: return torch::mish(x);
+    case FEWBIT_SELU: return torch::selu(x);
+    case FEWBIT_SIGMOID: return torch::sigmoid(x);
+    case FEWBIT_SILU: return torch::silu(x);
+    case FEWBIT_SOFTPLUS: return torch::softplus(x, p0, p1);
+    case FEWBIT_SOFTSIGN: return x / (x.abs() + 1);
+    case FEWBIT_TANH: return torch::tanh(x);
+    case FEWBIT_TANHSHRINK: return x - torch::tanh(x);
+    default: return x.clone();    // FEWBIT_IDENTITY, FEWBIT_IDENTITY_FOLD
+    }
+}
+
+void check_host_table(const Tensor &self, const Tensor &table, const char *name) {
+    TORCH_CHECK(table.dim() == 1, "fewbit: `", name, "` must be one-dimensional");
+    TORCH_CHECK(table.device().is_cpu(), "fewbit: `", name, "` lives on ", table.device(), ", input on ", self.device());
+    TORCH_CHECK(table.scalar_type() == self.scalar_type(), "fewbit: `", name, "` has dtype ", table.scalar_type(),
+                ", input ", self.scalar_type());
+}
+
+// y = fn(self) into `out` (may be `self`); returns the packed state
+Tensor host_quantize(int fn, const Tensor &self, Tensor &out, const Tensor &bounds, double p0, double p1) {
+    TORCH_CHECK(self.is_contiguous(), "fewbit: `self` must be contiguous");
+    TORCH_CHECK(self.is_floating_point(), "fewbit: unsupported dtype ", self.scalar_type());
+    check_host_table(self, bounds, "bounds");
+    const Tensor b = bounds.contiguous();
+    TORCH_CHECK(b.numel() >= 1 && b.numel() <= 255, "fewbit: number of borders must be in [1, 255], got ", b.numel());
+    const int nbits = bitwidth_of(b.numel() + 1);
+    const Tensor flat = self.reshape({-1});
+    // the even-parity fold of a custom table searches the fp32 distance |x - shift_x| (see stepwise_folded)
+    const Tensor codes = fn == FEWBIT_IDENTITY_FOLD
+                             ? torch::searchsorted(b.to(torch::kFloat), flat.to(torch::kFloat).sub(p0).abs(), /*out_int32=*/true)
+                             : torch::searchsorted(b, flat, /*out_int32=*/true);
+    Tensor state = host_pack(codes, nbits);
+    const Tensor y = host_activation(fn, self, p0, p1);      // before `self` may be overwritten below
+    if (out.is_same(self)) out.copy_(y);
+    else out = y;
+    return state;
+}
+
+struct HostContinuousFunction : public torch::autograd::Function<HostContinuousFunction> {
+    static Tensor forward(AutogradContext *ctx, Tensor self, const Tensor &bounds, const Tensor &levels, int64_t fn,
+                          double p0, double p1, bool inplace) {
+        TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
+                    "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(),
+                    " and ", levels.numel());
+        check_host_table(self, levels, "levels");
+        Tensor out = inplace ? self : Tensor();
+        Tensor state = host_quantize(static_cast<int>(fn), self, out, bounds, p0, p1);
+        if (inplace) ctx->mark_dirty({self});
+        ctx->save_for_backward({state, levels});
+        return out;
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grad_output) {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor lv = saved[1].contiguous();
+        return {host_unpack_mul(grad_output[0], saved[0], lv, bitwidth_of(lv.numel())), Tensor(), Tensor(), Tensor(),
+                Tensor(), Tensor(), Tensor()};
+    }
+};
+
+// 1-bit family on the host: values by ATen, the derivative-branch bit by the same rules as the kernels
+// (Step1<> in fewbit_device.h; fewbit/cuda/codec.cu:298-487)
+Tensor host_step1_activation(int fn, const Tensor &x, double p0, double p1) {
+    switch (fn) {
+    case FEWBIT_HARDSHRINK: return torch::hardshrink(x, p0);
+    case FEWBIT_HARDSIGMOID: return torch::hardsigmoid(x);
+    case FEWBIT_HARDTANH: return torch::hardtanh(x, p0, p1);
+    case FEWBIT_LEAKY_RELU: return torch::leaky_relu(x, p0);
+    case FEWBIT_RELU: return torch::relu(x);
+    case FEWBIT_RELU6: return torch::relu6(x);
+    case FEWBIT_SOFTSHRINK: return torch::softshrink(x, p0);
+    default: return torch::threshold(x, p0, p1);
+    }
+}
+
+Tensor host_step1_bits(int fn, const Tensor &x, double p0, double p1) {
+    const Tensor v = x.reshape({-1}).to(torch::kFloat);
+    const float a = static_cast<float>(p0), b = static_cast<float>(p1);
+    Tensor bit;
+    switch (fn) {
+    case FEWBIT_HARDSHRINK: bit = (v < -a).logical_or(v > a); break;
+    case FEWBIT_HARDSIGMOID: bit = (v <= -3.0f).logical_or(v >= 3.0f).logical_not(); break;
+    case FEWBIT_HARDTANH: bit = (v <= a).logical_or(v >= b).logical_not(); break;
+    case FEWBIT_LEAKY_RELU: bit = (v >= 0.0f).logical_not(); break;
+    case FEWBIT_RELU: bit = (v <= 0.0f).logical_not(); break;
+    case FEWBIT_RELU6: bit = (v <= 0.0f).logical_or(v >= 6.0f).logical_not(); break;
+    case FEWBIT_SOFTSHRINK: bit = (v < -a).logical_or(v > a); break;
+    default: bit = (v <= a).logical_not(); break;
+    }
+    return bit.to(torch::kInt32);
+}
+
+struct HostStepwise1Function : public torch::autograd::Function<HostStepwise1Function> {
+    static Tensor forward(AutogradContext *ctx, Tensor self, int64_t fn, double p0, double p1, bool inplace) {
+        TORCH_CHECK(self.is_contiguous(), "fewbit: `self` must be contiguous");
+        TORCH_CHECK(self.is_floating_point(), "fewbit: unsupported dtype ", self.scalar_type());
+        Tensor state = host_pack(host_step1_bits(static_cast<int>(fn), self, p0, p1), 1);
+        Tensor y = host_step1_activation(static_cast<int>(fn), self, p0, p1);
+        if (inplace) {
+            self.copy_(y);
+            ctx->mark_dirty({self});
+            y = self;
+        }
+        ctx->save_for_backward({state});
+        ctx->saved_data["fn"] = fn;
+        ctx->saved_data["p0"] = p0;
+        return y;
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grad_output) {
+        const auto saved = ctx->get_saved_variables();
+        const auto fn = ctx->saved_data["fn"].toInt();
+        const auto p0 = ctx->saved_data["p0"].toDouble();
+        float pair[2] = {0.0f, 1.0f};       // as fewbit_hip_stepwise1_backward: (m0, m1) in fp32
+        if (fn == FEWBIT_HARDSIGMOID) pair[1] = 1.0f / 6.0f;
+        if (fn == FEWBIT_LEAKY_RELU) { pair[0] = 1.0f; pair[1] = static_cast<float>(p0); }
+        return {host_unpack_mul(grad_output[0], saved[0], Tensor(), 1, pair), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+// ---- the three flavours every operator is registered in --------------------------------------------
+enum class Where { AutogradGpu, RawGpu, AutogradHost, RawHost };
+
+template <Where W>
+Tensor continuous(int fn, const Tensor &self, const Tensor &bounds, const Tensor &levels, double p0 = 0.0, double p1 = 0.0,
+                  bool inplace = true) {
+    if constexpr (W == Where::AutogradGpu) {
+        return ContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, inplace);
+    } else if constexpr (W == Where::AutogradHost) {
+        return HostContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, inplace);
+    } else if constexpr (W == Where::RawHost) {     // no autograd node: nothing to save, plain activation
+        TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
+                    "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(), " and ",
+                    levels.numel());
+        const Tensor y = host_activation(fn, self, p0, p1);
+        return inplace ? self.copy_(y) : y;
+    } else {
+        // no autograd node (inference_mode): same kernel, the packed state goes to a scratch buffer and is dropped
+        TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
+                    "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(), " and ",
+                    levels.numel());
+        Tensor out = inplace ? self : torch::empty_like(self);
+        launch_quantize(fn, self, out, bounds, p0, p1);
+        return out;
+    }
+}
+
+template <Where W> Tensor stepwise1(int fn, const Tensor &self, double p0 = 0.0, double p1 = 0.0, bool inplace = true) {
+    if constexpr (W == Where::AutogradGpu) {
+        return Stepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, inplace);
+    } else if constexpr (W == Where::AutogradHost) {
+        return HostStepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, inplace);
+    } else if constexpr (W == Where::RawHost) {
+        const Tensor y = host_step1_activation(fn, self, p0, p1);
+        return inplace ? self.copy_(y) : y;
+    } else {
+        check_input(self, "self");
+        Tensor out = inplace ? self : torch::empty_like(self);
+        Tensor state = new_state(self, self.numel(), 1);
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(self.device());
+        check_status(fewbit_hip_stepwise1_forward(fn, dtype_code(self), self.data_ptr(), out.data_ptr(), state.data_ptr<uint8_t>(),
+                                                  static_cast<size_t>(self.numel()), p0, p1, current_stream(self)),
+                     "stepwise1_forward");
+        return out;
+    }
 }
 
 }  // namespace
 
-// ---- op implementations (names follow the schema list below) ------------------------------------
+// ---- op implementations (names follow the schema list below), one instantiation per dispatch key ----
 
-Tensor hardshrink(const Tensor &self, double lambd) { return stepwise1(FEWBIT_HARDSHRINK, self, lambd); }
-Tensor hardsigmoid(const Tensor &self) { return stepwise1(FEWBIT_HARDSIGMOID, self); }
-Tensor hardtanh(const Tensor &self, double min_val, double max_val) { return stepwise1(FEWBIT_HARDTANH, self, min_val, max_val); }
-Tensor leaky_relu(const Tensor &self, double negative_slope) { return stepwise1(FEWBIT_LEAKY_RELU, self, negative_slope); }
-Tensor relu(const Tensor &self) { return stepwise1(FEWBIT_RELU, self); }
-Tensor relu6(const Tensor &self) { return stepwise1(FEWBIT_RELU6, self); }
-Tensor softshrink(const Tensor &self, double lambd) { return stepwise1(FEWBIT_SOFTSHRINK, self, lambd); }
-Tensor threshold(const Tensor &self, double threshold, double value) { return stepwise1(FEWBIT_THRESHOLD, self, threshold, value); }
+template <Where W> Tensor hardshrink(const Tensor &self, double lambd) { return stepwise1<W>(FEWBIT_HARDSHRINK, self, lambd); }
+template <Where W> Tensor hardsigmoid(const Tensor &self) { return stepwise1<W>(FEWBIT_HARDSIGMOID, self); }
+template <Where W> Tensor hardtanh(const Tensor &self, double min_val, double max_val) { return stepwise1<W>(FEWBIT_HARDTANH, self, min_val, max_val); }
+template <Where W> Tensor leaky_relu(const Tensor &self, double negative_slope) { return stepwise1<W>(FEWBIT_LEAKY_RELU, self, negative_slope); }
+template <Where W> Tensor relu(const Tensor &self) { return stepwise1<W>(FEWBIT_RELU, self); }
+template <Where W> Tensor relu6(const Tensor &self) { return stepwise1<W>(FEWBIT_RELU6, self); }
+template <Where W> Tensor softshrink(const Tensor &self, double lambd) { return stepwise1<W>(FEWBIT_SOFTSHRINK, self, lambd); }
+template <Where W> Tensor threshold(const Tensor &self, double threshold, double value) { return stepwise1<W>(FEWBIT_THRESHOLD, self, threshold, value); }
 
-Tensor celu(const Tensor &self, const Tensor &b, const Tensor &l, double alpha) { return continuous(FEWBIT_CELU, self, b, l, alpha); }
-Tensor elu(const Tensor &self, const Tensor &b, const Tensor &l, double alpha) { return continuous(FEWBIT_ELU, self, b, l, alpha); }
-Tensor gelu(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_GELU, self, b, l); }
-Tensor hardswish(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_HARDSWISH, self, b, l); }
-Tensor logsigmoid(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_LOGSIGMOID, self, b, l); }
-Tensor mish(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_MISH, self, b, l); }
-Tensor selu(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_SELU, self, b, l); }
-Tensor sigmoid(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_SIGMOID, self, b, l); }
-Tensor silu(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_SILU, self, b, l); }
-Tensor softplus(const Tensor &self, const Tensor &b, const Tensor &l, double beta, double threshold) {
-    return continuous(FEWBIT_SOFTPLUS, self, b, l, beta, threshold);
+template <Where W> Tensor celu(const Tensor &self, const Tensor &b, const Tensor &l, double alpha) { return continuous<W>(FEWBIT_CELU, self, b, l, alpha); }
+template <Where W> Tensor elu(const Tensor &self, const Tensor &b, const Tensor &l, double alpha) { return continuous<W>(FEWBIT_ELU, self, b, l, alpha); }
+template <Where W> Tensor gelu(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous<W>(FEWBIT_GELU, self, b, l); }
+template <Where W> Tensor hardswish(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous<W>(FEWBIT_HARDSWISH, self, b, l); }
+template <Where W> Tensor logsigmoid(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous<W>(FEWBIT_LOGSIGMOID, self, b, l); }
+template <Where W> Tensor mish(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous<W>(FEWBIT_MISH, self, b, l); }
+template <Where W> Tensor selu(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous<W>(FEWBIT_SELU, self, b, l); }
+template <Where W> Tensor sigmoid(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous<W>(FEWBIT_SIGMOID, self, b, l); }
+template <Where W> Tensor silu(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous<W>(FEWBIT_SILU, self, b, l); }
+template <Where W> Tensor softplus(const Tensor &self, const Tensor &b, const Tensor &l, double beta, double threshold) {
+    return continuous<W>(FEWBIT_SOFTPLUS, self, b, l, beta, threshold);
 }
-Tensor softsign(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_SOFTSIGN, self, b, l); }
-Tensor tanh(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_TANH, self, b, l); }
-Tensor tanhshrink(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous(FEWBIT_TANHSHRINK, self, b, l); }
+template <Where W> Tensor softsign(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous<W>(FEWBIT_SOFTSIGN, self, b, l); }
+template <Where W> Tensor tanh(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous<W>(FEWBIT_TANH, self, b, l); }
+template <Where W> Tensor tanhshrink(const Tensor &self, const Tensor &b, const Tensor &l) { return continuous<W>(FEWBIT_TANHSHRINK, self, b, l); }
 
 // Custom table on the identity.  The reference declares this schema without any kernel (fewbit/fewbit.cc:37,
 // NotImplementedError in fewbit/functional/activations.py:137-139; module fewbit/modules/activations.py:97-134:
@@ -204,9 +448,10 @@ Tensor tanhshrink(const Tensor &self, const Tensor &b, const Tensor &l) { return
 //   odd   g(sx+t)-sy = -(g(sx-t)-sy):   equal to the plain table  borders {sx-b'} u {sx} u {sx+b'},
 //                                        levels {2sy-l'} u {l'}  -- mirrored here (fp32, rounded once to the tensor
 //                                        dtype) and run through the plain kernels; the sign costs the one extra bit
+template <Where W>
 Tensor stepwise_folded_impl(const Tensor &self, const Tensor &b, const Tensor &l, bool even, double sx, double sy,
                             bool inplace) {
-    if (even) return ContinuousFunction::apply(self, b, l, FEWBIT_IDENTITY_FOLD, sx, 0.0, inplace);
+    if (even) return continuous<W>(FEWBIT_IDENTITY_FOLD, self, b, l, sx, 0.0, inplace);
     TORCH_CHECK(b.dim() == 1 && l.dim() == 1, "fewbit: `bounds` and `levels` must be one-dimensional");
     TORCH_CHECK(b.numel() + 1 == l.numel(), "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ",
                 b.numel(), " and ", l.numel());
@@ -215,44 +460,45 @@ Tensor stepwise_folded_impl(const Tensor &self, const Tensor &b, const Tensor &l
     const Tensor centre = torch::full({1}, sx, bf.options());
     const Tensor full_b = torch::cat({torch::rsub(bf.flip(0), sx), centre, bf.add(sx)}).to(self.scalar_type());
     const Tensor full_l = torch::cat({torch::rsub(lf.flip(0), 2.0 * sy), lf}).to(self.scalar_type());
-    return ContinuousFunction::apply(self, full_b, full_l, FEWBIT_IDENTITY, 0.0, 0.0, inplace);
+    return continuous<W>(FEWBIT_IDENTITY, self, full_b, full_l, 0.0, 0.0, inplace);
 }
 
-Tensor stepwise_folded(const Tensor &self, const Tensor &b, const Tensor &l, bool even, double sx, double sy) {
-    return stepwise_folded_impl(self, b, l, even, sx, sy, /*inplace=*/true);
+template <Where W> Tensor stepwise_folded(const Tensor &self, const Tensor &b, const Tensor &l, bool even, double sx, double sy) {
+    return stepwise_folded_impl<W>(self, b, l, even, sx, sy, /*inplace=*/true);
 }
 
-Tensor stepwise_folded_out(const Tensor &self, const Tensor &b, const Tensor &l, bool even, double sx, double sy) {
-    return stepwise_folded_impl(self, b, l, even, sx, sy, /*inplace=*/false);
+template <Where W> Tensor stepwise_folded_out(const Tensor &self, const Tensor &b, const Tensor &l, bool even, double sx, double sy) {
+    return stepwise_folded_impl<W>(self, b, l, even, sx, sy, /*inplace=*/false);
 }
 
 // the reference's schema: integer shift only (fewbit/fewbit.cc:37); `stepwise_folded` takes real shifts
+template <Where W>
 Tensor stepwise(const Tensor &self, const Tensor &b, const Tensor &l, std::optional<bool> parity,
                 c10::OptionalArrayRef<int64_t> shift) {
     if (!parity.has_value()) {
         TORCH_CHECK(!shift.has_value(), "fewbit: stepwise `shift` needs a `parity`");
-        return continuous(FEWBIT_IDENTITY, self, b, l);
+        return continuous<W>(FEWBIT_IDENTITY, self, b, l);
     }
     double sx = 0.0, sy = 0.0;
     if (shift.has_value()) {
         sx = static_cast<double>((*shift)[0]);
         sy = static_cast<double>((*shift)[1]);
     }
-    return stepwise_folded_impl(self, b, l, *parity, sx, sy, /*inplace=*/true);
+    return stepwise_folded_impl<W>(self, b, l, *parity, sx, sy, /*inplace=*/true);
 }
 
 // Out-of-place variants (additions, not in the reference): same kernels writing to a fresh tensor.  The python layer
 // uses them when the input is a VIEW (e.g. the 3-D output of nn.Linear): an in-place op on a view makes autograd
 // rebase the view's history (CopySlices), whose backward costs a zero-fill and four full-size copies per call --
 // seen as +5 % step time on RoBERTa-base before this path existed.
-Tensor continuous_out(const Tensor &self, const Tensor &b, const Tensor &l, int64_t fn, double p0, double p1) {
+template <Where W> Tensor continuous_out(const Tensor &self, const Tensor &b, const Tensor &l, int64_t fn, double p0, double p1) {
     TORCH_CHECK(fn >= 0 && fn < FEWBIT_CONTINUOUS_COUNT, "fewbit: unknown continuous function id ", fn);
-    return ContinuousFunction::apply(self, b, l, fn, p0, p1, /*inplace=*/false);
+    return continuous<W>(static_cast<int>(fn), self, b, l, p0, p1, /*inplace=*/false);
 }
 
-Tensor stepwise1_out(const Tensor &self, int64_t fn, double p0, double p1) {
+template <Where W> Tensor stepwise1_out(const Tensor &self, int64_t fn, double p0, double p1) {
     TORCH_CHECK(fn >= 0 && fn < FEWBIT_STEPWISE_COUNT, "fewbit: unknown stepwise function id ", fn);
-    return Stepwise1Function::apply(self, fn, p0, p1, /*inplace=*/false);
+    return stepwise1<W>(static_cast<int>(fn), self, p0, p1, /*inplace=*/false);
 }
 
 // raw pieces, fewbit/cpu/gelu.cc:7-45: quantize(x, bounds) -> (gelu(x), state); out of place like the reference
@@ -265,6 +511,52 @@ std::tuple<Tensor, Tensor> quantize(const Tensor &inputs, const Tensor &bounds) 
 
 Tensor quantize_backward(const Tensor &grads, const Tensor &buffer, const Tensor &levels) {
     return launch_dequantize(grads, buffer, levels);
+}
+
+// ... and for host tensors (the reference's own home for these two, fewbit/fewbit.cc:6-7)
+std::tuple<Tensor, Tensor> quantize_host(const Tensor &inputs, const Tensor &bounds) {
+    const Tensor x = inputs.contiguous();
+    Tensor outputs;
+    Tensor state = host_quantize(FEWBIT_GELU, x, outputs, bounds, 0.0, 0.0);
+    return std::make_tuple(outputs, state);
+}
+
+Tensor quantize_backward_host(const Tensor &grads, const Tensor &buffer, const Tensor &levels) {
+    check_host_table(grads, levels, "levels");
+    const Tensor lv = levels.contiguous();
+    TORCH_CHECK(lv.numel() >= 2 && lv.numel() <= 256, "fewbit: number of levels must be in [2, 256], got ", lv.numel());
+    return host_unpack_mul(grads, buffer, lv, bitwidth_of(lv.numel()));
+}
+
+template <Where W> void register_activations(torch::Library &m) {
+    m.impl("hardshrink", &hardshrink<W>);
+    m.impl("hardsigmoid", &hardsigmoid<W>);
+    m.impl("hardtanh", &hardtanh<W>);
+    m.impl("leaky_relu", &leaky_relu<W>);
+    m.impl("relu", &relu<W>);
+    m.impl("relu6", &relu6<W>);
+    m.impl("softshrink", &softshrink<W>);
+    m.impl("threshold", &threshold<W>);
+
+    m.impl("celu", &celu<W>);
+    m.impl("elu", &elu<W>);
+    m.impl("gelu", &gelu<W>);
+    m.impl("hardswish", &hardswish<W>);
+    m.impl("logsigmoid", &logsigmoid<W>);
+    m.impl("mish", &mish<W>);
+    m.impl("selu", &selu<W>);
+    m.impl("sigmoid", &sigmoid<W>);
+    m.impl("silu", &silu<W>);
+    m.impl("softplus", &softplus<W>);
+    m.impl("softsign", &softsign<W>);
+    m.impl("tanh", &tanh<W>);
+    m.impl("tanhshrink", &tanhshrink<W>);
+
+    m.impl("stepwise", &stepwise<W>);
+    m.impl("stepwise_folded", &stepwise_folded<W>);
+    m.impl("stepwise_folded_out", &stepwise_folded_out<W>);
+    m.impl("continuous_out", &continuous_out<W>);
+    m.impl("stepwise1_out", &stepwise1_out<W>);
 }
 
 }  // namespace fewbit_amd
@@ -305,38 +597,18 @@ TORCH_LIBRARY(fewbit, m) {
     m.def("stepwise1_out(Tensor self, int fn, float p0 = 0.0, float p1 = 0.0) -> Tensor");
 }
 
-TORCH_LIBRARY_IMPL(fewbit, AutogradCUDA, m) {
-    m.impl("hardshrink", fewbit_amd::hardshrink);
-    m.impl("hardsigmoid", fewbit_amd::hardsigmoid);
-    m.impl("hardtanh", fewbit_amd::hardtanh);
-    m.impl("leaky_relu", fewbit_amd::leaky_relu);
-    m.impl("relu", fewbit_amd::relu);
-    m.impl("relu6", fewbit_amd::relu6);
-    m.impl("softshrink", fewbit_amd::softshrink);
-    m.impl("threshold", fewbit_amd::threshold);
-
-    m.impl("celu", fewbit_amd::celu);
-    m.impl("elu", fewbit_amd::elu);
-    m.impl("gelu", fewbit_amd::gelu);
-    m.impl("hardswish", fewbit_amd::hardswish);
-    m.impl("logsigmoid", fewbit_amd::logsigmoid);
-    m.impl("mish", fewbit_amd::mish);
-    m.impl("selu", fewbit_amd::selu);
-    m.impl("sigmoid", fewbit_amd::sigmoid);
-    m.impl("silu", fewbit_amd::silu);
-    m.impl("softplus", fewbit_amd::softplus);
-    m.impl("softsign", fewbit_amd::softsign);
-    m.impl("tanh", fewbit_amd::tanh);
-    m.impl("tanhshrink", fewbit_amd::tanhshrink);
-
-    m.impl("stepwise", fewbit_amd::stepwise);
-    m.impl("stepwise_folded", fewbit_amd::stepwise_folded);
-    m.impl("stepwise_folded_out", fewbit_amd::stepwise_folded_out);
-    m.impl("continuous_out", fewbit_amd::continuous_out);
-    m.impl("stepwise1_out", fewbit_amd::stepwise1_out);
-}
+TORCH_LIBRARY_IMPL(fewbit, AutogradCUDA, m) { fewbit_amd::register_activations<fewbit_amd::Where::AutogradGpu>(m); }
 
 TORCH_LIBRARY_IMPL(fewbit, CUDA, m) {
+    fewbit_amd::register_activations<fewbit_amd::Where::RawGpu>(m);
     m.impl("quantize", fewbit_amd::quantize);
     m.impl("quantize_backward", fewbit_amd::quantize_backward);
+}
+
+TORCH_LIBRARY_IMPL(fewbit, AutogradCPU, m) { fewbit_amd::register_activations<fewbit_amd::Where::AutogradHost>(m); }
+
+TORCH_LIBRARY_IMPL(fewbit, CPU, m) {
+    fewbit_amd::register_activations<fewbit_amd::Where::RawHost>(m);
+    m.impl("quantize", fewbit_amd::quantize_host);
+    m.impl("quantize_backward", fewbit_amd::quantize_backward_host);
 }

@@ -67,10 +67,12 @@ def _gpu_continuous(name: str, input, inner, levels, extra):
     """In place like the reference op -- except on a view (say, the reshaped output of nn.Linear), where an in-place
     op would make autograd rebase the view (CopySlices: a zero-fill plus four full-size copies in backward); there the
     same kernel writes a fresh tensor and the view's base is simply released."""
-    if input._is_view():
+    if input._is_view() or not input.is_contiguous():
         p = tuple(extra) + (0.0, ) * (2 - len(extra))
         _native_op(name)  # loud failure if the library is missing
-        return torch.ops.fewbit.continuous_out(input, inner, levels, _CONTINUOUS_ID[name], *p)
+        # (a strided view -- chunk(2, -1) of a GEGLU, a transpose, channels_last -- is gathered first: the kernels
+        # stream flat memory)
+        return torch.ops.fewbit.continuous_out(input.contiguous(), inner, levels, _CONTINUOUS_ID[name], *p)
     return _native_op(name)(input, inner, levels, *extra)
 
 
@@ -81,6 +83,8 @@ class _HostQuantized(torch.autograd.Function):
     def forward(ctx, impl, input, borders, levels, *args):
         if borders.numel() + 1 != levels.numel():
             raise ValueError('Size of `borders` should be lesser than size of `levels` by one.')
+        if levels.numel() > 256:                   # codes are kept in one byte each; the GPU operators have the same limit
+            raise ValueError(f'Maximal number of levels is 256, got {levels.numel()}.')
         key = input.detach().float().contiguous()
         fold = getattr(impl, 'fold', None)
         if fold is not None:                       # even-parity fold of a custom table: search |x - shift_x|
@@ -157,7 +161,10 @@ def _make_continuous(name: str) -> Callable:
     fn.__name__ = fn.__qualname__ = name
     fn.__doc__ = (f'Few-bit ``{name}``: forward as :func:`torch.nn.functional.{name}`; backward multiplies the incoming '
                   'gradient by a piecewise-constant approximation of the derivative whose bucket index was\n'
-                  'stored with ``bits`` bits per element (default 3).  GPU tensors are modified in place.\n\n'
+                  'stored with ``bits`` bits per element (default 3).\n\n'
+                  'In-place rule (GPU): a tensor that owns its memory is overwritten and returned, like the reference op '
+                  '(``Tensor(a!)``); a VIEW or a\nnon-contiguous tensor is left intact and a fresh tensor is returned '
+                  '(an in-place write through a view would make autograd rebase it).  Host tensors are never modified.\n\n'
                   'Either ``bits`` (built-in table) or ``borders`` and ``values`` (custom table; ``borders`` with '
                   'both outer sentinels) may be given.')
     fn.__signature__ = _signature(name, True)
@@ -171,16 +178,17 @@ def _make_stepwise1(name: str) -> Callable:
         # `bits` is accepted and ignored: these functions have an exact 1-bit state (generated modules pass it)
         extra = _bind_extra(name, args, kwargs)
         if input.device.type == 'cuda':
-            if input._is_view():                 # see _gpu_continuous
+            if input._is_view() or not input.is_contiguous():                 # see _gpu_continuous
                 p = tuple(extra) + (0.0, ) * (2 - len(extra))
                 _native_op(name)
-                return torch.ops.fewbit.stepwise1_out(input, _STEPWISE_ID[name], *p)
+                return torch.ops.fewbit.stepwise1_out(input.contiguous(), _STEPWISE_ID[name], *p)
             return _native_op(name)(input, *extra)
         return impl(input, *extra)
 
     fn.__name__ = fn.__qualname__ = name
     fn.__doc__ = (f'Few-bit ``{name}``: same values and gradients as :func:`torch.nn.functional.{name}`, but only one '
-                  'bit per element is saved for backward.  GPU tensors are modified in place.')
+                  'bit per element is saved for backward.  GPU tensors that own their memory are overwritten in place; views and '
+                  'non-contiguous tensors are left intact (a fresh tensor is returned).')
     fn.__signature__ = _signature(name, False)
     return fn
 
@@ -205,18 +213,21 @@ def stepwise(input: torch.Tensor, borders: torch.Tensor, levels: torch.Tensor, p
     else:
         sx, sy = (0.0, 0.0) if shift is None else (float(shift[0]), float(shift[1]))
         if input.device.type == 'cuda':
-            op = _native_op('stepwise_folded_out' if input._is_view() else 'stepwise_folded')
-            return op(input, borders.to(input), levels.to(input), bool(parity), sx, sy)
+            if input._is_view() or not input.is_contiguous():
+                return _native_op('stepwise_folded_out')(input.contiguous(), borders.to(input), levels.to(input), bool(parity), sx, sy)
+            return _native_op('stepwise_folded')(input, borders.to(input), levels.to(input), bool(parity), sx, sy)
         if parity:
             return _HostQuantized.apply(_FoldedIdentity(sx), input, borders.to(input), levels.to(input))
+        if levels.numel() > 128:                   # as torch.ops.fewbit.stepwise_folded (torch_ops.cpp)
+            raise ValueError(f'An odd-parity table mirrors to twice its size: at most 128 levels, got {levels.numel()}.')
         bf, lf = borders.float(), levels.float()
         full_b = torch.cat([sx - bf.flip(0), bf.new_full((1, ), sx), bf + sx]).to(input)
         full_l = torch.cat([2.0 * sy - lf.flip(0), lf]).to(input)
         return _HostQuantized.apply(lambda t: t.clone(), input, full_b, full_l)
     if input.device.type == 'cuda':
-        if input._is_view():
+        if input._is_view() or not input.is_contiguous():
             _native_op('stepwise')
-            return torch.ops.fewbit.continuous_out(input, borders.to(input), levels.to(input), _CONTINUOUS_ID['identity'], 0.0, 0.0)
+            return torch.ops.fewbit.continuous_out(input.contiguous(), borders.to(input), levels.to(input), _CONTINUOUS_ID['identity'], 0.0, 0.0)
         return _native_op('stepwise')(input, borders.to(input), levels.to(input))
     return _HostQuantized.apply(lambda t: t.clone(), input, borders.to(input), levels.to(input))
 

@@ -75,9 +75,13 @@ def _replay_rng(token) -> torch.Generator:
     return gen
 
 
-def _dense_sketch(kind: str, p: int, rows: int, like: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
+def _dense_sketch(kind: str, p: int, rows: int, like: torch.Tensor, gen: torch.Generator,
+                  draw_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     if kind == 'gaussian':
-        return torch.randn((p, rows), generator=gen, device=gen.device, dtype=like.dtype).to(like.device)
+        # drawn in ONE dtype (`draw_dtype`, recorded by the forward) and then cast to the operand: randn's stream depends
+        # on the dtype, so a backward whose grad_output has another dtype than the forward's input (autocast) would
+        # otherwise replay a different S and return pure noise
+        return torch.randn((p, rows), generator=gen, device=gen.device, dtype=draw_dtype or like.dtype).to(like.device, like.dtype)
     signs = torch.randint(0, 2, (p, rows), generator=gen, device=gen.device, dtype=torch.int8).to(like.device)
     return (signs.to(like.dtype) * 2) - 1                                       # Rademacher: +-1
 
@@ -86,14 +90,14 @@ def _sampled_rows(p: int, rows: int, like: torch.Tensor, gen: torch.Generator) -
     return torch.randint(0, rows, (p, ), generator=gen, device=gen.device).to(like.device)
 
 
-def _sketch(kind: str, mat: torch.Tensor, p: int, gen: torch.Generator, sketch_dtype=None) -> torch.Tensor:
+def _sketch(kind: str, mat: torch.Tensor, p: int, gen: torch.Generator, sketch_dtype=None, draw_dtype=None) -> torch.Tensor:
     """``S @ mat`` for the unscaled sketch (``E[S^T S] = p * I`` dense, ``(p / rows) * I`` for sampled transforms)."""
     rows = mat.shape[0]
     if kind in ('gaussian', 'rademacher'):
         if sketch_dtype is not None and sketch_dtype != mat.dtype:
             low = mat.to(sketch_dtype)
-            return (_dense_sketch(kind, p, rows, low, gen) @ low).to(mat.dtype)
-        return _dense_sketch(kind, p, rows, mat, gen) @ mat
+            return (_dense_sketch(kind, p, rows, low, gen, draw_dtype) @ low).to(mat.dtype)
+        return _dense_sketch(kind, p, rows, mat, gen, draw_dtype) @ mat
     idx = _sampled_rows(p, rows, mat, gen)
     if kind == 'dct':
         return dct(mat, dim=0, norm='ortho')[idx]
@@ -109,9 +113,10 @@ class _LinearGRP(torch.autograd.Function):
         token, gen = _capture_rng(generator, input.device)
         rows = flat.shape[0]
         scale = 1.0 / p if kind in ('gaussian', 'rademacher') else rows / p
-        sketch = _sketch(kind, flat.detach(), p, gen, sketch_dtype) * scale
+        draw_dtype = sketch_dtype or flat.dtype
+        sketch = _sketch(kind, flat.detach(), p, gen, sketch_dtype, draw_dtype) * scale
         ctx.save_for_backward(sketch, weight)
-        ctx.token, ctx.p, ctx.kind, ctx.sketch_dtype = token, p, kind, sketch_dtype
+        ctx.token, ctx.p, ctx.kind, ctx.sketch_dtype, ctx.draw_dtype = token, p, kind, sketch_dtype, draw_dtype
         ctx.has_bias = bias is not None
         return F.linear(input, weight, bias)
 
@@ -123,7 +128,7 @@ class _LinearGRP(torch.autograd.Function):
             grad_input = grad_output @ weight
         flat = grad_output.reshape(-1, grad_output.shape[-1])
         if ctx.needs_input_grad[1]:
-            proj = _sketch(ctx.kind, flat, ctx.p, _replay_rng(ctx.token), ctx.sketch_dtype)
+            proj = _sketch(ctx.kind, flat, ctx.p, _replay_rng(ctx.token), ctx.sketch_dtype, ctx.draw_dtype)
             if proj.is_complex():                                               # Re((F G)^H (F X))
                 grad_weight = (proj.real.T @ sketch.real + proj.imag.T @ sketch.imag).to(weight.dtype)
             else:

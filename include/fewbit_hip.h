@@ -12,16 +12,16 @@
  * reference tree skolai/fewbit):
  *
  *   fewbit_hip_quantize_forward   <- the 13 `DECLARE_CONTINOUS_FUNC` launchers
- *                                    Celu ... Tanhshrink, fewbit/cuda/codec.h:74-91
+ *                                    Celu ... Tanhshrink, fewbit/cuda/codec.h:75-92
  *                                    (kernel StepwiseKernel, fewbit/cuda/codec.cu:489-504)
- *   fewbit_hip_quantize_backward  <- StepwiseBackward, fewbit/cuda/codec.h:93-95
+ *   fewbit_hip_quantize_backward  <- StepwiseBackward, fewbit/cuda/codec.h:94-96
  *                                    (fewbit/cuda/codec.cu:655-670)
  *   fewbit_hip_stepwise1_forward  <- Hardshrink/Hardsigmoid/Hardtanh/LeakyRelu/Relu/Relu6/
- *                                    Softshrink/Threshold, fewbit/cuda/codec.h:58-67
- *   fewbit_hip_stepwise1_backward <- <Name>Backward, fewbit/cuda/codec.h:58-67
- *   fewbit_hip_pack_codes         <- DeflateBlock, fewbit/cuda/codec.h:17-18 (layout of
+ *                                    Softshrink/Threshold, fewbit/cuda/codec.h:59-68
+ *   fewbit_hip_stepwise1_backward <- <Name>Backward, fewbit/cuda/codec.h:59-68
+ *   fewbit_hip_pack_codes         <- DeflateBlock, fewbit/cuda/codec.h:16-17 (layout of
  *                                    fewbit::Deflate, fewbit/cpu/codec.h:33-57)
- *   fewbit_hip_unpack_codes       <- InflateBlock, fewbit/cuda/codec.h:22-23
+ *   fewbit_hip_unpack_codes       <- InflateBlock, fewbit/cuda/codec.h:21-22
  *   fewbit_hip_state_nbytes       <- buffer_len = nobits * ceil(n/8),
  *                                    fewbit/cuda/activation.cc:349-351
  *   fewbit_hip_bitwidth           <- GetBitWidth, fewbit/cuda/activation.cc:17-21 (the

@@ -5,6 +5,7 @@ All functions take/return CPU torch tensors (bf16/fp16 are passed as raw
 16-bit words to the C side, which does its own software conversions).
 """
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 
@@ -39,7 +40,8 @@ def build(ref: bool = False) -> None:
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        so = HERE / 'liboracle.so'
+        # FEWBIT_ORACLE_LIB: the sanitizer build of the same restatement (`make -C oracle asan-test`)
+        so = Path(os.environ.get('FEWBIT_ORACLE_LIB') or HERE / 'liboracle.so')
         if not so.exists():
             build()
         L = ctypes.CDLL(str(so))

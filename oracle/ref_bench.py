@@ -4,7 +4,7 @@ with g++ against this image's libtorch) on a bounded sample -- the `cpu_baseline
 
 TEST/BENCH INFRASTRUCTURE: runs in its own process because the reference library registers the same
 TORCH_LIBRARY(fewbit) namespace as the product's libfewbit.so.  Prints one JSON line.
-usage: ref_bench.py ROWS COLS DTYPE BITS REPS TABLES_NPZ
+usage: ref_bench.py ROWS COLS DTYPE BITS REPS TABLES_NPZ [THREADS]
 """
 import json
 import os
@@ -21,6 +21,8 @@ HERE = Path(__file__).resolve().parent
 def main():
     rows, cols, dtype_name, bits, reps, tables = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), \
         int(sys.argv[5]), sys.argv[6]
+    if len(sys.argv) > 7:
+        torch.set_num_threads(int(sys.argv[7]))
     dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[dtype_name]
     so = HERE / '_ref' / 'libfewbit_ref.so'
     torch.ops.load_library(str(so))

@@ -265,3 +265,23 @@ def test_graph_accounting_like_reference_util_test():
     net = fewbit.map_module(m2, lambda m, p: convert_linear(m, fewbit.RandomizedLinear, proj_dim_ratio=0.5))
     assert isinstance(net[0], fewbit.RandomizedLinear) and isinstance(net[1], torch.nn.ReLU)
     assert net(torch.randn(6, 8)).shape == (6, 1)
+
+
+def test_host_path_refuses_tables_its_byte_codes_cannot_hold():
+    """codes are one byte each on the host path: 257 levels (or an odd-parity table that mirrors beyond 256) must
+    raise instead of wrapping silently (the GPU operators have the same limits, torch_ops.cpp)."""
+    x = torch.randn(64, requires_grad=True)
+    b = torch.linspace(-3, 3, 258)
+    with pytest.raises(ValueError):
+        fewbit.functional.gelu(x, borders=b, values=torch.rand(257))
+    y = fewbit.functional.gelu(x, borders=b[:257], values=torch.rand(256))           # 256 levels still fit
+    y.sum().backward()
+    half_b, half_l = torch.linspace(0.01, 3, 128), torch.rand(129)
+    with pytest.raises(ValueError):
+        fewbit.functional.stepwise(x, half_b, half_l, parity=False)
+    half_b, half_l = torch.linspace(0.01, 3, 127), torch.rand(128)
+    xx = torch.randn(500, requires_grad=True)
+    fewbit.functional.stepwise(xx, half_b, half_l, parity=False, shift=(0.0, 0.0)).sum().backward()
+    code = torch.searchsorted(half_b, xx.detach().abs())
+    want = torch.where(xx.detach() > 0, half_l[code], -half_l[code])
+    assert torch.equal(xx.grad, want)

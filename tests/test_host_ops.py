@@ -1,0 +1,155 @@
+"""The operator library on HOST tensors (dispatch keys AutogradCPU / CPU of fewbit_amd/csrc/torch_ops.cpp), no GPU.
+
+The reference registers `gelu` under the CPU key and exposes `quantize` / `quantize_backward` for host tensors
+(fewbit/cpu/gelu.cc:74-76, fewbit/fewbit.cc:6-7); here every operator has a host implementation with the same packed
+state as the GPU kernels.  Checked bit for bit against the outputs of the reference itself (tests/golden/quantize_ref.npz,
+codec_ref.npz), and against the oracle for what the reference cannot run."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import fewbit
+import oracle
+from fewbit_amd.store import store
+from helpers import DTYPES, GOLDEN, assert_bit_equal, from_raw
+
+
+@pytest.fixture(scope='module')
+def qref():
+    with np.load(GOLDEN / 'quantize_ref.npz') as z:
+        return {k: z[k].copy() for k in z.files}
+
+
+def _cases(qref):
+    return sorted({k.rsplit('_', 1)[0] for k in qref if k.endswith('_x')})
+
+
+def test_quantize_ops_match_reference_run_bitwise(qref):
+    """torch.ops.fewbit.quantize / quantize_backward / gelu on host tensors == the reference's own outputs."""
+    seen = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                        # e.g. "autograd kernel was not registered"
+        for key in _cases(qref):
+            name_k, dt, _ = key.split('_')
+            dtype = DTYPES[dt]
+            x, gy = from_raw(qref[key + '_x'], dtype), from_raw(qref[key + '_gy'], dtype)
+            b, l = from_raw(qref[f'{name_k}_{dt}_borders'], dtype), from_raw(qref[f'{name_k}_{dt}_levels'], dtype)
+            k = int(name_k[-2:])
+            y, state = torch.ops.fewbit.quantize(x, b)
+            ref_state = torch.from_numpy(qref[key + '_state'])            # reference length: ceil(k*n/8)
+            assert state.numel() == k * ((x.numel() + 7) // 8)             # here: k*ceil(n/8), zero padded
+            assert torch.equal(state[:ref_state.numel()], ref_state), key
+            assert int(state[ref_state.numel():].sum()) == 0
+            want_gx = from_raw(qref[key + '_gx'], dtype)
+            assert_bit_equal(torch.ops.fewbit.quantize_backward(gy, state, l), want_gx, key)
+            assert_bit_equal(torch.ops.fewbit.quantize_backward(gy, ref_state, l), want_gx, key + ' (reference-sized state)')
+            if name_k.startswith('gelu'):
+                assert_bit_equal(y, from_raw(qref[key + '_y'], dtype), key + ' y')
+                xx = x.clone().requires_grad_()
+                inp = xx.clone()
+                out = torch.ops.fewbit.gelu(inp, b, l)                     # in place on its input, like the reference op
+                assert out.data_ptr() == inp.data_ptr()
+                out.backward(gy)
+                assert_bit_equal(xx.grad, want_gx, key + ' autograd')
+            seen += 1
+    assert seen >= 70
+
+
+@pytest.mark.parametrize('name', [n for n in fewbit.functional.CONTINOUS])
+@pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16, torch.float16))
+def test_every_continuous_op_on_host_matches_oracle_state(name, dtype):
+    g = torch.Generator().manual_seed(11)
+    n = 1003
+    x = (torch.randn(n, generator=g) * 2).to(dtype)
+    x[:5] = torch.tensor([float('nan'), float('inf'), -float('inf'), 0.0, -0.0]).to(dtype)
+    gy = torch.randn(n, generator=g).to(dtype)
+    for bits in (1, 2, 3, 4):
+        inner, levels = store.get_inner(name, bits, torch.device('cpu'), dtype)
+        _, state_o, _ = oracle.quantize(name, x, inner)
+        gx_o = oracle.quantize_backward(gy, state_o, levels)
+        xx = x.clone().requires_grad_()
+        saved = []
+        with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(t), t)[1], lambda t: t):
+            y = getattr(torch.ops.fewbit, name)(xx.clone(), inner, levels)
+        packed = [t for t in saved if t.dtype == torch.uint8]
+        assert len(packed) == 1 and torch.equal(packed[0], state_o)        # the packed state is what is saved
+        y.backward(gy)
+        assert_bit_equal(xx.grad, gx_o, f'{name} k={bits}')
+        ref = getattr(F, name)(x) if hasattr(F, name) else getattr(torch, name)(x)
+        assert_bit_equal(y.detach(), ref, f'{name} forward')
+
+
+@pytest.mark.parametrize('name,args', [('hardshrink', (0.5,)), ('hardsigmoid', ()), ('hardtanh', (-1.0, 1.0)),
+                                       ('leaky_relu', (0.01,)), ('relu', ()), ('relu6', ()), ('softshrink', (0.5,)),
+                                       ('threshold', (0.25, -3.0))])
+@pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16))
+def test_stepwise1_ops_on_host(name, args, dtype):
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(777, generator=g) * 3).to(dtype)
+    x[:6] = torch.tensor([0.0, -0.0, 3.0, -3.0, 6.0, 0.5]).to(dtype)
+    gy = torch.randn(777, generator=g).to(dtype)
+    y_o, state_o = oracle.stepwise1_forward(name, x, *args)
+    gx_o = oracle.stepwise1_backward(name, gy, state_o, *(args[:1] if name == 'leaky_relu' else ()))
+    xx = x.clone().requires_grad_()
+    saved = []
+    with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(t), t)[1], lambda t: t):
+        y = getattr(torch.ops.fewbit, name)(xx.clone(), *args)
+    assert len(saved) == 1 and torch.equal(saved[0], state_o)
+    y.backward(gy)
+    # values are ATen's on the host (sign of a zero result included, where ATen's relu keeps -0 and the kernels'
+    # `x <= 0 -> 0` rule, fewbit/cuda/codec.cu:412-425, gives +0); equal as numbers to the oracle's
+    assert_bit_equal(y.detach(), getattr(F, name)(x, *args), name)
+    assert torch.equal(y.detach().float(), y_o.float())
+    assert_bit_equal(xx.grad, gx_o, name)
+
+
+def test_relu_1bit_matches_reference_packed_bits():
+    with np.load(GOLDEN / 'codec_ref.npz') as z:
+        for dt, dtype in DTYPES.items():
+            x = from_raw(z[f'relu01_{dt}_x'], dtype)
+            saved = []
+            with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(t), t)[1], lambda t: t):
+                y = torch.ops.fewbit.relu(x.clone().requires_grad_().clone())
+            assert torch.equal(saved[0], torch.from_numpy(z[f'relu01_{dt}_state']))
+            assert torch.equal(y.detach().float().nan_to_num(7.0), from_raw(z[f'relu01_{dt}_y'], dtype).float().nan_to_num(7.0))
+
+
+def test_host_state_layout_is_the_device_layout():
+    """ragged sizes, non power-of-two tables, wide tables: the host pack equals the oracle's (== reference Deflate)"""
+    g = torch.Generator().manual_seed(3)
+    for nlev in (2, 3, 5, 8, 9, 17, 100, 256):
+        borders = torch.sort(torch.randn(nlev - 1, generator=g))[0]
+        levels = torch.randn(nlev, generator=g)
+        for n in (1, 7, 8, 9, 63, 64, 65, 1001):
+            x = torch.randn(n, generator=g)
+            gy = torch.randn(n, generator=g)
+            _, state_o, k = oracle.quantize('identity', x, borders)
+            xx = x.clone().requires_grad_()
+            saved = []
+            with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(t), t)[1], lambda t: t):
+                y = torch.ops.fewbit.stepwise(xx.clone(), borders, levels)
+            st = [t for t in saved if t.dtype == torch.uint8][0]
+            assert torch.equal(st, state_o), (nlev, n)
+            y.backward(gy)
+            assert_bit_equal(xx.grad, oracle.quantize_backward(gy, state_o, levels))
+
+
+def test_host_ops_without_autograd_and_errors():
+    inner, levels = store.get_inner('silu', 2, torch.device('cpu'), torch.float32)
+    x = torch.randn(100)
+    with torch.inference_mode():
+        y = torch.ops.fewbit.silu(x.clone(), inner, levels)
+    assert torch.equal(y, F.silu(x))
+    with torch.no_grad():
+        assert torch.equal(torch.ops.fewbit.relu(x.clone()), F.relu(x))
+    with pytest.raises(RuntimeError):
+        torch.ops.fewbit.gelu(x.clone(), inner, levels[:-1])              # table sizes
+    with pytest.raises(RuntimeError):
+        torch.ops.fewbit.gelu(x.clone(), inner.double(), levels.double())  # dtype mismatch
+    with pytest.raises(RuntimeError):
+        torch.ops.fewbit.quantize_backward(x, torch.zeros(3, dtype=torch.uint8), levels)   # state too small
+    with pytest.raises(RuntimeError):
+        torch.ops.fewbit.gelu(torch.randn(4, 4).t(), inner, levels)       # not contiguous

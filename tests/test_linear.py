@@ -128,3 +128,21 @@ def test_sketch_dtype_keeps_the_estimate_unbiased():
     assert (torch.linalg.norm(gi - ri) / torch.linalg.norm(ri)).item() <= 1e-6
     assert (torch.linalg.norm(gw - rw) / torch.linalg.norm(rw)).item() <= 1e-1
     assert gw.dtype == torch.float32
+
+
+def test_replay_survives_a_dtype_change_between_forward_and_backward():
+    """CPU autocast: fp32 input in forward, bf16 grad_output in backward.  The Gaussian sketch must be replayed from
+    the forward's draw dtype (randn's stream depends on the dtype) -- otherwise the estimate is pure noise."""
+    torch.manual_seed(5)
+    module = LinearGRP(48, 24, proj_dim=24)
+    xs = torch.randn(96, 48)
+    exact = (torch.ones(96, 24).T @ xs)                        # d/dW of sum(linear(x)) is ones^T x
+    acc = torch.zeros_like(exact)
+    runs = 400
+    for _ in range(runs):
+        module.zero_grad()
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            module(xs).sum().backward()
+        acc += module.weight.grad
+    rel = (torch.linalg.norm(acc / runs - exact) / torch.linalg.norm(exact)).item()
+    assert rel <= 0.15, rel                                     # was ~1.0 (uncorrelated S in forward and backward)

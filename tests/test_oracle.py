@@ -229,3 +229,20 @@ def test_reference_smoke_vectors_pin_each_other():
     assert np.array_equal(oracle.deflate(np.array(REF_SMOKE_CODES, dtype=np.int32), 3), state.numpy())
     assert torch.equal(oracle.quantize_backward(torch.ones(16), state, levels), levels[torch.tensor(REF_SMOKE_CODES)])
     assert y[4].item() == pytest.approx(999.9) and y[15].item() == pytest.approx(999.9)
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """the CPU restatement is run under ASan/UBSan (build container only, never on the GPU box):
+    `make -C oracle asan-test` re-runs this file and tests/test_host_ops.py against liboracle_asan.so."""
+    import os
+    import shutil
+    import subprocess
+    if os.environ.get('FEWBIT_ORACLE_LIB'):
+        pytest.skip('already inside the sanitizer run')
+    if not shutil.which('gcc') or not os.path.exists(subprocess.run(['gcc', '-print-file-name=libasan.so'], capture_output=True,
+                                                                     text=True).stdout.strip()):
+        pytest.skip('no libasan in this image')
+    from helpers import ROOT
+    r = subprocess.run(['make', '-s', '-C', str(ROOT / 'oracle'), 'asan-test'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert ' passed' in r.stdout and 'ERROR: AddressSanitizer' not in r.stdout + r.stderr and 'runtime error' not in r.stderr
