@@ -232,6 +232,9 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
 // instructions -- independent of K -- and runs on the otherwise idle LDS unit, which takes the forward from
 // VALU-bound back to memory-bound.  Blocks are 1024 threads (16 waves) so that two of them (2 x 64 KiB of LDS) fill
 // a CU with 32 waves.
+#ifndef FEWBIT_LUT_HEAD
+#define FEWBIT_LUT_HEAD 0
+#endif
 #ifndef FEWBIT_LUT_WPS
 #define FEWBIT_LUT_WPS 8      // waves per SIMD the table kernel is compiled for (two 16-wave blocks per CU)
 #endif
@@ -264,6 +267,128 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
     }
 
     struct Buf { Raw r[U]; };
+#if FEWBIT_LUT_HEAD
+    // ---- head variants under measurement (FEWBIT_LUT_HEAD bit mask): 1 = one-barrier build, 2 = second tile prefetched
+    // before the build, 4 = first tile bucketed by register search BEFORE the barrier
+    float b[NBMAX];
+    auto load = [&](size_t t, Buf &buf) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + s.lane);
+    };
+    auto finish = [&](size_t t, const Buf &buf, const uint32_t (&w)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float v[8];
+            GroupIO<DT>::unpack(buf.r[u], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
+            const size_t g = (t * U + u) * kWave + s.lane;
+            GroupIO<DT>::template store<true>(y, g, v);
+            store_state_quad<K, false>(state, g, s.lane, w[u]);
+        }
+    };
+    auto process_lut = [&](size_t t, const Buf &buf) {
+        uint32_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            w[u] = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t d = buf.r[u].q[i];
+                w[u] |= static_cast<uint32_t>(lut[d & 0xffffu]) << (K * 2 * i);
+                w[u] |= static_cast<uint32_t>(lut[d >> 16]) << (K * (2 * i + 1));
+            }
+        }
+        finish(t, buf, w);
+    };
+    auto process_search = [&](size_t t, const Buf &buf) {
+        uint32_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float v[8];
+            GroupIO<DT>::unpack(buf.r[u], v);
+            w[u] = pack_group<K>(v, b);
+        }
+        finish(t, buf, w);
+    };
+    Buf A, B;
+    const size_t t0 = s.wave;
+    const bool active = t0 < s.ntiles;                                   // wave-uniform
+    const size_t last = s.ntiles ? s.ntiles - 1 : 0;
+    size_t t1 = t0 + s.nwaves;
+    if (active) {
+        load(t0, A);
+        if (FEWBIT_LUT_HEAD & 2) load(t1 < last ? t1 : last, B);
+    }
+#pragma unroll
+    for (int j = 0; j < NBMAX; ++j) b[j] = bits_f32(__builtin_amdgcn_readlane(f32_bits(mine), j));
+    auto code_of = [&](uint32_t r) -> uint32_t {
+        return ((r & 0x7fffu) > kInf) ? static_cast<uint32_t>(nborders) : count_below<NBMAX>(b, value_of_pattern<DT>(r));
+    };
+    {
+        const uint32_t r0 = threadIdx.x * 64u;
+        const uint32_t c_first = code_of(r0);
+        const uint32_t c0 = c_first * 0x01010101u;
+        u32x4 fill = {c0, c0, c0, c0};
+        u32x4 *dst = reinterpret_cast<u32x4 *>(lut + r0);
+        dst[0] = fill; dst[1] = fill; dst[2] = fill; dst[3] = fill;
+#if FEWBIT_LUT_HEAD & 1
+        // the code is monotone over a chunk (ascending patterns in the positive half, descending values in the negative
+        // half, NaN patterns -> nborders at the far end), so a chunk is constant iff its two ends agree; the few chunks a
+        // border cuts are rewritten pattern by pattern by the SAME wave that filled them (LDS operations of one wave
+        // stay in order), which is why one barrier is enough
+        unsigned long long cut = __ballot(c_first != code_of(r0 + 63u));
+        const uint32_t wave_r0 = (threadIdx.x & ~63u) * 64u;
+        while (cut) {                                                    // wave-uniform, at most NBMAX + 2 rounds per block
+            const int l = __builtin_ctzll(cut);
+            cut &= cut - 1;
+            const uint32_t r = wave_r0 + static_cast<uint32_t>(l) * 64u + s.lane;
+            lut[r] = static_cast<uint8_t>(code_of(r));
+        }
+#else
+        __syncthreads();
+        const int wv = threadIdx.x >> 6;
+        uint32_t *lut32 = reinterpret_cast<uint32_t *>(lut);
+        if (wv < nborders) {
+            const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine_raw), wv));
+            const uint32_t mag = bits & 0x7fffu;
+            const bool neg = (bits >> 15) != 0 && mag != 0;
+            if (mag <= kInf) {
+                const uint32_t first = neg ? 0x8000u + mag : mag + 1u;
+                const uint32_t r = first + s.lane;
+                if ((first & 63u) != 0 && r < ((first | 63u) + 1u) && (r & 0x7fffu) <= kInf) {
+                    const uint32_t one = 1u << (8u * (r & 3u));
+                    if (neg) __hip_atomic_fetch_sub(&lut32[r >> 2], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_fetch_add(&lut32[r >> 2], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        if (wv == kLutWaves - 1 && s.lane > 0) {
+            lut[kInf + s.lane] = static_cast<uint8_t>(nborders);
+            lut[0x8000u + kInf + s.lane] = static_cast<uint8_t>(nborders);
+        }
+#endif
+    }
+    // the register search gives NaN -> 2^K - 1, which is the right code only for a full table
+    const bool head_search = (FEWBIT_LUT_HEAD & 4) && nborders == NBMAX;
+    if (active && head_search) process_search(t0, A);
+    __syncthreads();
+    if (active) {
+        if (!(FEWBIT_LUT_HEAD & 2)) load(t1 < last ? t1 : last, B);
+        if (!head_search) process_lut(t0, A);
+        while (t1 < s.ntiles) {                                          // B holds tile t1
+            const size_t t2 = t1 + s.nwaves;
+            load(t2 < last ? t2 : last, A);
+            process_lut(t1, B);
+            if (t2 >= s.ntiles) break;
+            const size_t t3 = t2 + s.nwaves;
+            load(t3 < last ? t3 : last, B);
+            process_lut(t2, A);
+            t1 = t3;
+        }
+    }
+    (void)mine_raw;
+#else
     auto build = [&]() {
         // wave-uniform copy of the table (padding +inf never satisfies !(b >= x) for a number)
         float b[NBMAX];
@@ -330,6 +455,8 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
                 store_state_quad<K, false>(state, g, s.lane, w);
             }
         });
+
+#endif
 
     // ---- tail: element-wise through the same table, last wave only
     if (s.wave != s.nwaves - 1) return;

@@ -3,7 +3,8 @@
 
 Run from the repo root, only where /root/reference exists:
 
-    make -C oracle ref && python tests/golden/gen_golden.py
+    make -C oracle ref && python tests/golden/gen_golden.py            (everything)
+    python tests/golden/gen_golden.py fullsize                         (only the full-size digests)
 
 What is executed is the reference itself, where it lies:
   * oracle/_ref/libfewbit_ref.so  = fewbit/fewbit.cc + fewbit/cpu/gelu.cc + fewbit/cpu/codec.cc
@@ -197,13 +198,40 @@ def gen_api(tables):
     print('api_surface.json', {k: len(v) if hasattr(v, '__len__') else v for k, v in api.items()})
 
 
+def gen_fullsize(tables):
+    """The reference itself on the full BASELINE-size tensors (C2, C3 k=2/k=4, the C4 per-GPU shard): only SHA-256
+    digests of x, gy, the packed state and gx are committed (tests/golden/fullsize_digests.json); the GPU test
+    regenerates x/gy with the same seeded recipe (tests/helpers.py:full_size_inputs), checks their digests, and compares
+    the digests of the HIP kernels' state and gx."""
+    sys.path.insert(0, str(ROOT / 'tests'))
+    from helpers import FULL_SIZE_CASES, full_size_inputs, sha256_of
+    torch.ops.load_library(str(ROOT / 'oracle/_ref/libfewbit_ref.so'))
+    doc = {'recipe': 'tests/helpers.py:full_size_inputs; state/gx from torch.ops.fewbit.quantize / quantize_backward of '
+                     'oracle/_ref/libfewbit_ref.so (the reference compiled as is); sha256 over the raw little-endian bytes',
+           'torch': torch.__version__, 'cases': {}}
+    for case, (name, bits, dt, rows, cols) in FULL_SIZE_CASES.items():
+        x, gy, b, l = full_size_inputs(case, tables)
+        _, state = torch.ops.fewbit.quantize(x, b)
+        gx = torch.ops.fewbit.quantize_backward(gy, state, l)
+        assert state.numel() == bits * (rows * cols // 8)
+        doc['cases'][case] = {'function': name, 'bits': bits, 'dtype': dt, 'shape': [rows, cols], 'x': sha256_of(x),
+                              'gy': sha256_of(gy), 'state': sha256_of(state), 'gx': sha256_of(gx),
+                              'state_bytes': state.numel(), 'state_byte_sum': int(state.sum(dtype=torch.int64))}
+        print(case, doc['cases'][case]['state'][:16], doc['cases'][case]['gx'][:16])
+    (OUT / 'fullsize_digests.json').write_text(json.dumps(doc, indent=1, sort_keys=True) + '\n')
+
+
 def main():
     assert REF.exists(), 'the reference tree is only present in the build container'
     with np.load(REF / 'fewbit/data/builtin.npz') as z:
         tables = {k: z[k].copy() for k in z.files}
+    if len(sys.argv) > 1 and sys.argv[1] == 'fullsize':
+        gen_fullsize(tables)
+        return
     gen_quantize(tables)
     gen_codec()
     gen_api(tables)
+    gen_fullsize(tables)
 
 
 if __name__ == '__main__':

@@ -90,3 +90,45 @@ REF_SMOKE_CODES = (6, 5, 6, 1, 7, 0, 4, 2, 2, 3, 0, 4, 5, 5, 6, 7)
 REF_SMOKE_GELU_INPUTS = (2.29811567e+00, 6.10855860e-01, 2.29811567e+00, -8.11248159e-01, 9.99900000e+02, -2.49798704e+00,
                          2.26182064e-01, -4.26290283e-01, -4.26290283e-01, -1.00155338e-01, -2.49798704e+00, 2.26182064e-01,
                          6.10855860e-01, 6.10855860e-01, 2.29811567e+00, 9.99900000e+02)
+
+
+# ---- full-size inputs of the BASELINE configs (shared by tests/golden/gen_golden.py, which runs the REFERENCE on them and
+# commits SHA-256 digests, and by tests/test_gpu_parity.py, which regenerates them on the GPU box) -------------------------
+FULL_SIZE_CASES = {
+    # name: (function, bits, dtype key, rows, cols)
+    'c2_gelu3_bf16_4096x4096': ('gelu', 3, 'bf16', 4096, 4096),
+    'c3_silu2_f16_8192x8192': ('silu', 2, 'f16', 8192, 8192),
+    'c3_silu4_f16_8192x8192': ('silu', 4, 'f16', 8192, 8192),
+    'c4shard_gelu3_bf16_8192x4096': ('gelu', 3, 'bf16', 8192, 4096),
+}
+
+
+def border_specials(inner_borders: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """NaN (both signs), +-inf, +-0, every border and its two neighbours in `dtype`, +-100, +-200."""
+    b = inner_borders.to(dtype)
+    it = torch.int32 if dtype == torch.float32 else torch.int16
+    nb = b.view(it)
+    fixed = torch.tensor([float('nan'), float('inf'), -float('inf'), 0.0, -0.0, 100.0, -100.0, 200.0, -200.0, 1e-30, -1e-30]).to(dtype)
+    neg_nan = torch.tensor([-1], dtype=it).view(dtype)
+    return torch.cat([fixed, b, (nb + 1).view(dtype), (nb - 1).view(dtype), neg_nan])
+
+
+def full_size_inputs(case: str, tables: dict):
+    """(x, gy, inner borders, levels) of a BASELINE-size case: seeded host randn cast to the dtype, with the
+    special values spliced in at the start and at the end of x."""
+    name, bits, dt, rows, cols = FULL_SIZE_CASES[case]
+    dtype = DTYPES[dt]
+    borders = torch.tensor(tables[f'{name}{bits:02d}-borders']).to(dtype)[1:-1].contiguous()
+    levels = torch.tensor(tables[f'{name}{bits:02d}-levels']).to(dtype)
+    x = torch.randn(rows * cols, generator=torch.Generator().manual_seed(0)).to(dtype)
+    gy = torch.randn(rows * cols, generator=torch.Generator().manual_seed(1)).to(dtype)
+    sp = border_specials(borders, dtype)
+    x[:sp.numel()] = sp
+    x[-sp.numel():] = sp
+    return x, gy, borders, levels
+
+
+def sha256_of(t: torch.Tensor) -> str:
+    import hashlib
+    t = t.detach().cpu().contiguous()
+    return hashlib.sha256(t.view(torch.uint8).numpy().tobytes()).hexdigest()

@@ -327,3 +327,63 @@ def test_torch_free_host_program_on_the_c_abi():
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'mismatches: codes 0, gradients 0, forward 0' in out.stdout
+
+
+def test_inference_mode_and_no_grad_run_the_kernels():
+    """Under torch.inference_mode() the Autograd keys are excluded: the plain CUDA-key registration must serve the
+    call (the reference, registered for AutogradCUDA only, raises there)."""
+    from fewbit_amd.store import store
+    x = torch.randn(5000, device=DEV, dtype=torch.bfloat16)
+    inner, levels = store.get_inner('gelu', 3, torch.device(DEV), torch.bfloat16)
+    want = fewbit.functional.gelu(x.clone().requires_grad_().clone(), bits=3).detach()
+    with torch.inference_mode():
+        y = torch.ops.fewbit.gelu(x.clone(), inner, levels)
+        assert torch.equal(y.view(torch.int16), want.view(torch.int16))
+        z = fewbit.GELU(bits=3)(x.clone())
+        assert torch.equal(z.view(torch.int16), want.view(torch.int16))
+        r = torch.ops.fewbit.relu(x.clone())
+        assert torch.equal(r, F.relu(x))
+        o = torch.ops.fewbit.continuous_out(x, inner, levels, 2)          # FEWBIT_GELU
+        assert torch.equal(o.view(torch.int16), want.view(torch.int16)) and o.data_ptr() != x.data_ptr()
+    with torch.no_grad():
+        y = fewbit.functional.silu(x.clone(), bits=2)
+    assert not y.requires_grad and forward_value_ok(x.cpu(), y.cpu(), F.silu(x.float()).to(torch.bfloat16).cpu()).all()
+
+
+def test_strided_inputs_are_gathered_and_left_intact():
+    """chunk(2, -1) of a GEGLU, a transpose, channels_last: non-contiguous views go through the out-of-place operators
+    after a gather (F.gelu accepts them; the flat-memory kernels need the copy)."""
+    base = torch.randn(64, 96, device=DEV, dtype=torch.float16)
+    for view in (base.chunk(2, -1)[1], base.t(), base[:, ::2]):
+        assert not view.is_contiguous()
+        keep = view.clone()
+        v = view.detach().requires_grad_()
+        y = fewbit.functional.gelu(v, bits=3)
+        assert y.shape == view.shape and torch.equal(view, keep)             # input untouched
+        ok = forward_value_ok(keep.cpu(), y.detach().cpu(), F.gelu(keep.float()).half().cpu())
+        assert ok.all()
+        y.sum().backward()
+        borders, levels = fewbit.functional.store.get('gelu', 3, 'cpu', torch.float16)
+        code = torch.searchsorted(borders[1:-1].float(), keep.cpu().float())
+        assert torch.equal(v.grad.cpu(), levels[code])
+        r = fewbit.functional.relu(view.detach().requires_grad_())
+        assert torch.equal(r, F.relu(keep)) and torch.equal(view, keep)
+    x4 = torch.randn(2, 8, 5, 5, device=DEV).to(memory_format=torch.channels_last)
+    assert torch.allclose(fewbit.functional.silu(x4, bits=4), F.silu(x4), atol=1e-6)
+
+
+def test_state_moves_between_host_and_device_operators():
+    """The host operators (AutogradCPU/CPU keys) pack the same bytes as the kernels: a state produced on one side is
+    consumed on the other."""
+    from fewbit_amd.store import store
+    g = torch.Generator().manual_seed(9)
+    for dtype in (torch.float32, torch.bfloat16):
+        x = (torch.randn(10007, generator=g) * 2).to(dtype)
+        gy = torch.randn(10007, generator=g).to(dtype)
+        inner, levels = store.get_inner('gelu', 3, torch.device('cpu'), dtype)
+        _, st_host = torch.ops.fewbit.quantize(x, inner)
+        _, st_dev = torch.ops.fewbit.quantize(x.to(DEV), inner.to(DEV))
+        assert torch.equal(st_host, st_dev.cpu())
+        gx_dev_from_host = torch.ops.fewbit.quantize_backward(gy.to(DEV), st_host.to(DEV), levels.to(DEV))
+        gx_host_from_dev = torch.ops.fewbit.quantize_backward(gy, st_dev.cpu(), levels)
+        assert_bit_equal(gx_dev_from_host.cpu(), gx_host_from_dev)

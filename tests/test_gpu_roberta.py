@@ -1,0 +1,82 @@
+"""BASELINE.json configs[4] on the GPU: RoBERTa-base (random init, `RobertaConfig()` defaults 768/12/12/3072), batch 128 x
+seq 128, forward+backward with all 12 intermediate GELUs replaced by fewbit.GELU(bits=3), against the vanilla model.
+
+The caller this mimics is the reference's benchmark/bench-roberta.py:123-149 (it patches ACT2FN['gelu'] with
+torch.ops.fewbit.gelu and reports wall time and the peak-memory delta); SURVEY 8(d) C5 gives the expected saving:
+12 x 16384 x 3072 x (s - 3/8) bytes of saved activations (s = element size)."""
+import statistics
+import sys
+import time
+
+import pytest
+import torch
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, str(ROOT / 'tools'))
+
+BATCH, SEQ, BITS = 128, 128, 3
+
+
+def _step_times(model, ids, labels, steps):
+    opt = torch.optim.SGD(model.parameters(), lr=1e-4)
+    times = []
+    for i in range(steps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        model(input_ids=ids, labels=labels).loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        if i >= 2:
+            times.append(time.perf_counter() - t0)
+    return times
+
+
+@pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16))
+def test_roberta_base_all_gelu_fewbit(dtype):
+    pytest.importorskip('transformers')
+    import fewbit
+    import fewbit_amd
+    import roberta_bench as rb
+    assert fewbit_amd.native_loaded(), fewbit_amd.native_error()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(5, 50000, (BATCH, SEQ), generator=g).to(dev)
+    labels = torch.randint(0, 2, (BATCH,), generator=g).to(dev)
+    es = torch.empty(0, dtype=dtype).element_size()
+
+    res = {}
+    for name in ('vanilla', 'fewbit'):
+        model = rb.build(dtype, dev)                                  # same seed -> same weights
+        swapped = rb.swap_gelu(model, BITS) if name == 'fewbit' else 0
+        assert swapped == (12 if name == 'fewbit' else 0)
+        # first step: same weights, same dropout stream -> the loss may differ only by the GELU arithmetic
+        torch.manual_seed(123)
+        torch.cuda.reset_peak_memory_stats(dev)
+        with fewbit.memory_usage_hooks() as usage:
+            out = model(input_ids=ids, labels=labels)
+            loss = float(out.loss)
+            out.loss.backward()
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated(dev)
+        del out
+        times = _step_times(model, ids, labels, steps=8)
+        res[name] = dict(loss=loss, saved=usage.forward, peak=peak, ms=statistics.median(times) * 1e3)
+        del model
+        torch.cuda.empty_cache()
+
+    n_act = 12 * BATCH * SEQ * 3072
+    expect = n_act * es - (BITS * n_act) // 8                          # 12 * 16384 * 3072 * (s - 3/8)
+    delta = res['vanilla']['saved'] - res['fewbit']['saved']
+    assert abs(delta - expect) <= 1024, (delta, expect)
+    # the peak moves by (almost) the same amount: nothing else grew
+    assert res['vanilla']['peak'] - res['fewbit']['peak'] >= 0.95 * expect
+    tol = 1e-4 if dtype == torch.float32 else 4e-3                     # bf16 loss has 8 significant bits
+    assert abs(res['vanilla']['loss'] - res['fewbit']['loss']) <= tol, res
+    ratio = res['fewbit']['ms'] / res['vanilla']['ms']
+    print(f'\nroberta-base {dtype}: vanilla {res["vanilla"]["ms"]:.2f} ms, fewbit {res["fewbit"]["ms"]:.2f} ms (ratio {ratio:.3f}); '
+          f'peak {res["vanilla"]["peak"] / 2**30:.2f} -> {res["fewbit"]["peak"] / 2**30:.2f} GiB; saved-tensor delta {delta} B')
+    assert ratio <= 1.03, res
