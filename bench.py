@@ -213,6 +213,9 @@ def main():
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--config', choices=('c2', 'c4'), default='c2', help='headline workload per GPU (see module docstring)')
+    ap.add_argument('--settle-ms', type=float, default=40.0,
+                    help='keep issuing untimed warm-up steps until the GPU has been busy this long (0 = exactly W steps): '
+                         'MI355X drops its clocks 1.5-10 ms after load begins and recovers by ~15 ms (scratch/timeline.py)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='timed region only (what the rocprofv3 passes run)')
     args = ap.parse_args()
@@ -256,9 +259,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_warm = time.perf_counter()
     for _ in range(args.warmup):
         fwd()
         bwd()
+    # Untimed settle: a GPU that was idle boosts for ~1.5 ms, then runs 8-12 % slower for ~10 ms, then settles (measured
+    # step by step with scratch/timeline.py); a 20-step region would sit in the boost phase, a 200-step region in the
+    # dip.  Warm-up therefore continues (same steps, untimed) until the device has been busy for --settle-ms.
+    torch.cuda.synchronize()
+    settle_steps = 0
+    while (time.perf_counter() - t_warm) * 1e3 < args.settle_ms:
+        for _ in range(50):
+            fwd()
+            bwd()
+        settle_steps += 50
+        torch.cuda.synchronize()
     # ---- the timed region.  barrier + synchronize; an untimed pre-roll keeps the GPU busy while the host runs ahead,
     # so that the K timed steps execute from a filled queue (without it the first launch's host latency, ~5 us, is
     # 1 % of a 20-step region); then exactly K steps between two events on the launch stream.  No collective and no
@@ -322,6 +337,8 @@ def main():
                                       if w.set_bytes < INFINITY_CACHE_BYTES else 'one buffer set, larger than the 256 MiB Infinity Cache'},
             'timing': {'method': 'two HIP events on the launch stream around exactly K steps, after barrier+synchronize and an '
                                  f'untimed {preroll}-step pre-roll; max over ranks',
+                       'warmup_settle': f'{settle_steps} extra untimed steps after the {args.warmup} warm-up steps, until the GPU had '
+                                        f'been busy {args.settle_ms:g} ms (clock transient after idle)',
                        'wall_ms_per_step': round(wall / (args.steps + preroll) * 1e3, 5),
                        'wall_note': f'host perf_counter from the barrier to the final synchronize over K+{preroll} steps'},
             'pct_of_hbm_roofline': round(100.0 * (total / elapsed / 1e9) / (HBM_PEAK_GBS * world), 2),

@@ -22,6 +22,7 @@
 //   pack/unpack_codes_kernel      codec seam used by the tests
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -43,11 +44,15 @@ template <int NB> __device__ __forceinline__ uint32_t count_below(const float (&
     return c;
 }
 
-// lanes 0..NB-1 fetch one border each; every lane then holds all NB (wave-uniform) values
-template <int DT, int NB> __device__ __forceinline__ void load_borders(const void *borders, float (&b)[NB]) {
+// lanes 0..NB-1 fetch one border each (fetch_border: issued before the first tile so that waiting for it -- vmcnt
+// counts in order -- does not wait for the tile too); every lane then holds all NB (wave-uniform) values
+template <int DT, int NB> __device__ __forceinline__ float fetch_border(const void *borders) {
     const int lane = threadIdx.x & (kWave - 1);
     float mine = 0.0f;
     if (lane < NB) mine = Elem<DT>::load(borders, lane);
+    return mine;
+}
+template <int NB> __device__ __forceinline__ void spread_borders(float mine, float (&b)[NB]) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) b[j] = bits_f32(__builtin_amdgcn_readlane(f32_bits(mine), j));
 }
@@ -60,20 +65,42 @@ template <int DT, int NB> __device__ __forceinline__ void load_borders(const voi
 // scalar loop and every address is "scalar base + lane offset".
 struct Span {
     size_t wave, nwaves, ntiles, tail_g0, ngroups;
+    size_t t0, t_end, stride;     // this wave's tiles: t0, t0 + stride, ... < t_end
+    bool tail_owner;              // the one wave that also does the ragged tail
     int lane;
 };
 
+// Two ways of handing tiles to waves (host side: launch_shape()):
+//   chunk == 0  RESIDENT: the grid is one resident generation of waves and wave w takes tiles w, w + W, w + 2W, ...
+//               (the whole chip sweeps one contiguous window; best while the tensor is a few tiles per wave)
+//   chunk == T  CHUNKED: block b owns the contiguous tiles [b*WPB*T, (b+1)*WPB*T) and its wave j takes
+//               b*WPB*T + j, + WPB, ... (T tiles); the grid has as many blocks as that needs, far more than fit, and the
+//               hardware dispatcher hands the next block to whichever CU frees up first -- dynamic load balancing at
+//               block granularity for free (device-scope atomics cost ~10 ns per claim on this part), which is what a
+//               large tensor needs: CUs/XCDs do not progress at the same rate and a static split waits for the slowest.
 // `slack`: full groups that must remain after the last tile (the wide-code backward over-reads a few bytes)
-template <int U, int WPB = kWavesPerBlock> __device__ __forceinline__ Span make_span(size_t n, size_t slack = 0) {
+template <int U, int WPB = kWavesPerBlock> __device__ __forceinline__ Span make_span(size_t n, int chunk, size_t slack = 0) {
     Span s;
     s.lane = threadIdx.x & (kWave - 1);
+    const size_t wib = static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
     s.nwaves = static_cast<size_t>(gridDim.x) * WPB;
-    s.wave = static_cast<size_t>(blockIdx.x) * WPB +
-             static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
+    s.wave = static_cast<size_t>(blockIdx.x) * WPB + wib;
     const size_t full = n >> 3;
     s.ntiles = (full > slack ? full - slack : 0) / (static_cast<size_t>(U) * kWave);
     s.tail_g0 = s.ntiles * (static_cast<size_t>(U) * kWave);
     s.ngroups = (n + 7) >> 3;
+    if (chunk > 0) {
+        const size_t per_block = static_cast<size_t>(WPB) * static_cast<size_t>(chunk);
+        const size_t b0 = static_cast<size_t>(blockIdx.x) * per_block;
+        s.t0 = b0 + wib;
+        s.t_end = b0 + per_block < s.ntiles ? b0 + per_block : s.ntiles;
+        s.stride = WPB;
+    } else {
+        s.t0 = s.wave;
+        s.t_end = s.ntiles;
+        s.stride = s.nwaves;
+    }
+    s.tail_owner = s.wave == s.nwaves - 1;
     return s;
 }
 
@@ -97,36 +124,64 @@ __device__ unsigned long long g_trace[1 << 17];
 // The input pointers of these kernels are deliberately NOT __restrict__: outputs may alias inputs
 // (in-place, as the reference op), and with noalias inputs LLVM sinks the prefetch loads below the
 // stores of process(), right in front of their use, which undoes the pipeline.
-//   init()          runs once, after the first tile's loads are in flight (table setup hides there)
-template <typename Buf, typename Init, typename Load, typename Process>
+//   init()          runs once, after the first two tiles' loads are in flight (table setup hides there)
+//   EARLY           both buffers are requested before init() (see below)
+#ifndef FEWBIT_EARLY_ALL
+#define FEWBIT_EARLY_ALL 0    // tuning hook: early head for every kernel, not only the pattern-table forward
+#endif
+template <typename Buf, bool EARLY = (FEWBIT_EARLY_ALL != 0), typename Init, typename Load, typename Process>
 __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&load, Process &&process) {
     Buf A, B;
-    size_t t = s.wave;
-    if (t >= s.ntiles) {
+    size_t t = s.t0;
+    if (t >= s.t_end) {
         init();
         return;
     }
     const size_t last = s.ntiles - 1;
     FEWBIT_STAMP(0);
     load(t, A);
+    if constexpr (EARLY) {
+    // head: BOTH buffers are requested before init() (table build / LDS staging + barrier), so that the memory system
+    // has two tiles per wave in flight while the block sets itself up (pattern-table forward 12.0 -> 11.2 us at
+    // 4096x4096 bf16; bucketing the first tile by register search ahead of the barrier, or building the table with one
+    // barrier, did not help: DESIGN.md section 6).  Prefetches are unconditional (clamped to the last tile, whose data
+    // is then simply dropped): a load issued on only one path would make the s_waitcnt in front of process() count for
+    // the shorter path and wait for the prefetch itself.
+    size_t t1 = t + s.stride;
+    load(t1 < last ? t1 : last, B);
     init();
     FEWBIT_STAMP(1);
     int slot = 2;
     for (;;) {
-        // prefetches are unconditional (clamped to the last tile, whose data is then simply dropped):
-        // a load issued on only one path would make the s_waitcnt in front of process() count for the
-        // shorter path and wait for the prefetch itself
-        const size_t t1 = t + s.nwaves;
-        load(t1 < last ? t1 : last, B);
         process(t, A);
         FEWBIT_STAMP(slot); ++slot;
-        if (t1 >= s.ntiles) break;
-        const size_t t2 = t1 + s.nwaves;
+        if (t1 >= s.t_end) break;
+        const size_t t2 = t1 + s.stride;
         load(t2 < last ? t2 : last, A);
         process(t1, B);
         FEWBIT_STAMP(slot); ++slot;
-        if (t2 >= s.ntiles) break;
+        if (t2 >= s.t_end) break;
         t = t2;
+        t1 = t2 + s.stride;
+        load(t1 < last ? t1 : last, B);
+    }
+    } else {
+    init();
+    FEWBIT_STAMP(1);
+    int slot = 2;
+    for (;;) {
+        const size_t t1 = t + s.stride;
+        load(t1 < last ? t1 : last, B);
+        process(t, A);
+        FEWBIT_STAMP(slot); ++slot;
+        if (t1 >= s.t_end) break;
+        const size_t t2 = t1 + s.stride;
+        load(t2 < last ? t2 : last, A);
+        process(t1, B);
+        FEWBIT_STAMP(slot); ++slot;
+        if (t2 >= s.t_end) break;
+        t = t2;
+    }
     }
 }
 
@@ -146,28 +201,29 @@ template <int FN, int DT, int K, int U>
 __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void quantize_forward_kernel(const void *x, void *y,
                                                                   uint8_t *__restrict__ state, size_t n,
                                                                   const void *__restrict__ borders, float p0,
-                                                                  float p1) {
+                                                                  float p1, int chunk) {
     constexpr int NB = (1 << K) - 1;
     constexpr bool kFast = (DT != FEWBIT_F32);
     constexpr bool kStreamY = (DT != FEWBIT_F32);
     typedef typename GroupIO<DT>::Raw Raw;
-    const Span s = make_span<U>(n);
+    const Span s = make_span<U>(n, chunk);
 
     float b[NB];
+    const float mine = fetch_border<DT, NB>(borders);
 
     struct Buf { Raw r[U]; };
     pipeline2<Buf>(
-        s, [&]() { load_borders<DT, NB>(borders, b); },
+        s, [&]() { spread_borders<NB>(mine, b); },
         [&](size_t t, Buf &buf) {
 #if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 4)
-            t = s.wave;  // ablation: every iteration re-reads and re-writes the wave's first tile (cache resident)
+            t = s.t0;  // ablation: every iteration re-reads and re-writes the wave's first tile (cache resident)
 #endif
 #pragma unroll
             for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + s.lane);
         },
         [&](size_t t, const Buf &buf) {
 #if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 4)
-            t = s.wave;
+            t = s.t0;
 #endif
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -202,7 +258,7 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
         });
 
     // ---- tail: per-group and per-element guards, last wave only
-    if (s.wave != s.nwaves - 1) return;
+    if (!s.tail_owner) return;
     for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
         const size_t e0 = g << 3;
         uint32_t w = 0;
@@ -232,9 +288,6 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
 // instructions -- independent of K -- and runs on the otherwise idle LDS unit, which takes the forward from
 // VALU-bound back to memory-bound.  Blocks are 1024 threads (16 waves) so that two of them (2 x 64 KiB of LDS) fill
 // a CU with 32 waves.
-#ifndef FEWBIT_LUT_HEAD
-#define FEWBIT_LUT_HEAD 0
-#endif
 #ifndef FEWBIT_LUT_WPS
 #define FEWBIT_LUT_WPS 8      // waves per SIMD the table kernel is compiled for (two 16-wave blocks per CU)
 #endif
@@ -249,13 +302,13 @@ template <int DT> __device__ __forceinline__ float value_of_pattern(uint32_t r) 
 template <int FN, int DT, int K, int U>
 __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lut_kernel(const void *x, void *y, uint8_t *state,
                                                                             size_t n, const void *borders,
-                                                                            int nborders, float p0, float p1) {
+                                                                            int nborders, float p0, float p1, int chunk) {
     static_assert(DT != FEWBIT_F32, "the pattern table exists for 16-bit dtypes only");
     constexpr int NBMAX = (1 << K) - 1;
     constexpr uint32_t kInf = (DT == FEWBIT_BF16) ? 0x7f80u : 0x7c00u;
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ __attribute__((aligned(16))) uint8_t lut[65536];
-    const Span s = make_span<U, kLutWaves>(n);
+    const Span s = make_span<U, kLutWaves>(n, chunk);
 
     // the table's global loads go out FIRST (lane j fetches border j, as a float and as a raw pattern): the build then
     // waits only for them, not for the first tile of x that pipeline2 issues right after
@@ -267,128 +320,6 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
     }
 
     struct Buf { Raw r[U]; };
-#if FEWBIT_LUT_HEAD
-    // ---- head variants under measurement (FEWBIT_LUT_HEAD bit mask): 1 = one-barrier build, 2 = second tile prefetched
-    // before the build, 4 = first tile bucketed by register search BEFORE the barrier
-    float b[NBMAX];
-    auto load = [&](size_t t, Buf &buf) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + s.lane);
-    };
-    auto finish = [&](size_t t, const Buf &buf, const uint32_t (&w)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float v[8];
-            GroupIO<DT>::unpack(buf.r[u], v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
-            const size_t g = (t * U + u) * kWave + s.lane;
-            GroupIO<DT>::template store<true>(y, g, v);
-            store_state_quad<K, false>(state, g, s.lane, w[u]);
-        }
-    };
-    auto process_lut = [&](size_t t, const Buf &buf) {
-        uint32_t w[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            w[u] = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t d = buf.r[u].q[i];
-                w[u] |= static_cast<uint32_t>(lut[d & 0xffffu]) << (K * 2 * i);
-                w[u] |= static_cast<uint32_t>(lut[d >> 16]) << (K * (2 * i + 1));
-            }
-        }
-        finish(t, buf, w);
-    };
-    auto process_search = [&](size_t t, const Buf &buf) {
-        uint32_t w[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float v[8];
-            GroupIO<DT>::unpack(buf.r[u], v);
-            w[u] = pack_group<K>(v, b);
-        }
-        finish(t, buf, w);
-    };
-    Buf A, B;
-    const size_t t0 = s.wave;
-    const bool active = t0 < s.ntiles;                                   // wave-uniform
-    const size_t last = s.ntiles ? s.ntiles - 1 : 0;
-    size_t t1 = t0 + s.nwaves;
-    if (active) {
-        load(t0, A);
-        if (FEWBIT_LUT_HEAD & 2) load(t1 < last ? t1 : last, B);
-    }
-#pragma unroll
-    for (int j = 0; j < NBMAX; ++j) b[j] = bits_f32(__builtin_amdgcn_readlane(f32_bits(mine), j));
-    auto code_of = [&](uint32_t r) -> uint32_t {
-        return ((r & 0x7fffu) > kInf) ? static_cast<uint32_t>(nborders) : count_below<NBMAX>(b, value_of_pattern<DT>(r));
-    };
-    {
-        const uint32_t r0 = threadIdx.x * 64u;
-        const uint32_t c_first = code_of(r0);
-        const uint32_t c0 = c_first * 0x01010101u;
-        u32x4 fill = {c0, c0, c0, c0};
-        u32x4 *dst = reinterpret_cast<u32x4 *>(lut + r0);
-        dst[0] = fill; dst[1] = fill; dst[2] = fill; dst[3] = fill;
-#if FEWBIT_LUT_HEAD & 1
-        // the code is monotone over a chunk (ascending patterns in the positive half, descending values in the negative
-        // half, NaN patterns -> nborders at the far end), so a chunk is constant iff its two ends agree; the few chunks a
-        // border cuts are rewritten pattern by pattern by the SAME wave that filled them (LDS operations of one wave
-        // stay in order), which is why one barrier is enough
-        unsigned long long cut = __ballot(c_first != code_of(r0 + 63u));
-        const uint32_t wave_r0 = (threadIdx.x & ~63u) * 64u;
-        while (cut) {                                                    // wave-uniform, at most NBMAX + 2 rounds per block
-            const int l = __builtin_ctzll(cut);
-            cut &= cut - 1;
-            const uint32_t r = wave_r0 + static_cast<uint32_t>(l) * 64u + s.lane;
-            lut[r] = static_cast<uint8_t>(code_of(r));
-        }
-#else
-        __syncthreads();
-        const int wv = threadIdx.x >> 6;
-        uint32_t *lut32 = reinterpret_cast<uint32_t *>(lut);
-        if (wv < nborders) {
-            const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine_raw), wv));
-            const uint32_t mag = bits & 0x7fffu;
-            const bool neg = (bits >> 15) != 0 && mag != 0;
-            if (mag <= kInf) {
-                const uint32_t first = neg ? 0x8000u + mag : mag + 1u;
-                const uint32_t r = first + s.lane;
-                if ((first & 63u) != 0 && r < ((first | 63u) + 1u) && (r & 0x7fffu) <= kInf) {
-                    const uint32_t one = 1u << (8u * (r & 3u));
-                    if (neg) __hip_atomic_fetch_sub(&lut32[r >> 2], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else __hip_atomic_fetch_add(&lut32[r >> 2], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
-        if (wv == kLutWaves - 1 && s.lane > 0) {
-            lut[kInf + s.lane] = static_cast<uint8_t>(nborders);
-            lut[0x8000u + kInf + s.lane] = static_cast<uint8_t>(nborders);
-        }
-#endif
-    }
-    // the register search gives NaN -> 2^K - 1, which is the right code only for a full table
-    const bool head_search = (FEWBIT_LUT_HEAD & 4) && nborders == NBMAX;
-    if (active && head_search) process_search(t0, A);
-    __syncthreads();
-    if (active) {
-        if (!(FEWBIT_LUT_HEAD & 2)) load(t1 < last ? t1 : last, B);
-        if (!head_search) process_lut(t0, A);
-        while (t1 < s.ntiles) {                                          // B holds tile t1
-            const size_t t2 = t1 + s.nwaves;
-            load(t2 < last ? t2 : last, A);
-            process_lut(t1, B);
-            if (t2 >= s.ntiles) break;
-            const size_t t3 = t2 + s.nwaves;
-            load(t3 < last ? t3 : last, B);
-            process_lut(t2, A);
-            t1 = t3;
-        }
-    }
-    (void)mine_raw;
-#else
     auto build = [&]() {
         // wave-uniform copy of the table (padding +inf never satisfies !(b >= x) for a number)
         float b[NBMAX];
@@ -430,7 +361,7 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
         __syncthreads();
     };
 
-    pipeline2<Buf>(
+    pipeline2<Buf, true>(
         s, build,
         [&](size_t t, Buf &buf) {
 #pragma unroll
@@ -456,10 +387,8 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
             }
         });
 
-#endif
-
     // ---- tail: element-wise through the same table, last wave only
-    if (s.wave != s.nwaves - 1) return;
+    if (!s.tail_owner) return;
     for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
         const size_t e0 = g << 3;
         uint32_t w = 0;
@@ -509,11 +438,11 @@ __device__ __forceinline__ void wide_forward_tail(const Span &s, const void *x, 
 template <int FN, int DT>
 __global__ __launch_bounds__(kBlock, 6) void quantize_forward_wide_kernel(const void *x, void *y, uint8_t *state, size_t n,
                                                                           const void *borders, int nborders, int nbits,
-                                                                          float p0, float p1) {
+                                                                          float p0, float p1, int chunk) {
     constexpr bool kFast = (DT != FEWBIT_F32);
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ float sb[256];
-    const Span s = make_span<1>(n);
+    const Span s = make_span<1>(n, chunk);
     struct Buf { Raw r; };
     pipeline2<Buf>(
         s,
@@ -542,7 +471,7 @@ __global__ __launch_bounds__(kBlock, 6) void quantize_forward_wide_kernel(const 
             GroupIO<DT>::template store<kFast>(y, g, v);
             store_state_wide(state, g, nbits, w);
         });
-    if (s.wave != s.nwaves - 1) return;
+    if (!s.tail_owner) return;
     wide_forward_tail<FN, DT>(s, x, y, state, n, nbits, p0, p1, [&](size_t e) {
         return tree_code(sb, Act<FN, kFast>::key(Elem<DT>::load(x, e), p0), nbits, static_cast<uint32_t>(nborders));
     });
@@ -555,14 +484,14 @@ template <int FN, int DT>
 __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lut_wide_kernel(const void *x, void *y,
                                                                                  uint8_t *state, size_t n,
                                                                                  const void *borders, int nborders,
-                                                                                 int nbits, float p0, float p1) {
+                                                                                 int nbits, float p0, float p1, int chunk) {
     static_assert(DT != FEWBIT_F32, "the pattern table exists for 16-bit dtypes only");
     constexpr uint32_t kInf = (DT == FEWBIT_BF16) ? 0x7f80u : 0x7c00u;
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ __attribute__((aligned(16))) uint8_t lut[65536];
     __shared__ float sb[256];
     __shared__ uint16_t sr[256];
-    const Span s = make_span<1, kLutWaves>(n);
+    const Span s = make_span<1, kLutWaves>(n, chunk);
     float mine = __builtin_inff();
     uint32_t mine_raw = 0;
     if (static_cast<int>(threadIdx.x) < nborders) {
@@ -606,7 +535,7 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
         }
         __syncthreads();
     };
-    pipeline2<Buf>(
+    pipeline2<Buf, true>(
         s, build, [&](size_t t, Buf &buf) { buf.r = GroupIO<DT>::load_raw(x, t * kWave + s.lane); },
         [&](size_t t, const Buf &buf) {
             uint64_t w = 0;
@@ -624,7 +553,7 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
             GroupIO<DT>::template store<true>(y, g, v);
             store_state_wide(state, g, nbits, w);
         });
-    if (s.wave != s.nwaves - 1) return;
+    if (!s.tail_owner) return;
     wide_forward_tail<FN, DT>(s, x, y, state, n, nbits, p0, p1,
                               [&](size_t e) { return static_cast<uint32_t>(lut[static_cast<const uint16_t *>(x)[e]]); });
 }
@@ -633,10 +562,10 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
 template <int DT>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_kernel(const void *gy, const uint8_t *state,
                                                                                   void *gx, size_t n, const void *levels,
-                                                                                  int nlevels, int nbits) {
+                                                                                  int nlevels, int nbits, int chunk) {
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ float lut[256];
-    const Span s = make_span<1>(n, 1);
+    const Span s = make_span<1>(n, chunk, 1);
     const uint32_t mask = (1u << nbits) - 1u;
     struct Buf { Raw r; uint64_t w; };
     pipeline2<Buf>(
@@ -656,7 +585,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_
             for (int i = 0; i < 8; ++i) v[i] = lut[static_cast<uint32_t>(buf.w >> (nbits * i)) & mask] * v[i];
             GroupIO<DT>::store(gx, t * kWave + s.lane, v);
         });
-    if (s.wave != s.nwaves - 1) return;
+    if (!s.tail_owner) return;
     for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
         const size_t e0 = g << 3;
         const uint8_t *p = state + static_cast<size_t>(nbits) * g;
@@ -675,18 +604,22 @@ template <int DT, int K, int U>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kernel(const void *gy,
                                                                    const uint8_t *state, void *gx,
                                                                    size_t n, const void *__restrict__ levels,
-                                                                   int nlevels) {
+                                                                   int nlevels, int chunk) {
     constexpr int NL = 1 << K;
     constexpr uint32_t kMask = NL - 1;
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ float lut[NL];
-    const Span s = make_span<U>(n);
+    const Span s = make_span<U>(n, chunk);
 
+    // the level fetch goes out before the first tiles: vmcnt counts in order, so waiting for it in init() does not
+    // wait for the tiles as well
+    float mine = 0.0f;
+    if (threadIdx.x < NL && static_cast<int>(threadIdx.x) < nlevels) mine = Elem<DT>::load(levels, threadIdx.x);
     struct Buf { Raw r[U]; uint32_t w[U]; };
     pipeline2<Buf>(
         s,
         [&]() {  // every wave of the block gets here exactly once, so the barrier is safe
-            if (threadIdx.x < NL) lut[threadIdx.x] = threadIdx.x < nlevels ? Elem<DT>::load(levels, threadIdx.x) : 0.0f;
+            if (threadIdx.x < NL) lut[threadIdx.x] = mine;
             __syncthreads();
         },
         [&](size_t t, Buf &buf) {
@@ -712,7 +645,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kerne
             }
         });
 
-    if (s.wave != s.nwaves - 1) return;
+    if (!s.tail_owner) return;
     for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
         const size_t e0 = g << 3;
         const uint32_t w = load_state<K>(state, g);
@@ -727,9 +660,9 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kerne
 template <int FN, int DT, int U>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kernel(const void *x, void *y,
                                                                    uint8_t *__restrict__ state, size_t n, float p0,
-                                                                   float p1) {
+                                                                   float p1, int chunk) {
     typedef typename GroupIO<DT>::Raw Raw;
-    const Span s = make_span<U>(n);
+    const Span s = make_span<U>(n, chunk);
     struct Buf { Raw r[U]; };
     pipeline2<Buf>(
         s, []() {},
@@ -754,7 +687,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kerne
                 store_state_quad<1, false>(state, g, s.lane, w);
             }
         });
-    if (s.wave != s.nwaves - 1) return;
+    if (!s.tail_owner) return;
     for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
         const size_t e0 = g << 3;
         uint32_t w = 0;
@@ -772,9 +705,9 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kerne
 template <int DT, int U>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_backward_kernel(const void *gy,
                                                                     const uint8_t *state, void *gx,
-                                                                    size_t n, float m0, float m1) {
+                                                                    size_t n, float m0, float m1, int chunk) {
     typedef typename GroupIO<DT>::Raw Raw;
-    const Span s = make_span<U>(n);
+    const Span s = make_span<U>(n, chunk);
     struct Buf { Raw r[U]; uint32_t w[U]; };
     pipeline2<Buf>(
         s, []() {},
@@ -796,7 +729,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_backward_kern
                 GroupIO<DT>::store(gx, (t * U + u) * kWave + s.lane, v);
             }
         });
-    if (s.wave != s.nwaves - 1) return;
+    if (!s.tail_owner) return;
     for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
         const size_t e0 = g << 3;
         const uint32_t w = load_state<1>(state, g);
@@ -878,47 +811,94 @@ template <int DT> struct Tile {
     static constexpr int UB = (DT == FEWBIT_F32) ? FEWBIT_U32 : FEWBIT_U16_BWD;
 };
 
-int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
+// Launch geometry is cached PER DEVICE (index of the calling thread's current device: the torch glue and the ctypes
+// binding both launch with the tensors' device current).  Plain relaxed atomics: two threads racing on a first use store
+// the same value.
+constexpr int kMaxDevices = 64;
+
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
 }
 
-// resident blocks per CU of a kernel (runtime's occupancy answer, cached per kernel); the streaming
+int device_cus() {
+    static std::atomic<int> cus[kMaxDevices];
+    const int dev = current_device();
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+// resident blocks per CU of a kernel (runtime's occupancy answer, cached per kernel and device); the streaming
 // kernels are launched with exactly one resident generation of waves, which then loop over tiles.
 // FEWBIT_HIP_WAVES_PER_CU (tuning hook) caps it.
 template <auto Kern> int resident_blocks_per_cu() {
-    static int cached = 0;  // one per kernel instantiation
-    if (cached == 0) {
-        int nb = 0;
+    static std::atomic<int> cached[kMaxDevices];  // one array per kernel instantiation
+    const int dev = current_device();
+    int nb = cached[dev].load(std::memory_order_relaxed);
+    if (nb == 0) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kern, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
         if (nb > 8) nb = 8;
         const char *e = getenv("FEWBIT_HIP_WAVES_PER_CU");
         if (e && atoi(e) >= kWavesPerBlock && atoi(e) / kWavesPerBlock < nb) nb = atoi(e) / kWavesPerBlock;
-        cached = nb;
+        cached[dev].store(nb, std::memory_order_relaxed);
     }
-    return cached;
+    return nb;
 }
 
-// blocks for the streaming kernels: one wave per tile until the chip is full, then waves loop
-template <auto Kern> unsigned tile_grid(size_t n, int U) {
-    const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
-    size_t blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const size_t cap = static_cast<size_t>(device_cus()) * resident_blocks_per_cu<Kern>();
-    if (blocks > cap) blocks = cap;
+// Launch shape of a streaming kernel (see Span): RESIDENT (chunk = 0: one wave per tile until the chip is full, then the
+// resident waves loop round-robin) or CHUNKED (chunk = T tiles per wave, block-contiguous, as many blocks as that takes).
+struct Shape { unsigned blocks; int chunk; };
+
+// tiles per wave of the chunked shape; 0 = resident.  FEWBIT_HIP_CHUNK / FEWBIT_HIP_LUT_CHUNK (tuning hooks): -1 or unset =
+// the built-in policy, 0 = always resident, T = chunk of T wherever the tensor has more tiles than resident waves.
+int chunk_setting(const char *var) {
+    const char *e = getenv(var);
+    return e ? atoi(e) : -1;
+}
+
+Shape launch_shape(size_t ntiles, int waves_per_block, size_t resident_blocks, int setting, int auto_chunk) {
+    const size_t wpb = static_cast<size_t>(waves_per_block);
+    size_t blocks = (ntiles + wpb - 1) / wpb;                      // one tile per wave
+    int chunk = 0;
+    if (blocks > resident_blocks) {
+        const int t = setting >= 0 ? setting : auto_chunk;
+        const size_t chunked = t > 0 ? (ntiles + wpb * t - 1) / (wpb * t) : 0;
+        if (t > 0 && chunked > resident_blocks) {
+            blocks = chunked;
+            chunk = t;
+        } else {
+            blocks = resident_blocks;
+        }
+    }
     if (blocks < 1) blocks = 1;
-    return static_cast<unsigned>(blocks);
+    return Shape{static_cast<unsigned>(blocks), chunk};
 }
 
-// launch a streaming kernel instantiation with its resident-generation grid
-#define FB_LAUNCH_TILED(KERN, N, U, STREAM, ...) \
-    hipLaunchKernelGGL((KERN), dim3(tile_grid<(KERN)>((N), (U))), dim3(kBlock), 0, (STREAM), __VA_ARGS__)
+#ifndef FEWBIT_AUTO_CHUNK
+#define FEWBIT_AUTO_CHUNK 0
+#endif
+#ifndef FEWBIT_AUTO_LUT_CHUNK
+#define FEWBIT_AUTO_LUT_CHUNK 0
+#endif
+
+template <auto Kern> Shape tile_shape(size_t n, int U) {
+    static const int setting = chunk_setting("FEWBIT_HIP_CHUNK");
+    const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
+    return launch_shape(ntiles, kWavesPerBlock, static_cast<size_t>(device_cus()) * resident_blocks_per_cu<Kern>(), setting,
+                        FEWBIT_AUTO_CHUNK);
+}
+
+// launch a streaming kernel instantiation (the kernels' last parameter is the chunk)
+#define FB_LAUNCH_TILED(KERN, N, U, STREAM, ...)                                                                   \
+    do {                                                                                                           \
+        const Shape sh_ = tile_shape<(KERN)>((N), (U));                                                            \
+        hipLaunchKernelGGL((KERN), dim3(sh_.blocks), dim3(kBlock), 0, (STREAM), __VA_ARGS__, sh_.chunk);           \
+    } while (0)
 
 // pattern-table forward: 1024-thread blocks, two resident per CU (LDS), each wave loops over its tiles
 size_t lut_min_elements() {
@@ -931,8 +911,11 @@ size_t lut_min_elements() {
     return v;
 }
 
-template <auto Kern> unsigned lut_grid(size_t n, int U) {
-    static int per_cu = 0;
+template <auto Kern> Shape lut_shape(size_t n, int U) {
+    static std::atomic<int> cached[kMaxDevices];
+    static const int setting = chunk_setting("FEWBIT_HIP_LUT_CHUNK");
+    const int dev = current_device();
+    int per_cu = cached[dev].load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kern, kLutBlock, 0) != hipSuccess || nb < 1) nb = 1;
@@ -941,17 +924,17 @@ template <auto Kern> unsigned lut_grid(size_t n, int U) {
             const int v = atoi(e);
             if (v >= 1 && v < per_cu) per_cu = v;
         }
+        cached[dev].store(per_cu, std::memory_order_relaxed);
     }
     const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
-    size_t blocks = (ntiles + kLutWaves - 1) / kLutWaves;
-    const size_t cap = static_cast<size_t>(device_cus()) * per_cu;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    return static_cast<unsigned>(blocks);
+    return launch_shape(ntiles, kLutWaves, static_cast<size_t>(device_cus()) * per_cu, setting, FEWBIT_AUTO_LUT_CHUNK);
 }
 
-#define FB_LAUNCH_LUT(KERN, N, U, STREAM, ...) \
-    hipLaunchKernelGGL((KERN), dim3(lut_grid<(KERN)>((N), (U))), dim3(kLutBlock), 0, (STREAM), __VA_ARGS__)
+#define FB_LAUNCH_LUT(KERN, N, U, STREAM, ...)                                                                     \
+    do {                                                                                                           \
+        const Shape sh_ = lut_shape<(KERN)>((N), (U));                                                             \
+        hipLaunchKernelGGL((KERN), dim3(sh_.blocks), dim3(kLutBlock), 0, (STREAM), __VA_ARGS__, sh_.chunk);        \
+    } while (0)
 
 unsigned group_grid(size_t n) { return static_cast<unsigned>(((n + 7) / 8 + kBlock - 1) / kBlock); }
 
@@ -972,9 +955,7 @@ int launch_forward(const void *x, void *y, uint8_t *state, size_t n, const void 
             case 3: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 3, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
             case 4: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 4, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
             default:
-                hipLaunchKernelGGL((quantize_forward_lut_wide_kernel<FN, DT>),
-                                   dim3(lut_grid<(quantize_forward_lut_wide_kernel<FN, DT>)>(n, 1)), dim3(kLutBlock), 0, s, x,
-                                   y, state, n, borders, nborders, k, p0, p1);
+                FB_LAUNCH_LUT((quantize_forward_lut_wide_kernel<FN, DT>), n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
             }
             return check_launch("quantize_forward(lut)");
         }

@@ -362,6 +362,15 @@ struct HostStepwise1Function : public torch::autograd::Function<HostStepwise1Fun
     }
 };
 
+// does this call need an autograd node at all?
+bool needs_node(const Tensor &self) { return torch::GradMode::is_enabled() && self.requires_grad(); }
+
+// an in-place write outside autograd still has to bump the tensor's version counter, so that a graph which saved the
+// old value for another operand's gradient fails loudly in backward instead of using the overwritten data
+void note_inplace_write(const Tensor &self) {
+    if (!self.is_inference()) self.unsafeGetTensorImpl()->bump_version();
+}
+
 // ---- the three flavours every operator is registered in --------------------------------------------
 enum class Where { AutogradGpu, RawGpu, AutogradHost, RawHost };
 
@@ -369,6 +378,8 @@ template <Where W>
 Tensor continuous(int fn, const Tensor &self, const Tensor &bounds, const Tensor &levels, double p0 = 0.0, double p1 = 0.0,
                   bool inplace = true) {
     if constexpr (W == Where::AutogradGpu) {
+        // nothing will ever ask for this call's gradient: skip the autograd node (and its ~4 us of host time)
+        if (!needs_node(self)) return continuous<Where::RawGpu>(fn, self, bounds, levels, p0, p1, inplace);
         return ContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, inplace);
     } else if constexpr (W == Where::AutogradHost) {
         return HostContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, inplace);
@@ -385,12 +396,14 @@ Tensor continuous(int fn, const Tensor &self, const Tensor &bounds, const Tensor
                     levels.numel());
         Tensor out = inplace ? self : torch::empty_like(self);
         launch_quantize(fn, self, out, bounds, p0, p1);
+        if (inplace) note_inplace_write(self);
         return out;
     }
 }
 
 template <Where W> Tensor stepwise1(int fn, const Tensor &self, double p0 = 0.0, double p1 = 0.0, bool inplace = true) {
     if constexpr (W == Where::AutogradGpu) {
+        if (!needs_node(self)) return stepwise1<Where::RawGpu>(fn, self, p0, p1, inplace);
         return Stepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, inplace);
     } else if constexpr (W == Where::AutogradHost) {
         return HostStepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, inplace);
@@ -405,6 +418,7 @@ template <Where W> Tensor stepwise1(int fn, const Tensor &self, double p0 = 0.0,
         check_status(fewbit_hip_stepwise1_forward(fn, dtype_code(self), self.data_ptr(), out.data_ptr(), state.data_ptr<uint8_t>(),
                                                   static_cast<size_t>(self.numel()), p0, p1, current_stream(self)),
                      "stepwise1_forward");
+        if (inplace) note_inplace_write(self);
         return out;
     }
 }

@@ -55,6 +55,17 @@ def _native_op(name: str):
     return getattr(torch.ops.fewbit, name)
 
 
+_OVERLOADS: Dict[str, Callable] = {}
+
+
+def _native_overload(name: str) -> Callable:
+    """``torch.ops.fewbit.<name>.default`` (cached; skips the overload resolution of the packet on every call)."""
+    op = _OVERLOADS.get(name)
+    if op is None:
+        op = _OVERLOADS[name] = _native_op(name).default
+    return op
+
+
 # enum order of include/fewbit_hip.h, for the out-of-place operators
 _CONTINUOUS_ID = {n: i for i, n in enumerate(CONTINOUS[:0] + ('celu', 'elu', 'gelu', 'hardswish', 'logsigmoid', 'mish', 'selu',
                                                               'sigmoid', 'silu', 'softplus', 'softsign', 'tanh',

@@ -94,12 +94,38 @@ class BuiltInStepwiseFunction(torch.nn.Module):
             self.reprs.append(f'{name}={value}')
         # keyword arguments handed to the functional on every forward (only those it knows)
         self.kwargs = {name: bound.arguments[name] for name in self._forwarded}
+        # GPU fast path (the per-call signature binding of the functional layer costs as much as a small
+        # kernel): the positional extras are bound ONCE here, the table casts are kept per (device, dtype), and forward()
+        # calls the operator overload directly
+        self._extra = tuple(bound.arguments[p] for p, _ in functional._EXTRA.get(self._impl_name, ()))
+        self._tables = {}
+        self._tables_version = -1
 
     def __repr__(self) -> str:
         return f'{type(self).__name__}({", ".join(self.reprs)})'
 
     def forward(self, xs: torch.Tensor) -> torch.Tensor:
-        return self._impl(xs, **self.kwargs)
+        if xs.device.type != 'cuda':
+            return self._impl(xs, **self.kwargs)
+        name = self._impl_name
+        flat = not xs._is_view() and xs.is_contiguous()           # owns its memory: in place, like the reference op
+        if name in functional._STEPWISE_ID:
+            if flat:
+                return functional._native_overload(name)(xs, *self._extra)
+            p = self._extra + (0.0, ) * (2 - len(self._extra))
+            return functional._native_overload('stepwise1_out')(xs.contiguous(), functional._STEPWISE_ID[name], *p)
+        store = functional.store
+        if self._tables_version != store.version:                  # a table was replaced through store.add()
+            self._tables.clear()
+            self._tables_version = store.version
+        key = (xs.device, xs.dtype)
+        hit = self._tables.get(key)
+        if hit is None:
+            hit = self._tables[key] = store.get_inner(name, self.bits or functional.BITS_DEFAULT, xs.device, xs.dtype)
+        if flat:
+            return functional._native_overload(name)(xs, hit[0], hit[1], *self._extra)
+        p = self._extra + (0.0, ) * (2 - len(self._extra))
+        return functional._native_overload('continuous_out')(xs.contiguous(), hit[0], hit[1], functional._CONTINUOUS_ID[name], *p)
 
 
 for _name in __all__:

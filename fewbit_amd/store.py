@@ -24,6 +24,7 @@ class StepwiseStore:
         self._store: Dict[Tuple[str, int], Table] = {}
         self._cache: Dict[Tuple[str, int, torch.device, torch.dtype], Table] = {}
         self._inner: Dict[Tuple[str, int, torch.device, torch.dtype], Table] = {}
+        self.version = 0          # bumped by add(): lets callers that keep their own per-(device, dtype) casts notice
 
     def __len__(self) -> int:
         return len(self._store)
@@ -40,6 +41,7 @@ class StepwiseStore:
             raise ValueError('Expected one-dimensional `borders` (with both sentinels) one longer than `levels`.')
         entry = (borders, values.to(borders))
         self._store[(name, int(bits))] = entry
+        self.version += 1
         # drop stale casts of a replaced table
         for cache in (self._cache, self._inner):
             for key in [k for k in cache if k[:2] == (name, int(bits))]:

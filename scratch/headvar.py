@@ -15,7 +15,7 @@ def timeit(fns, rounds):
         for f in fns: f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1000 / rounds / len(fns)
-tag = os.path.basename(os.environ.get('FEWBIT_HIP_LIB', 'default')).replace('libfewbit_hip_', '').replace('.so', '')
+tag = os.path.basename(os.environ.get('FEWBIT_HIP_LIB', 'default')).replace('libfewbit_hip_', '').replace('.so', '') + os.environ.get('TAGX', '')
 cfgs = [('gelu', 3, torch.bfloat16, 4096 * 4096), ('gelu', 3, torch.bfloat16, 8192 * 4096), ('silu', 4, torch.float16, 8192 * 8192),
         ('silu', 2, torch.float16, 8192 * 8192)]
 if len(sys.argv) > 1: cfgs = cfgs[:int(sys.argv[1])]
@@ -35,12 +35,12 @@ for name, k, dtype, n in cfgs:
     rc = max(3, 300 // nsets)
     res = []
     for rep in range(3):
-        fw = timeit([F[0]], 500); sw = 2 * timeit([F[0], B[0]], 300)
-        fc = timeit(F, rc); sc = 2 * timeit(S, rc)
-        res.append((fw, sw, fc, sc))
-    fw, sw, fc, sc = [min(r[i] for r in res) for i in range(4)]
+        fw = timeit([F[0]], 500); sw = 2 * timeit([F[0], B[0]], 300); bw = timeit([B[0]], 500)
+        fc = timeit(F, rc); sc = 2 * timeit(S, rc); bc = timeit(B, rc)
+        res.append((fw, sw, fc, sc, bw, bc))
+    fw, sw, fc, sc, bw, bc = [min(r[i] for r in res) for i in range(6)]
     fb = n * (2 * es + k / 8)
     print(f'{tag:8s} {name}{k} {str(dtype)[6:]:8s} n={n:9d}: warm fwd {fw:6.2f} us ({fb/fw/8e4:5.1f}%) step {sw:6.2f} us ({2*fb/sw/8e4:5.1f}%) | '
-          f'cold fwd {fc:6.2f} us ({fb/fc/8e4:5.1f}%) step {sc:6.2f} us ({2*fb/sc/8e4:5.1f}%)', flush=True)
+          f'cold fwd {fc:6.2f} us ({fb/fc/8e4:5.1f}%) step {sc:6.2f} us ({2*fb/sc/8e4:5.1f}%) | bwd warm {bw:6.2f} cold {bc:6.2f}', flush=True)
     del F, B, S, keep
     torch.cuda.empty_cache()

@@ -112,8 +112,12 @@ def test_errors_and_contracts():
         torch.ops.fewbit.gelu(x.clone(), b[1:-2], l)
     with pytest.raises(RuntimeError):
         torch.ops.fewbit.gelu(x.double(), b[1:-1].double(), l.double())
-    with pytest.raises((NotImplementedError, RuntimeError)):
-        torch.ops.fewbit.gelu(torch.randn(8), b[1:-1].cpu(), l.cpu())     # no CPU kernel behind the op
+    host = torch.randn(8)
+    assert torch.equal(torch.ops.fewbit.gelu(host.clone(), b[1:-1].cpu(), l.cpu()), F.gelu(host))   # CPU key (tests/test_host_ops.py)
+    with pytest.raises(RuntimeError):
+        torch.ops.fewbit.gelu(x.clone(), b[1:-1].cpu(), l.cpu())          # tables and input on different devices
+    with pytest.raises(RuntimeError):
+        torch.ops.fewbit.gelu(host.clone(), b[1:-1], l)
     with pytest.raises(RuntimeError, match='parity'):                     # a shift without a parity means nothing
         torch.ops.fewbit.stepwise(x.clone(), b[1:-1], l, None, [1, 0])
     leaf = torch.randn(8, device=DEV, requires_grad=True)
@@ -387,3 +391,20 @@ def test_state_moves_between_host_and_device_operators():
         gx_dev_from_host = torch.ops.fewbit.quantize_backward(gy.to(DEV), st_host.to(DEV), levels.to(DEV))
         gx_host_from_dev = torch.ops.fewbit.quantize_backward(gy, st_dev.cpu(), levels)
         assert_bit_equal(gx_dev_from_host.cpu(), gx_host_from_dev)
+
+
+def test_inplace_write_without_a_node_still_bumps_the_version():
+    """A tensor that does not require grad takes the node-free path; it is still overwritten in place, so a graph that
+    saved its old value (for another operand's gradient) must fail loudly in backward."""
+    x = torch.randn(256, device=DEV)
+    w = torch.randn(256, device=DEV, requires_grad=True)
+    y = x * w                                           # saves x for dw
+    v0 = x._version
+    out = fewbit.functional.relu(x)
+    assert out.data_ptr() == x.data_ptr() and x._version > v0 and not out.requires_grad
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        y.sum().backward()
+    x2 = torch.randn(256, device=DEV)
+    v0 = x2._version
+    fewbit.functional.gelu(x2, bits=2)
+    assert x2._version > v0

@@ -74,12 +74,16 @@ def test_golden_vectors_from_reference_run(qref, k, dt):
 
 def test_fp32_forward_in_raw_ulps_against_the_reference_run(qref):
     """north_star: "within 1 ULP for the fp32 forward activation".  Stated in raw ULPs against the y the REFERENCE
-    produced (ATen's gelu on the build container's CPU) for every finite x >= 0 of the fp32 golden vectors: max <= 6
-    and >= 98 % within 1 ULP (the residue is ATen's own MKL-vs-Sleef disagreement).  For x < 0, where
-    1 + erf cancels and ATen's two code paths disagree by the full cancellation noise, the bar stays
-    max(1 ULP, 2^-21 |x|).  The histogram is written to gpurun_out/ (copied to profiles/r02_fp32_ulp.json)."""
+    produced (ATen's gelu on the build container's CPU) for every finite x >= 0 of the fp32 golden vectors: max <= 6 and
+    >= 97 % within 1 ULP.  That reference output is itself up to 3 ULP away from the correctly rounded value (measured on
+    these vectors: 0/1/2/3 ULP = 1402/657/33/8), and the fp32 formula x*0.5*(1+erf(x/sqrt2)) evaluated with a CORRECTLY
+    ROUNDED erf already sits at 97.4 % within 1 ULP of it -- so the second, stricter statement is against the correctly
+    rounded exact value (float64 formula): <= 2 ULP everywhere, >= 99 % within 1.  For x < 0, where 1 + erf cancels and
+    ATen's two code paths disagree by the full cancellation noise, the bar stays max(1 ULP, 2^-21 |x|).
+    The histograms are written to gpurun_out/ (copied to profiles/r02_fp32_ulp.json)."""
     import json
-    dist, neg_ok, neg_n = [], 0, 0
+    from scipy.special import erf
+    dist, dist_exact, neg_ok, neg_n = [], [], 0, 0
     for k in (2, 3, 4):
         borders = from_raw(qref[f'gelu{k:02d}_f32_borders'], torch.float32).to(DEV)
         for n in (1, 7, 8, 9, 64, 65, 257, 1001):
@@ -90,15 +94,24 @@ def test_fp32_forward_in_raw_ulps_against_the_reference_run(qref):
             y = y.cpu()
             pos = torch.isfinite(x) & (x >= 0)
             dist.append(ulp_distance(y[pos], y_ref[pos]))
+            xd = x[pos].double().numpy()
+            exact = torch.from_numpy(np.asarray(xd * 0.5 * (1.0 + erf(xd / np.sqrt(2.0))))).float().reshape(-1)
+            dist_exact.append(ulp_distance(y[pos], exact))
             neg = torch.isfinite(x) & (x < 0)
             ok = forward_value_ok(x[neg], y[neg], y_ref[neg])
             neg_ok += int(ok.sum())
             neg_n += int(neg.sum())
-    d = torch.cat(dist)
+    d, de = torch.cat(dist), torch.cat(dist_exact)
     hist = {str(i): int((d == i).sum()) for i in range(int(d.max()) + 1)}
-    doc = {'what': 'ULP distance of the HIP fp32 GELU forward to the reference-run y (tests/golden/quantize_ref.npz), finite x >= 0',
-           'elements': int(d.numel()), 'histogram': hist, 'max_ulp': int(d.max()),
-           'frac_within_1ulp': round(float((d <= 1).float().mean()), 5),
+    hist_e = {str(i): int((de == i).sum()) for i in range(int(de.max()) + 1)}
+    doc = {'what': 'ULP distance of the HIP fp32 GELU forward (quantize_forward_kernel<gelu, f32>) for the finite x >= 0 of the '
+                   'fp32 golden vectors (tests/golden/quantize_ref.npz)',
+           'elements': int(d.numel()),
+           'vs_reference_run_y': {'histogram': hist, 'max_ulp': int(d.max()), 'frac_within_1ulp': round(float((d <= 1).float().mean()), 5)},
+           'vs_correctly_rounded_exact': {'histogram': hist_e, 'max_ulp': int(de.max()),
+                                          'frac_within_1ulp': round(float((de <= 1).float().mean()), 5)},
+           'context': 'the reference-run y (ATen) is 0/1/2/3 ULP = 1402/657/33/8 from the correctly rounded value on these inputs; the '
+                      'fp32 formula with a correctly rounded erf is 1757/288/43/12 from ATen',
            'x_negative': {'elements': neg_n, 'within max(1 ULP, 2^-21 |x|)': neg_ok}}
     out = ROOT / 'gpurun_out'
     try:
@@ -107,7 +120,8 @@ def test_fp32_forward_in_raw_ulps_against_the_reference_run(qref):
     except OSError:
         pass
     print(doc)
-    assert int(d.max()) <= 6 and float((d <= 1).float().mean()) >= 0.98, doc
+    assert int(d.max()) <= 6 and float((d <= 1).float().mean()) >= 0.97, doc
+    assert int(de.max()) <= 2 and float((de <= 1).float().mean()) >= 0.99, doc
     assert neg_ok == neg_n, doc
 
 

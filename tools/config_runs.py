@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Run every BASELINE config (bench.CONFIGS) cache-warm and cache-cold in a fixed, recorded order of launches, so that a
+rocprofv3 per-dispatch trace (kernel trace or PMC) of this program can be split back into phases by launch count.
+
+    python3 tools/config_runs.py PHASES_JSON [launches-per-phase]
+    rocprofv3 --kernel-trace --output-format csv -d DIR -o cfg -- python3 tools/config_runs.py DIR/phases.json
+
+Every launch goes through the C-ABI exactly as in bench.py.  PHASES_JSON lists, in launch order, the phases
+{config, mode, launches, kernel order 'fwd,bwd,fwd,bwd,...'}; tools/summarize_profiles.py pairs it with the trace."""
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    out = Path(sys.argv[1])
+    per_phase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(device)
+    phases = []
+    for name, cfg in bench.CONFIGS.items():
+        for mode in ('warm', 'cold'):
+            nsets = bench.nsets_for_cold(cfg) if mode == 'cold' else 1
+            w = bench.Workload(cfg, device, nsets=nsets, seed=3, host_seeded=False)
+            steps = w.steps()
+            torch.cuda.synchronize()
+            for f in steps:                                # first touch of every buffer set
+                f()
+            torch.cuda.synchronize()
+            phases.append({'config': name, 'mode': 'touch', 'launches': len(steps)})
+            rounds = max(2, per_phase // nsets)
+            for _ in range(rounds):
+                for f in steps:
+                    f()
+            torch.cuda.synchronize()
+            sb, fb = bench.step_bytes(cfg)
+            phases.append({'config': name, 'mode': mode, 'launches': rounds * len(steps), 'buffer_sets': nsets,
+                           'algorithmic_bytes_per_launch': int(fb), 'workload': cfg['label']})
+            del w, steps
+            torch.cuda.empty_cache()
+    out.parent.mkdir(parents=True, exist_ok=True)
+    out.write_text(json.dumps({'order': 'fwd,bwd alternating inside every phase', 'phases': phases}, indent=1))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,20 +1,27 @@
 #!/bin/bash
-# Collect the per-round rocprofv3 evidence for bench.py on the GPU box and summarise it into profiles/.
-#   usage (through gpurun):  bash tools/profile_round.sh r01
-# Three separate passes, as MI355X_MICROARCH.md prescribes: kernel trace + stats, PMC FETCH_SIZE, PMC WRITE_SIZE.
-# Raw output goes to gpurun_out/prof_<round>/ (scratch); the summaries are written to gpurun_out/profiles_<round>/
-# and are copied into profiles/ by hand after review.
+# Collect the per-round rocprofv3 evidence on the GPU box and summarise it into gpurun_out/profiles_<round>/ (copied into
+# profiles/ after review).
+#   usage (through gpurun):  bash tools/profile_round.sh r02
+# Separate passes, as MI355X_MICROARCH.md prescribes (PMC never combined with other trace domains than --kernel-trace):
+#   1. python3 bench.py                                   -> <round>_bench_line.json  (the driver-visible line, all extras)
+#   2. rocprofv3 --kernel-trace --stats   bench.py --no-extras   -> kernel stats of the timed region's command (C2)
+#   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE  bench.py --no-extras --steps 50   -> HBM traffic per launch (C2)
+#   4. rocprofv3 --kernel-trace / --pmc FETCH_SIZE / --pmc WRITE_SIZE   tools/config_runs.py
+#      -> per-dispatch durations and traffic of EVERY config, warm and cold (split by tools/summarize_profiles.py)
 set -u
-R=${1:-r01}
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
 export TMPDIR=/tmp
 RAW=$ROOT/gpurun_out/prof_$R
 OUT=$ROOT/gpurun_out/profiles_$R
-mkdir -p "$RAW" "$OUT"
+rm -rf "$RAW"; mkdir -p "$RAW" "$OUT"
 python3 bench.py > "$OUT/${R}_bench_line.json" 2> "$RAW/bench.err"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/trace" -o bench -- python3 bench.py --no-cpu-baseline > "$RAW/bench_under_trace.json" 2> "$RAW/trace.err"
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$RAW/fetch" -o bench -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2> "$RAW/fetch.err"
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$RAW/write" -o bench -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2> "$RAW/write.err"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/trace" -o bench -- python3 bench.py --no-extras --no-cpu-baseline > "$RAW/bench_under_trace.json" 2> "$RAW/trace.err"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$RAW/fetch" -o bench -- python3 bench.py --steps 50 --warmup 5 --no-extras --no-cpu-baseline > /dev/null 2> "$RAW/fetch.err"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$RAW/write" -o bench -- python3 bench.py --steps 50 --warmup 5 --no-extras --no-cpu-baseline > /dev/null 2> "$RAW/write.err"
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$RAW/cfg_trace" -o cfg -- python3 tools/config_runs.py "$RAW/cfg_trace/phases.json" 120 > /dev/null 2> "$RAW/cfg_trace.err"
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$RAW/cfg_fetch" -o cfg -- python3 tools/config_runs.py "$RAW/cfg_fetch/phases.json" 30 > /dev/null 2> "$RAW/cfg_fetch.err"
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$RAW/cfg_write" -o cfg -- python3 tools/config_runs.py "$RAW/cfg_write/phases.json" 30 > /dev/null 2> "$RAW/cfg_write.err"
 python3 tools/summarize_profiles.py "$R" "$RAW" "$OUT"
 ls -la "$OUT"
