@@ -137,18 +137,21 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
         init();
         return;
     }
-    const size_t last = s.ntiles - 1;
+    // a prefetch past the wave's own tiles is redirected to ONE tile shared by every wave of the launch (the tensor's
+    // last tile: always hot in every L2, the data is dropped) -- not to a tile of its own (evicted by then: a real
+    // extra read, measured +1 us at 4096x4096) and not past the chunk into a neighbour's tiles
+    const size_t hot = s.ntiles - 1;
     FEWBIT_STAMP(0);
     load(t, A);
     if constexpr (EARLY) {
     // head: BOTH buffers are requested before init() (table build / LDS staging + barrier), so that the memory system
     // has two tiles per wave in flight while the block sets itself up (pattern-table forward 12.0 -> 11.2 us at
     // 4096x4096 bf16; bucketing the first tile by register search ahead of the barrier, or building the table with one
-    // barrier, did not help: DESIGN.md section 6).  Prefetches are unconditional (clamped to the last tile, whose data
+    // barrier, did not help: DESIGN.md section 6).  Prefetches are unconditional (redirected to `hot` past the end, the data
     // is then simply dropped): a load issued on only one path would make the s_waitcnt in front of process() count for
     // the shorter path and wait for the prefetch itself.
     size_t t1 = t + s.stride;
-    load(t1 < last ? t1 : last, B);
+    load(t1 < s.t_end ? t1 : hot, B);
     init();
     FEWBIT_STAMP(1);
     int slot = 2;
@@ -157,13 +160,13 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
         FEWBIT_STAMP(slot); ++slot;
         if (t1 >= s.t_end) break;
         const size_t t2 = t1 + s.stride;
-        load(t2 < last ? t2 : last, A);
+        load(t2 < s.t_end ? t2 : hot, A);
         process(t1, B);
         FEWBIT_STAMP(slot); ++slot;
         if (t2 >= s.t_end) break;
         t = t2;
         t1 = t2 + s.stride;
-        load(t1 < last ? t1 : last, B);
+        load(t1 < s.t_end ? t1 : hot, B);
     }
     } else {
     init();
@@ -171,12 +174,12 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
     int slot = 2;
     for (;;) {
         const size_t t1 = t + s.stride;
-        load(t1 < last ? t1 : last, B);
+        load(t1 < s.t_end ? t1 : hot, B);
         process(t, A);
         FEWBIT_STAMP(slot); ++slot;
         if (t1 >= s.t_end) break;
         const size_t t2 = t1 + s.stride;
-        load(t2 < last ? t2 : last, A);
+        load(t2 < s.t_end ? t2 : hot, A);
         process(t1, B);
         FEWBIT_STAMP(slot); ++slot;
         if (t2 >= s.t_end) break;
@@ -861,12 +864,18 @@ int chunk_setting(const char *var) {
     return e ? atoi(e) : -1;
 }
 
-Shape launch_shape(size_t ntiles, int waves_per_block, size_t resident_blocks, int setting, int auto_chunk) {
+// Built-in policy (measured on MI355X, scratch/headvar.py with SIZES=...): the resident shape wins
+// while a wave has only a few tiles (4096x4096 bf16: 11.2 vs 11.6 us), the chunked shape wins once the tensor is many
+// times the resident generation, where statically assigned waves drift apart and the launch waits for the slowest
+// (2^28 bf16 elements: backward 235 -> 197 us, pattern-table forward 224 -> 197 us; RoBERTa-size fp32, 5*10^7 elements:
+// forward+backward 169 -> 151 us).  `min_ratio` = tiles per resident wave from which the chunked shape is used.
+Shape launch_shape(size_t ntiles, int waves_per_block, size_t resident_blocks, int setting, int auto_chunk, size_t min_ratio) {
     const size_t wpb = static_cast<size_t>(waves_per_block);
     size_t blocks = (ntiles + wpb - 1) / wpb;                      // one tile per wave
     int chunk = 0;
     if (blocks > resident_blocks) {
-        const int t = setting >= 0 ? setting : auto_chunk;
+        int t = setting;
+        if (t < 0) t = ntiles >= min_ratio * resident_blocks * wpb ? auto_chunk : 0;
         const size_t chunked = t > 0 ? (ntiles + wpb * t - 1) / (wpb * t) : 0;
         if (t > 0 && chunked > resident_blocks) {
             blocks = chunked;
@@ -879,18 +888,27 @@ Shape launch_shape(size_t ntiles, int waves_per_block, size_t resident_blocks, i
     return Shape{static_cast<unsigned>(blocks), chunk};
 }
 
+// search / backward / 1-bit kernels (cheap per-block setup): one tile per wave from 4 tiles per resident wave up;
+// pattern-table forward (64 KiB table per block): three tiles per wave (an odd count: chunks of a power-of-two size start
+// every block on the same memory channels, T = 4 measured 5-15 % slower than T = 3) from 12 tiles per resident wave up
 #ifndef FEWBIT_AUTO_CHUNK
-#define FEWBIT_AUTO_CHUNK 0
+#define FEWBIT_AUTO_CHUNK 1
+#endif
+#ifndef FEWBIT_AUTO_CHUNK_RATIO
+#define FEWBIT_AUTO_CHUNK_RATIO 4
 #endif
 #ifndef FEWBIT_AUTO_LUT_CHUNK
-#define FEWBIT_AUTO_LUT_CHUNK 0
+#define FEWBIT_AUTO_LUT_CHUNK 3
+#endif
+#ifndef FEWBIT_AUTO_LUT_CHUNK_RATIO
+#define FEWBIT_AUTO_LUT_CHUNK_RATIO 12
 #endif
 
 template <auto Kern> Shape tile_shape(size_t n, int U) {
     static const int setting = chunk_setting("FEWBIT_HIP_CHUNK");
     const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
     return launch_shape(ntiles, kWavesPerBlock, static_cast<size_t>(device_cus()) * resident_blocks_per_cu<Kern>(), setting,
-                        FEWBIT_AUTO_CHUNK);
+                        FEWBIT_AUTO_CHUNK, FEWBIT_AUTO_CHUNK_RATIO);
 }
 
 // launch a streaming kernel instantiation (the kernels' last parameter is the chunk)
@@ -927,7 +945,8 @@ template <auto Kern> Shape lut_shape(size_t n, int U) {
         cached[dev].store(per_cu, std::memory_order_relaxed);
     }
     const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
-    return launch_shape(ntiles, kLutWaves, static_cast<size_t>(device_cus()) * per_cu, setting, FEWBIT_AUTO_LUT_CHUNK);
+    return launch_shape(ntiles, kLutWaves, static_cast<size_t>(device_cus()) * per_cu, setting, FEWBIT_AUTO_LUT_CHUNK,
+                        FEWBIT_AUTO_LUT_CHUNK_RATIO);
 }
 
 #define FB_LAUNCH_LUT(KERN, N, U, STREAM, ...)                                                                     \

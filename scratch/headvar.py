@@ -19,8 +19,10 @@ tag = os.path.basename(os.environ.get('FEWBIT_HIP_LIB', 'default')).replace('lib
 cfgs = [('gelu', 3, torch.bfloat16, 4096 * 4096), ('gelu', 3, torch.bfloat16, 8192 * 4096), ('silu', 4, torch.float16, 8192 * 8192),
         ('silu', 2, torch.float16, 8192 * 8192)]
 if len(sys.argv) > 1: cfgs = cfgs[:int(sys.argv[1])]
+DT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[os.environ.get('DT', 'bf16')]
+if os.environ.get('SIZES'): cfgs = [('gelu', 3, DT, int(v)) for v in os.environ['SIZES'].split(',')]
 for name, k, dtype, n in cfgs:
-    es = 2
+    es = torch.empty(0, dtype=dtype).element_size()
     per_set = n * (4 * es + k / 8)
     nsets = max(3, int(1.25 * 2**30 / per_set) + 1)
     bo, lv = store.get(name, k, dev, dtype); bo = bo[1:-1].contiguous()

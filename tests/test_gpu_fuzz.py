@@ -121,3 +121,54 @@ def test_fuzz_pattern_table_sizes():
         y, st = cabi.quantize_forward('gelu', xd, inner.to(DEV), state=sbuf[off:off + nbytes])
         assert_bit_equal(st.cpu(), s_o, f'{dt} nlev={nlev} n={n}')
         assert sbuf[:off].sum().item() == 0 and sbuf[off + nbytes:].sum().item() == 0
+
+
+RAGGED_LARGE = (4_194_304 + 512 * 37 + 5, 8_650_003, 13_000_001, 17_825_792 + 8 * 63 + 7)
+
+
+@pytest.mark.skipif('FEWBIT_SHAPE_WORKER' not in __import__('os').environ, reason='worker of test_every_launch_shape_at_ragged_large_sizes')
+def test_shape_worker():
+    """Tensors larger than one resident generation (so that a forced chunk setting really changes the launch shape), ragged
+    ends, every kernel family; expectations are computed independently on the GPU with torch (bucketize / gather) and
+    with the non-streaming codec kernel, plus an oracle window over the ragged end."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for n in RAGGED_LARGE:
+        for dtype in (torch.bfloat16, torch.float32):
+            for name, k in (('gelu', 3), ('silu', 4)):
+                from fewbit_amd.store import store
+                borders, levels = store.get(name, k, DEV, dtype)
+                inner = borders[1:-1].contiguous()
+                x = (torch.randn(n, generator=g, device=DEV) * 1.5).to(dtype)
+                gy = torch.randn(n, generator=g, device=DEV).to(dtype)
+                y, state = cabi.quantize_forward(name, x, inner)
+                codes = torch.bucketize(x.float(), inner.float(), out_int32=True)
+                assert torch.equal(state, cabi.pack_codes(codes, k)), (n, dtype, name)
+                gx = cabi.quantize_backward(gy, state, levels)
+                want = (levels.float()[codes.long()] * gy.float()).to(dtype)
+                assert_bit_equal(gx, want, f'gx {n} {dtype} {name}')
+                tail = slice(n - 4099, n)                                   # oracle over the ragged end
+                y_o, s_o, _ = oracle.quantize(name, x[tail].cpu(), inner.cpu())
+                assert forward_value_ok(x[tail].cpu(), y[tail].cpu(), y_o).all()
+                head = slice(0, 8 * 1000)
+                y_o, s_o, _ = oracle.quantize(name, x[head].cpu(), inner.cpu())
+                assert torch.equal(state[:k * 1000].cpu(), s_o)
+        x = torch.randn(n, generator=g, device=DEV)
+        gy = torch.randn(n, generator=g, device=DEV)
+        y, st = cabi.stepwise1_forward('relu', x)
+        assert torch.equal(y, torch.relu(x)) and torch.equal(st, cabi.pack_codes((x > 0).to(torch.int32), 1))
+        assert torch.equal(cabi.stepwise1_backward('relu', gy, st), torch.where(x > 0, gy, torch.zeros_like(gy)))
+
+
+@pytest.mark.parametrize('setting', ('0', '1', '2', '3', '5'))
+def test_every_launch_shape_at_ragged_large_sizes(setting):
+    """The streaming kernels have two launch shapes (resident round-robin / chunked, fewbit_kernels.hip `Span`) and a
+    built-in policy that picks by tensor size.  Here the shape is forced through the tuning hooks (read once per process,
+    hence the subprocess): 0 = always resident, T = chunks of T tiles per wave wherever the tensor has more tiles than
+    resident waves -- every kernel family, ragged ends, partial last chunks."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, FEWBIT_HIP_CHUNK=setting, FEWBIT_HIP_LUT_CHUNK=setting, FEWBIT_SHAPE_WORKER='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', __file__, '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        '-k', 'test_shape_worker'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -9,6 +9,7 @@ Every launch goes through the C-ABI exactly as in bench.py.  PHASES_JSON lists, 
 {config, mode, launches, kernel order 'fwd,bwd,fwd,bwd,...'}; tools/summarize_profiles.py pairs it with the trace."""
 import json
 import sys
+import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -17,6 +18,9 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+
+
+SETTLE_S = 0.04
 
 
 def main():
@@ -34,7 +38,16 @@ def main():
             for f in steps:                                # first touch of every buffer set
                 f()
             torch.cuda.synchronize()
-            phases.append({'config': name, 'mode': 'touch', 'launches': len(steps)})
+            launches = len(steps)
+            # untimed settle: the GPU's clocks dip 1.5-10 ms after load begins (scratch/timeline.py); run the same
+            # launches until the device has been busy ~40 ms, counted into the same 'touch' phase
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < SETTLE_S:
+                for f in steps:
+                    f()
+                launches += len(steps)
+                torch.cuda.synchronize()
+            phases.append({'config': name, 'mode': 'touch', 'launches': launches})
             rounds = max(2, per_phase // nsets)
             for _ in range(rounds):
                 for f in steps:
