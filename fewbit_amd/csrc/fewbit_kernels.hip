@@ -793,6 +793,46 @@ int check_launch(const char *what) {
 }
 
 
+// FEWBIT_HIP_VALIDATE=1 (debug aid, off by default: two runtime queries per pointer): every pointer handed to the
+// C-ABI must be device memory and [p, p + bytes) must lie inside its allocation -- a host pointer or a state buffer
+// sized with the wrong bit width then fails with FEWBIT_ERR_INVALID_ARGUMENT instead of a fault on the GPU.
+bool validate_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("FEWBIT_HIP_VALIDATE");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
+
+int validate_range(const char *what, const void *p, size_t bytes) {
+    if (!validate_enabled() || bytes == 0) return FEWBIT_OK;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FEWBIT_ERR_INVALID_ARGUMENT, "%s (%p) is not a pointer known to the HIP runtime", what, p);
+    }
+    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
+        return fail(FEWBIT_ERR_INVALID_ARGUMENT, "%s (%p) is not device memory", what, p);
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, const_cast<void *>(p)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FEWBIT_ERR_INVALID_ARGUMENT, "%s (%p): no allocation found", what, p);
+    }
+    const size_t off = static_cast<size_t>(static_cast<const char *>(p) - static_cast<const char *>(base));
+    if (off + bytes > size)
+        return fail(FEWBIT_ERR_INVALID_ARGUMENT, "%s needs %zu bytes but only %zu remain in its allocation", what, bytes, size - off);
+    return FEWBIT_OK;
+}
+
+size_t dtype_size(int dtype) { return dtype == FEWBIT_F32 ? 4 : 2; }
+
+#define FB_VALIDATE(WHAT, P, BYTES)                                  \
+    do {                                                             \
+        const int rc_ = validate_range((WHAT), (P), (BYTES));        \
+        if (rc_ != FEWBIT_OK) return rc_;                            \
+    } while (0)
+
 // groups per lane per pipeline stage (tunable, FEWBIT_HIP_U) and resident waves per CU the grid is
 // sized for (FEWBIT_HIP_WAVES_PER_CU); defaults from measurements on MI355X, see DESIGN.md
 #ifndef FEWBIT_U16
@@ -1069,6 +1109,11 @@ int fewbit_hip_quantize_forward(int fn, int dtype, const void *x, void *y, uint8
     if (n == 0) return FEWBIT_OK;
     if (!x || !y || !state || !borders) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
     const int k = fewbit_hip_bitwidth(nborders + 1);
+    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    FB_VALIDATE("x", x, n * dtype_size(dtype));
+    FB_VALIDATE("y", y, n * dtype_size(dtype));
+    FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, k));
+    FB_VALIDATE("borders", borders, static_cast<size_t>(nborders) * dtype_size(dtype));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float a = static_cast<float>(p0), b = static_cast<float>(p1);
 #define FB_CASE(F) case F: return dispatch_forward_dtype<F>(dtype, x, y, state, n, borders, nborders, k, a, b, s);
@@ -1088,6 +1133,11 @@ int fewbit_hip_quantize_backward(int dtype, const void *gy, const uint8_t *state
     if (n == 0) return FEWBIT_OK;
     if (!gy || !gx || !state || !levels) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
     const int k = fewbit_hip_bitwidth(nlevels);
+    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    FB_VALIDATE("gy", gy, n * dtype_size(dtype));
+    FB_VALIDATE("gx", gx, n * dtype_size(dtype));
+    FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, k));
+    FB_VALIDATE("levels", levels, static_cast<size_t>(nlevels) * dtype_size(dtype));
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (dtype) {
     case FEWBIT_F32: return launch_backward<FEWBIT_F32>(gy, state, gx, n, levels, nlevels, k, s);
@@ -1101,6 +1151,10 @@ int fewbit_hip_stepwise1_forward(int fn, int dtype, const void *x, void *y, uint
                                  double p1, void *stream) {
     if (n == 0) return FEWBIT_OK;
     if (!x || !y || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    FB_VALIDATE("x", x, n * dtype_size(dtype));
+    FB_VALIDATE("y", y, n * dtype_size(dtype));
+    FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, 1));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float a = static_cast<float>(p0), b = static_cast<float>(p1);
 #define FB_CASE(F) case F: return dispatch_step1_dtype<F>(dtype, x, y, state, n, a, b, s);
@@ -1117,6 +1171,10 @@ int fewbit_hip_stepwise1_backward(int fn, int dtype, const void *gy, const uint8
     if (fn < 0 || fn >= FEWBIT_STEPWISE_COUNT) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown stepwise fn %d", fn);
     if (n == 0) return FEWBIT_OK;
     if (!gy || !gx || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    FB_VALIDATE("gy", gy, n * dtype_size(dtype));
+    FB_VALIDATE("gx", gx, n * dtype_size(dtype));
+    FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, 1));
     float m0 = 0.0f, m1 = 1.0f;
     if (fn == FEWBIT_HARDSIGMOID) m1 = 1.0f / 6.0f;
     if (fn == FEWBIT_LEAKY_RELU) { m0 = 1.0f; m1 = static_cast<float>(p0); }
@@ -1140,6 +1198,8 @@ int fewbit_hip_pack_codes(const int32_t *codes, uint8_t *state, size_t n, int nb
     if (nbits < 1 || nbits > 8) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "nbits=%d outside [1,8]", nbits);
     if (n == 0) return FEWBIT_OK;
     if (!codes || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+    FB_VALIDATE("codes", codes, n * sizeof(int32_t));
+    FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, nbits));
     hipLaunchKernelGGL(pack_codes_kernel, dim3(group_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), codes,
                        state, n, nbits);
     return check_launch("pack_codes");
@@ -1149,6 +1209,8 @@ int fewbit_hip_unpack_codes(const uint8_t *state, int32_t *codes, size_t n, int 
     if (nbits < 1 || nbits > 8) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "nbits=%d outside [1,8]", nbits);
     if (n == 0) return FEWBIT_OK;
     if (!codes || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+    FB_VALIDATE("codes", codes, n * sizeof(int32_t));
+    FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, nbits));
     hipLaunchKernelGGL(unpack_codes_kernel, dim3(group_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        state, codes, n, nbits);
     return check_launch("unpack_codes");

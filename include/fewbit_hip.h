@@ -31,6 +31,11 @@
  * Differences from the reference launchers, all additive: fp16/bf16 I/O besides
  * fp32, 64-bit element counts, an explicit stream, and error returns.
  *
+ * Pointers are trusted by default (no runtime query on the launch path).  With
+ * FEWBIT_HIP_VALIDATE=1 in the environment every pointer is checked to be
+ * device memory and every buffer to extend far enough inside its allocation;
+ * violations return FEWBIT_ERR_INVALID_ARGUMENT.
+ *
  * Packed state layout (identical to the reference): element i occupies bits
  * [k*i, k*(i+1)) of one little-endian, LSB-first bitstream, so every 8
  * consecutive elements map to exactly k bytes.  The state buffer is

@@ -408,3 +408,39 @@ def test_inplace_write_without_a_node_still_bumps_the_version():
     v0 = x2._version
     fewbit.functional.gelu(x2, bits=2)
     assert x2._version > v0
+
+
+def test_c_abi_validation_mode():
+    """FEWBIT_HIP_VALIDATE=1 (read once per process, hence the subprocess): host pointers and under-sized buffers are
+    refused with an error code and a message instead of faulting on the GPU; valid calls still run."""
+    import subprocess
+    import sys
+    import textwrap
+    from helpers import ROOT
+    code = textwrap.dedent('''
+        import ctypes, sys, torch
+        sys.path.insert(0, %r)
+        from fewbit_amd import cabi
+        L = cabi.lib()
+        x = torch.randn(4096, device='cuda'); y = torch.empty_like(x)
+        b = torch.tensor([-1.0, 0.0, 1.0], device='cuda')
+        st = torch.empty(cabi.state_nbytes(4096, 2), dtype=torch.uint8, device='cuda')
+        s = torch.cuda.current_stream().cuda_stream
+        call = lambda xp, yp, sp, bp: L.fewbit_hip_quantize_forward(2, 0, xp, yp, sp, 4096, bp, 3, 0.0, 0.0, s)
+        assert call(x.data_ptr(), y.data_ptr(), st.data_ptr(), b.data_ptr()) == 0
+        host = torch.randn(4096)
+        assert call(host.data_ptr(), y.data_ptr(), st.data_ptr(), b.data_ptr()) == -1
+        assert b'x' in L.fewbit_hip_last_error() and b'device' in L.fewbit_hip_last_error()
+        small = torch.empty(100, dtype=torch.uint8, device='cuda')
+        assert call(x.data_ptr(), y.data_ptr(), small.data_ptr(), b.data_ptr()) == -1
+        assert b'state needs 1024 bytes' in L.fewbit_hip_last_error(), L.fewbit_hip_last_error()
+        lv = torch.tensor([0.0, 0.3, 0.7, 1.0], device='cuda')
+        assert L.fewbit_hip_quantize_backward(0, x.data_ptr(), st.data_ptr(), y.data_ptr(), 4096, lv.data_ptr(), 4, s) == 0
+        assert L.fewbit_hip_quantize_backward(0, x.data_ptr(), st.data_ptr(), y.data_ptr(), 8192, lv.data_ptr(), 4, s) == -1
+        torch.cuda.synchronize()
+        print('validated')
+    ''' % str(ROOT))
+    import os
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, FEWBIT_HIP_VALIDATE='1'), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and 'validated' in r.stdout, r.stdout + r.stderr
