@@ -33,7 +33,8 @@
  *
  * Pointers are trusted by default (no runtime query on the launch path).  With
  * FEWBIT_HIP_VALIDATE=1 in the environment every pointer is checked to be
- * device memory and every buffer to extend far enough inside its allocation;
+ * device memory and every buffer to extend far enough inside its allocation
+ * (the underlying hipMalloc: sub-blocks of a caching allocator share one);
  * violations return FEWBIT_ERR_INVALID_ARGUMENT.
  *
  * Packed state layout (identical to the reference): element i occupies bits

@@ -431,12 +431,20 @@ def test_c_abi_validation_mode():
         host = torch.randn(4096)
         assert call(host.data_ptr(), y.data_ptr(), st.data_ptr(), b.data_ptr()) == -1
         assert b'x' in L.fewbit_hip_last_error() and b'device' in L.fewbit_hip_last_error()
-        small = torch.empty(100, dtype=torch.uint8, device='cuda')
-        assert call(x.data_ptr(), y.data_ptr(), small.data_ptr(), b.data_ptr()) == -1
+        # extents are those of the underlying hipMalloc (a caching allocator's sub-blocks share one): allocate directly
+        hip = ctypes.CDLL('libamdhip64.so')
+        small = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(small), ctypes.c_size_t(100)) == 0
+        assert call(x.data_ptr(), y.data_ptr(), small.value, b.data_ptr()) == -1
         assert b'state needs 1024 bytes' in L.fewbit_hip_last_error(), L.fewbit_hip_last_error()
+        hip.hipFree(small)
         lv = torch.tensor([0.0, 0.3, 0.7, 1.0], device='cuda')
         assert L.fewbit_hip_quantize_backward(0, x.data_ptr(), st.data_ptr(), y.data_ptr(), 4096, lv.data_ptr(), 4, s) == 0
-        assert L.fewbit_hip_quantize_backward(0, x.data_ptr(), st.data_ptr(), y.data_ptr(), 8192, lv.data_ptr(), 4, s) == -1
+        big = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(big), ctypes.c_size_t(4096 * 4)) == 0
+        assert L.fewbit_hip_quantize_backward(0, big.value, st.data_ptr(), y.data_ptr(), 4096, lv.data_ptr(), 4, s) == 0
+        assert L.fewbit_hip_quantize_backward(0, big.value, st.data_ptr(), y.data_ptr(), 8192, lv.data_ptr(), 4, s) == -1
+        assert b'gy needs' in L.fewbit_hip_last_error()
         torch.cuda.synchronize()
         print('validated')
     ''' % str(ROOT))
