@@ -959,14 +959,17 @@ template <auto Kern> Shape tile_shape(size_t n, int U) {
     } while (0)
 
 // pattern-table forward: 1024-thread blocks, two resident per CU (LDS), each wave loops over its tiles
-size_t lut_min_elements() {
-    static size_t v = 0;
-    if (v == 0) {
-        const char *e = getenv("FEWBIT_HIP_LUT_MIN");       // tuning hook; a huge value disables the kernel
-        v = e ? static_cast<size_t>(atoll(e)) : (static_cast<size_t>(6) << 20);   // measured crossover: 2^22 search wins, 2^23 table wins
-        if (v == 0) v = 1;
-    }
-    return v;
+// Smallest tensor that takes it: building the table costs the same whatever the table, the register search it replaces
+// costs 2^k - 1 + k slow-class VALU per element -- measured crossover (scratch/xover.py, round 2): 6 Mi elements for
+// k <= 3 (6.39 vs 6.43 us), 4.5 Mi for k = 4 (5 Mi: 6.48 vs 6.68 us).  FEWBIT_HIP_LUT_MIN (tuning hook) overrides both; a
+// huge value disables the kernel.
+size_t lut_min_elements(int k) {
+    static const long long forced = [] {
+        const char *e = getenv("FEWBIT_HIP_LUT_MIN");
+        return e ? atoll(e) : -1ll;
+    }();
+    if (forced >= 0) return forced == 0 ? 1 : static_cast<size_t>(forced);
+    return k == 4 ? (static_cast<size_t>(9) << 19) : (static_cast<size_t>(6) << 20);
 }
 
 template <auto Kern> Shape lut_shape(size_t n, int U) {
@@ -1006,7 +1009,7 @@ int launch_forward(const void *x, void *y, uint8_t *state, size_t n, const void 
     if constexpr (DT != FEWBIT_F32 && FN != FEWBIT_IDENTITY_FOLD) {
         // 16-bit dtypes, any table (power of two or not): pattern-table kernel once the tensor is big enough to pay for
         // building the table in every block
-        if (n >= lut_min_elements()) {
+        if (n >= lut_min_elements(k)) {
             constexpr int UL = FEWBIT_U16_LUT;
             switch (k) {
             case 1: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 1, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;

@@ -452,3 +452,50 @@ def test_c_abi_validation_mode():
     r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, FEWBIT_HIP_VALIDATE='1'), capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0 and 'validated' in r.stdout, r.stdout + r.stderr
+
+
+def test_concurrent_streams_and_threads():
+    """The library keeps no per-call global state: launches from several host threads on several streams at once (first
+    use of the per-device launch-geometry caches included, when this test runs alone) give the same bytes as serial
+    launches."""
+    import threading
+    from fewbit_amd import cabi
+    from fewbit_amd.store import store
+    sizes = (8 * 1024 * 1024 + 13, 1_000_003, 4096, 6 * 1024 * 1024 + 512)
+    work = []
+    for i, n in enumerate(sizes):
+        dtype = (torch.bfloat16, torch.float32, torch.float16, torch.bfloat16)[i]
+        g = torch.Generator().manual_seed(100 + i)
+        x = (torch.randn(n, generator=g) * 1.5).to(dtype).to(DEV)
+        gy = torch.randn(n, generator=g).to(dtype).to(DEV)
+        b, l = store.get('gelu', 3, DEV, dtype)
+        work.append((x, gy, b[1:-1].contiguous(), l))
+    serial = []
+    for x, gy, b, l in work:
+        y, st = cabi.quantize_forward('gelu', x, b)
+        serial.append((y, st, cabi.quantize_backward(gy, st, l)))
+    torch.cuda.synchronize()
+    out, errors = [None] * len(work), []
+
+    def run(i):
+        try:
+            s = torch.cuda.Stream(device=DEV)
+            x, gy, b, l = work[i]
+            with torch.cuda.stream(s):
+                for _ in range(20):
+                    y, st = cabi.quantize_forward('gelu', x, b, stream=s.cuda_stream)
+                    gx = cabi.quantize_backward(gy, st, l, stream=s.cuda_stream)
+            s.synchronize()
+            out[i] = (y, st, gx)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(work))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for (y0, s0, g0), (y1, s1, g1) in zip(serial, out):
+        assert torch.equal(s0, s1)
+        assert torch.equal(y0.view(torch.uint8), y1.view(torch.uint8)) and torch.equal(g0.view(torch.uint8), g1.view(torch.uint8))
