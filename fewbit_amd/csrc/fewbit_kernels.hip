@@ -137,12 +137,14 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
         init();
         return;
     }
-    // a prefetch past the wave's own tiles is redirected to ONE tile shared by every wave of the launch (the tensor's
-    // last tile: always hot in every L2, the data is dropped) -- not to a tile of its own (evicted by then: a real
-    // extra read, measured +1 us at 4096x4096) and not past the chunk into a neighbour's tiles
+    // a prefetch past the wave's own tiles is redirected to ONE 16-byte piece shared by every wave of the launch (lane 0's
+    // piece of the tensor's last tile, requested by all 64 lanes: one cache line, always hot, the data is dropped) --
+    // not to a tile of its own (evicted by then: a real extra read, measured +1 us at 4096x4096), not past the chunk into
+    // a neighbour's tiles, and not to a whole hot tile either (1-2 KiB of L2 -> L1 fill per wave for nothing: with one or
+    // two tiles per wave that is as much fill traffic again as the real reads)
     const size_t hot = s.ntiles - 1;
     FEWBIT_STAMP(0);
-    load(t, A);
+    load(t, s.lane, A);
     if constexpr (EARLY) {
     // head: BOTH buffers are requested before init() (table build / LDS staging + barrier), so that the memory system
     // has two tiles per wave in flight while the block sets itself up (pattern-table forward 12.0 -> 11.2 us at
@@ -151,7 +153,7 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
     // is then simply dropped): a load issued on only one path would make the s_waitcnt in front of process() count for
     // the shorter path and wait for the prefetch itself.
     size_t t1 = t + s.stride;
-    load(t1 < s.t_end ? t1 : hot, B);
+    load(t1 < s.t_end ? t1 : hot, t1 < s.t_end ? s.lane : 0, B);
     init();
     FEWBIT_STAMP(1);
     int slot = 2;
@@ -160,13 +162,13 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
         FEWBIT_STAMP(slot); ++slot;
         if (t1 >= s.t_end) break;
         const size_t t2 = t1 + s.stride;
-        load(t2 < s.t_end ? t2 : hot, A);
+        load(t2 < s.t_end ? t2 : hot, t2 < s.t_end ? s.lane : 0, A);
         process(t1, B);
         FEWBIT_STAMP(slot); ++slot;
         if (t2 >= s.t_end) break;
         t = t2;
         t1 = t2 + s.stride;
-        load(t1 < s.t_end ? t1 : hot, B);
+        load(t1 < s.t_end ? t1 : hot, t1 < s.t_end ? s.lane : 0, B);
     }
     } else {
     init();
@@ -174,12 +176,12 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
     int slot = 2;
     for (;;) {
         const size_t t1 = t + s.stride;
-        load(t1 < s.t_end ? t1 : hot, B);
+        load(t1 < s.t_end ? t1 : hot, t1 < s.t_end ? s.lane : 0, B);
         process(t, A);
         FEWBIT_STAMP(slot); ++slot;
         if (t1 >= s.t_end) break;
         const size_t t2 = t1 + s.stride;
-        load(t2 < s.t_end ? t2 : hot, A);
+        load(t2 < s.t_end ? t2 : hot, t2 < s.t_end ? s.lane : 0, A);
         process(t1, B);
         FEWBIT_STAMP(slot); ++slot;
         if (t2 >= s.t_end) break;
@@ -217,12 +219,12 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
     struct Buf { Raw r[U]; };
     pipeline2<Buf>(
         s, [&]() { spread_borders<NB>(mine, b); },
-        [&](size_t t, Buf &buf) {
+        [&](size_t t, int ln, Buf &buf) {
 #if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 4)
             t = s.t0;  // ablation: every iteration re-reads and re-writes the wave's first tile (cache resident)
 #endif
 #pragma unroll
-            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + s.lane);
+            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + ln);
         },
         [&](size_t t, const Buf &buf) {
 #if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 4)
@@ -366,9 +368,9 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
 
     pipeline2<Buf, true>(
         s, build,
-        [&](size_t t, Buf &buf) {
+        [&](size_t t, int ln, Buf &buf) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + s.lane);
+            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + ln);
         },
         [&](size_t t, const Buf &buf) {
 #pragma unroll
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(kBlock, 6) void quantize_forward_wide_kernel(const 
             sb[threadIdx.x] = static_cast<int>(threadIdx.x) < nborders ? Elem<DT>::load(borders, threadIdx.x) : __builtin_inff();
             __syncthreads();
         },
-        [&](size_t t, Buf &buf) { buf.r = GroupIO<DT>::load_raw(x, t * kWave + s.lane); },
+        [&](size_t t, int ln, Buf &buf) { buf.r = GroupIO<DT>::load_raw(x, t * kWave + ln); },
         [&](size_t t, const Buf &buf) {
             float v[8];
             GroupIO<DT>::unpack(buf.r, v);
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
         __syncthreads();
     };
     pipeline2<Buf, true>(
-        s, build, [&](size_t t, Buf &buf) { buf.r = GroupIO<DT>::load_raw(x, t * kWave + s.lane); },
+        s, build, [&](size_t t, int ln, Buf &buf) { buf.r = GroupIO<DT>::load_raw(x, t * kWave + ln); },
         [&](size_t t, const Buf &buf) {
             uint64_t w = 0;
 #pragma unroll
@@ -577,9 +579,9 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_
             lut[threadIdx.x] = static_cast<int>(threadIdx.x) < nlevels ? Elem<DT>::load(levels, threadIdx.x) : 0.0f;
             __syncthreads();
         },
-        [&](size_t t, Buf &buf) {
-            buf.r = GroupIO<DT>::load_raw(gy, t * kWave + s.lane);
-            buf.w = load_state_wide(state, t * kWave + s.lane, nbits);
+        [&](size_t t, int ln, Buf &buf) {
+            buf.r = GroupIO<DT>::load_raw(gy, t * kWave + ln);
+            buf.w = load_state_wide(state, t * kWave + ln, nbits);
         },
         [&](size_t t, const Buf &buf) {
             float v[8];
@@ -625,11 +627,11 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kerne
             if (threadIdx.x < NL) lut[threadIdx.x] = mine;
             __syncthreads();
         },
-        [&](size_t t, Buf &buf) {
+        [&](size_t t, int ln, Buf &buf) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + s.lane);
-                buf.w[u] = load_state_quad_raw<K>(state, (t * U + u) * kWave + s.lane, s.lane);
+                buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + ln);
+                buf.w[u] = load_state_quad_raw<K>(state, (t * U + u) * kWave + ln, ln);
             }
         },
         [&](size_t t, const Buf &buf) {
@@ -669,9 +671,9 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kerne
     struct Buf { Raw r[U]; };
     pipeline2<Buf>(
         s, []() {},
-        [&](size_t t, Buf &buf) {
+        [&](size_t t, int ln, Buf &buf) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + s.lane);
+            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + ln);
         },
         [&](size_t t, const Buf &buf) {
 #pragma unroll
@@ -714,11 +716,11 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_backward_kern
     struct Buf { Raw r[U]; uint32_t w[U]; };
     pipeline2<Buf>(
         s, []() {},
-        [&](size_t t, Buf &buf) {
+        [&](size_t t, int ln, Buf &buf) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + s.lane);
-                buf.w[u] = load_state_quad_raw<1>(state, (t * U + u) * kWave + s.lane, s.lane);
+                buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + ln);
+                buf.w[u] = load_state_quad_raw<1>(state, (t * U + u) * kWave + ln, ln);
             }
         },
         [&](size_t t, const Buf &buf) {
