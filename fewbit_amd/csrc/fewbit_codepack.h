@@ -204,4 +204,28 @@ template <int K> __device__ __forceinline__ uint32_t pack_group(const float (&x)
     return w;
 }
 
+// packed K-bit codes of HALF a group (4 elements), element i in bits [K*i, K*i+K): the fp32 split layout packs the two
+// halves of a group in two neighbouring lanes (fewbit_device.h, SplitF32)
+template <int K> __device__ __forceinline__ uint32_t pack_half(const float (&x)[4], const float (&b)[(1 << K) - 1]) {
+    uint32_t w = 0;
+#if !defined(FEWBIT_CXX_BUCKET)
+    if constexpr (K == 1) {
+        w = push4_k1(w, x[3], x[2], x[1], x[0], b[0]);
+    } else if constexpr (K == 2) {
+        w = push2_k2(w, x[3], x[2], b);
+        w = push2_k2(w, x[1], x[0], b);
+    } else if constexpr (K == 3) {
+        w = push2_k3(w, x[3], x[2], b);
+        w = push2_k3(w, x[1], x[0], b);
+    } else {
+#pragma unroll
+        for (int i = 3; i >= 0; --i) w = push1_k4(w, x[i], b);
+    }
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w |= bucket<K>(b, x[i]) << (K * i);
+#endif
+    return w;
+}
+
 }  // namespace fewbit_hip

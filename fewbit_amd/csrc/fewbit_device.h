@@ -168,6 +168,38 @@ template <> struct GroupIO<FEWBIT_F16> {
     }
 };
 
+// ------------------------------------------------------------------ fp32 tiles in the SPLIT layout
+// GroupIO<FEWBIT_F32> gives lane l the 32 contiguous bytes of group l as two 16 B accesses at a 32 B lane stride: every
+// wave instruction touches 2 KiB and uses every other 16 B piece of it -- twice the cache lines per instruction, and
+// stores that only L2 write-combining turns into full lines (so no nontemporal stores).  In the split layout a tile of 64
+// groups (2 KiB) is moved by two fully contiguous 1 KiB instructions: lane l takes 16 B piece l and piece 64 + l, i.e.
+// HALF (l & 1) of group l/2 and the same half of group 32 + l/2.  Values need no exchange at all (they are stored back
+// the way they came); only the 4K-bit half-words of codes cross lanes: one DPP move per half pairs them up with the
+// neighbouring lane's, and one ds_bpermute puts the word of group t into lane t, where the quad state I/O expects it
+// (and takes it from there in the backward).
+#ifndef FEWBIT_F32_SPLIT
+#define FEWBIT_F32_SPLIT 1
+#endif
+struct SplitF32 {
+    struct Raw { f32x4 a, b; };
+    // g = first group of the tile + ln (ln = lane, or 0 for the collapsed redirect of pipeline2)
+    static __device__ __forceinline__ Raw load_raw(const void *base, size_t g, int ln) {
+        const float *p = static_cast<const float *>(base) + 8 * (g - ln) + 4 * ln;
+        return Raw{load_as<4, f32x4>(p), load_as<4, f32x4>(p + 256)};
+    }
+    static __device__ __forceinline__ void unpack(const Raw &r, float (&v)[8]) {
+        v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w;      // half (lane & 1) of group  lane/2
+        v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;      // the same half of group 32 + lane/2
+    }
+    template <bool NT>
+    static __device__ __forceinline__ void store(void *base, size_t g, int lane, const float (&v)[8]) {
+        float *p = static_cast<float *>(base) + 8 * (g - lane) + 4 * lane;
+        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        store_as<NT, 4>(p, a);
+        store_as<NT, 4>(p + 256, b);
+    }
+};
+
 // ------------------------------------------------------------------ packed state access, one group
 // K bytes at byte offset K*g.
 template <int K> __device__ __forceinline__ void store_state(uint8_t *state, size_t g, uint32_t w) {
@@ -255,6 +287,28 @@ template <int K> __device__ __forceinline__ uint32_t load_state_quad_fix(uint32_
         const uint32_t b = quad_perm<FEWBIT_QUAD_PERM(1, 1, 2, 2)>(raw);
         return __builtin_amdgcn_alignbit(b, a, (24 * i) & 31);
     } else return raw;
+}
+
+// ------------------------------------------------------------------ split layout: half-words <-> group words
+// forward: this lane's two 4K-bit half-words (cA: its half of group lane/2, cB: its half of group 32 + lane/2) -> the
+// 8K-bit word of group `lane`
+template <int K> __device__ __forceinline__ uint32_t split_halves_to_word(uint32_t cA, uint32_t cB, int lane) {
+    const uint32_t pA = quad_perm<FEWBIT_QUAD_PERM(1, 0, 3, 2)>(cA), pB = quad_perm<FEWBIT_QUAD_PERM(1, 0, 3, 2)>(cB);
+    const bool odd = (lane & 1) != 0;
+    // even lanes offer the word of group lane/2, odd lanes the word of group 32 + lane/2
+    const uint32_t lo = odd ? pB : cA, hi = odd ? cB : pA;
+    const uint32_t z = lo | (hi << (4 * K));
+    const int src = ((2 * lane) & 63) | (lane >> 5);       // lane t < 32 reads lane 2t, lane t >= 32 reads 2(t-32)+1
+    return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src * 4, static_cast<int>(z)));
+}
+
+// backward: the word of group `lane` (bits above 8K may be junk) -> this lane's two half-words (junk above 4K bits)
+template <int K> __device__ __forceinline__ void split_word_to_halves(uint32_t w, int lane, uint32_t &cA, uint32_t &cB) {
+    const uint32_t wA = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane >> 1) * 4, static_cast<int>(w)));
+    const uint32_t wB = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((32 + (lane >> 1)) * 4, static_cast<int>(w)));
+    const int sh = (lane & 1) * 4 * K;
+    cA = wA >> sh;
+    cB = wB >> sh;
 }
 
 // ------------------------------------------------------------------ packed state access, wide codes

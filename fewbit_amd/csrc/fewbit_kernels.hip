@@ -209,7 +209,8 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
                                                                   float p1, int chunk) {
     constexpr int NB = (1 << K) - 1;
     constexpr bool kFast = (DT != FEWBIT_F32);
-    constexpr bool kStreamY = (DT != FEWBIT_F32);
+    constexpr bool kSplit = (DT == FEWBIT_F32) && (FEWBIT_F32_SPLIT != 0);     // fp32: contiguous split tiles
+    constexpr bool kStreamY = (DT != FEWBIT_F32) || kSplit;
     typedef typename GroupIO<DT>::Raw Raw;
     const Span s = make_span<U>(n, chunk);
 
@@ -224,7 +225,15 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
             t = s.t0;  // ablation: every iteration re-reads and re-writes the wave's first tile (cache resident)
 #endif
 #pragma unroll
-            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + ln);
+            for (int u = 0; u < U; ++u) {
+                if constexpr (kSplit) {
+                    const SplitF32::Raw r = SplitF32::load_raw(x, (t * U + u) * kWave + ln, ln);
+                    buf.r[u].a = r.a;
+                    buf.r[u].b = r.b;
+                } else {
+                    buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + ln);
+                }
+            }
         },
         [&](size_t t, const Buf &buf) {
 #if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 4)
@@ -233,18 +242,19 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 float v[8];
-                GroupIO<DT>::unpack(buf.r[u], v);
+                GroupIO<DT>::unpack(buf.r[u], v);      // (the split layout unpacks the same way: v[0..3] | v[4..7] are its two halves)
 #if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 2)
                 const uint32_t w = f32_bits(v[0]) & 0xffffffu;  // ablation: no bucketing
 #else
                 uint32_t w;
-                if constexpr (Act<FN, kFast>::kFolded) {
-                    float key[8];
+                float key[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) key[i] = Act<FN, kFast>::key(v[i], p0);
-                    w = pack_group<K>(key, b);
+                for (int i = 0; i < 8; ++i) key[i] = Act<FN, kFast>::key(v[i], p0);      // x itself unless folded
+                if constexpr (kSplit) {
+                    const float ka[4] = {key[0], key[1], key[2], key[3]}, kb[4] = {key[4], key[5], key[6], key[7]};
+                    w = split_halves_to_word<K>(pack_half<K>(ka, b), pack_half<K>(kb, b), s.lane);
                 } else {
-                    w = pack_group<K>(v, b);
+                    w = pack_group<K>(key, b);
                 }
 #endif
 #if !(defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 1))
@@ -257,7 +267,8 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
                 // instruction leaves holes that only L2 write-combining fills -- nontemporal there costs 4 us per pass.
                 // state: plain store -- it is what backward reads, and a backward that follows closely finds it
                 // cached (4096x4096 bf16 step 26.5 -> 25.6 us); when backward runs much later it makes no difference.
-                GroupIO<DT>::template store<kStreamY>(y, g, v);
+                if constexpr (kSplit) SplitF32::store<true>(y, g, s.lane, v);
+                else GroupIO<DT>::template store<kStreamY>(y, g, v);
                 store_state_quad<K, false>(state, g, s.lane, w);
             }
         });
@@ -618,6 +629,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kerne
 
     // the level fetch goes out before the first tiles: vmcnt counts in order, so waiting for it in init() does not
     // wait for the tiles as well
+    constexpr bool kSplit = (DT == FEWBIT_F32) && (FEWBIT_F32_SPLIT != 0);
     float mine = 0.0f;
     if (threadIdx.x < NL && static_cast<int>(threadIdx.x) < nlevels) mine = Elem<DT>::load(levels, threadIdx.x);
     struct Buf { Raw r[U]; uint32_t w[U]; };
@@ -630,7 +642,13 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kerne
         [&](size_t t, int ln, Buf &buf) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + ln);
+                if constexpr (kSplit) {
+                    const SplitF32::Raw r = SplitF32::load_raw(gy, (t * U + u) * kWave + ln, ln);
+                    buf.r[u].a = r.a;
+                    buf.r[u].b = r.b;
+                } else {
+                    buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + ln);
+                }
                 buf.w[u] = load_state_quad_raw<K>(state, (t * U + u) * kWave + ln, ln);
             }
         },
@@ -640,12 +658,23 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kerne
                 float v[8];
                 GroupIO<DT>::unpack(buf.r[u], v);
                 const uint32_t w = load_state_quad_fix<K>(buf.w[u], s.lane);
+                if constexpr (kSplit) {      // v[0..3] / v[4..7] are halves of two different groups (SplitF32)
+                    uint32_t cA, cB;
+                    split_word_to_halves<K>(w, s.lane, cA, cB);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = lut[(cA >> (K * i)) & kMask] * v[i];
+                        v[4 + i] = lut[(cB >> (K * i)) & kMask] * v[4 + i];
+                    }
+                    SplitF32::store<true>(gx, (t * U + u) * kWave + s.lane, s.lane, v);
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = lut[(w >> (K * i)) & kMask] * v[i];
                 // gx of a 16-bit backward: nontemporal, like y in the forward -- a write-allocated gx pushes what is still to
                 // be read out of L2 / Infinity Cache and is written back during the NEXT kernel (cache-cold backward at
                 // 4096x4096 bf16 15.3 -> 13.9 us, 2^26 elements forward+backward 100.6 -> 94.1 us; RoBERTa-base step
-                // unchanged).  fp32 keeps plain stores (two 16 B pieces per lane at a 32 B stride need L2 write-combining).
+                // unchanged).  fp32 in the split layout (above) stores whole lines and is nontemporal too.
                 GroupIO<DT>::template store<(DT != FEWBIT_F32)>(gx, (t * U + u) * kWave + s.lane, v);
             }
         });
