@@ -697,12 +697,21 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kerne
                                                                    float p1, int chunk) {
     typedef typename GroupIO<DT>::Raw Raw;
     const Span s = make_span<U>(n, chunk);
+    constexpr bool kSplit = (DT == FEWBIT_F32) && (FEWBIT_F32_SPLIT != 0);     // see SplitF32
     struct Buf { Raw r[U]; };
     pipeline2<Buf>(
         s, []() {},
         [&](size_t t, int ln, Buf &buf) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + ln);
+            for (int u = 0; u < U; ++u) {
+                if constexpr (kSplit) {
+                    const SplitF32::Raw r = SplitF32::load_raw(x, (t * U + u) * kWave + ln, ln);
+                    buf.r[u].a = r.a;
+                    buf.r[u].b = r.b;
+                } else {
+                    buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + ln);
+                }
+            }
         },
         [&](size_t t, const Buf &buf) {
 #pragma unroll
@@ -717,7 +726,12 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kerne
                     w |= bit << i;
                 }
                 const size_t g = (t * U + u) * kWave + s.lane;
-                GroupIO<DT>::template store<(DT != FEWBIT_F32)>(y, g, v);
+                if constexpr (kSplit) {      // bits 0..3 / 4..7 of w belong to halves of two different groups
+                    w = split_halves_to_word<1>(w & 15u, w >> 4, s.lane);
+                    SplitF32::store<true>(y, g, s.lane, v);
+                } else {
+                    GroupIO<DT>::template store<(DT != FEWBIT_F32)>(y, g, v);
+                }
                 store_state_quad<1, false>(state, g, s.lane, w);
             }
         });
@@ -742,13 +756,20 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_backward_kern
                                                                     size_t n, float m0, float m1, int chunk) {
     typedef typename GroupIO<DT>::Raw Raw;
     const Span s = make_span<U>(n, chunk);
+    constexpr bool kSplit = (DT == FEWBIT_F32) && (FEWBIT_F32_SPLIT != 0);
     struct Buf { Raw r[U]; uint32_t w[U]; };
     pipeline2<Buf>(
         s, []() {},
         [&](size_t t, int ln, Buf &buf) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + ln);
+                if constexpr (kSplit) {
+                    const SplitF32::Raw r = SplitF32::load_raw(gy, (t * U + u) * kWave + ln, ln);
+                    buf.r[u].a = r.a;
+                    buf.r[u].b = r.b;
+                } else {
+                    buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + ln);
+                }
                 buf.w[u] = load_state_quad_raw<1>(state, (t * U + u) * kWave + ln, ln);
             }
         },
@@ -757,10 +778,16 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_backward_kern
             for (int u = 0; u < U; ++u) {
                 float v[8];
                 GroupIO<DT>::unpack(buf.r[u], v);
-                const uint32_t w = load_state_quad_fix<1>(buf.w[u], s.lane);
+                uint32_t w = load_state_quad_fix<1>(buf.w[u], s.lane);
+                if constexpr (kSplit) {
+                    uint32_t cA, cB;
+                    split_word_to_halves<1>(w, s.lane, cA, cB);
+                    w = (cA & 15u) | (cB << 4);
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = (((w >> i) & 1u) ? m1 : m0) * v[i];
-                GroupIO<DT>::template store<(DT != FEWBIT_F32)>(gx, (t * U + u) * kWave + s.lane, v);
+                if constexpr (kSplit) SplitF32::store<true>(gx, (t * U + u) * kWave + s.lane, s.lane, v);
+                else GroupIO<DT>::template store<(DT != FEWBIT_F32)>(gx, (t * U + u) * kWave + s.lane, v);
             }
         });
     if (!s.tail_owner) return;
