@@ -534,3 +534,37 @@ def test_autocast_and_activation_checkpointing():
     gv = net[0].weight.grad
     cos = torch.nn.functional.cosine_similarity(gv.flatten(), plain[0].flatten(), dim=0)
     assert cos > 0.97, cos
+
+
+def test_module_fast_path_follows_the_store_and_the_input_layout():
+    """fewbit.<Module>.forward binds its table casts per (device, dtype): a table replaced through store.add() must be
+    seen by the next call, and views / strided inputs must take the out-of-place route, as through fewbit.functional."""
+    from fewbit_amd.store import store
+    name, bits = 'tanh', 2
+    old = store.get(name, bits)
+    m = fewbit.Tanh(bits=bits)
+    x = torch.linspace(-3, 3, 4096, device=DEV)
+    try:
+        a = x.clone().requires_grad_()
+        m(a.clone()).sum().backward()
+        borders = torch.tensor([-100.0, -1.0, 0.0, 1.0, 100.0], dtype=torch.float64)
+        levels = torch.tensor([0.125, 0.25, 0.5, 1.0], dtype=torch.float64)
+        store.add(name, bits, (borders, levels))
+        b = x.clone().requires_grad_()
+        m(b.clone()).sum().backward()
+        want = levels.float().to(DEV)[torch.bucketize(x, borders[1:-1].float().to(DEV))]
+        assert torch.equal(b.grad, want) and not torch.equal(a.grad, b.grad)
+        # a view (row slice of a bigger buffer) and a strided tensor: input untouched, fresh output, same gradient
+        base = torch.randn(8, 4096, device=DEV, requires_grad=True)
+        for select in (lambda t: t[3], lambda t: t.t()[:, 3]):
+            base.grad = None
+            hidden = base * 1.0                                      # non-leaf; the selections below are views of it
+            inp = select(hidden)
+            keep = inp.detach().clone()
+            out = m(inp)
+            assert torch.equal(inp.detach(), keep) and out.data_ptr() != inp.data_ptr()
+            out.sum().backward()
+            assert torch.equal(base.grad[3], levels.float().to(DEV)[torch.bucketize(keep, borders[1:-1].float().to(DEV))])
+            assert int((base.grad != 0).sum()) == int((base.grad[3] != 0).sum())
+    finally:
+        store.add(name, bits, old)

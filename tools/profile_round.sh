@@ -8,6 +8,8 @@
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE  bench.py --no-extras --steps 50   -> HBM traffic per launch (C2)
 #   4. rocprofv3 --kernel-trace / --pmc FETCH_SIZE / --pmc WRITE_SIZE   tools/config_runs.py
 #      -> per-dispatch durations and traffic of EVERY config, warm and cold (split by tools/summarize_profiles.py)
+#   5. bench.py --config c4 / --steps 20 / 2 gloo ranks on the one GPU, stream micro-benchmark, host cost per call,
+#      clock-transient timeline, the fp32 ULP histogram written by the GPU test-suite
 set -u
 R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -24,4 +26,16 @@ timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$RAW/cfg_trace" -o 
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$RAW/cfg_fetch" -o cfg -- python3 tools/config_runs.py "$RAW/cfg_fetch/phases.json" 30 > /dev/null 2> "$RAW/cfg_fetch.err"
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$RAW/cfg_write" -o cfg -- python3 tools/config_runs.py "$RAW/cfg_write/phases.json" 30 > /dev/null 2> "$RAW/cfg_write.err"
 python3 tools/summarize_profiles.py "$R" "$RAW" "$OUT"
+# 5. the other driver-visible lines and the side measurements DESIGN.md quotes
+python3 bench.py --config c4 --no-cpu-baseline > "$OUT/${R}_bench_line_c4.json" 2>> "$RAW/bench.err"
+python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$OUT/${R}_bench_line_k20.json" 2>> "$RAW/bench.err"
+FEWBIT_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 \
+    bench.py --gpus 2 --steps 200 --warmup 10 2>> "$RAW/bench.err" | tail -1 > "$OUT/${R}_bench_line_2ranks_gloo_one_gpu.json"
+if [ -x scratch/stream_bench ]; then
+    scratch/stream_bench 32 > "$OUT/${R}_stream_bench_32MiB.txt" 2>&1
+    scratch/stream_bench 128 > "$OUT/${R}_stream_bench_128MiB.txt" 2>&1
+fi
+python3 scratch/hostcost.py > "$RAW/hostcost.log" 2>&1 && cp gpurun_out/hostcost.json "$OUT/${R}_hostcost.json"
+python3 scratch/timeline.py 0.0 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_clock_transient_timeline.txt"
+[ -f gpurun_out/fp32_ulp.json ] && cp gpurun_out/fp32_ulp.json "$OUT/${R}_fp32_ulp.json"   # written by pytest -m gpu
 ls -la "$OUT"
