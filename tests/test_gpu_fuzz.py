@@ -152,6 +152,24 @@ def test_shape_worker():
                 head = slice(0, 8 * 1000)
                 y_o, s_o, _ = oracle.quantize(name, x[head].cpu(), inner.cpu())
                 assert torch.equal(state[:k * 1000].cpu(), s_o)
+        # a wide table (6 bits: the run-time-width kernels) and a custom ragged one (5 levels -> 3 bits, not full)
+        for dtype, nlev in ((torch.float16, 33), (torch.float32, 40), (torch.bfloat16, 5)):
+            k = cabi.bitwidth(nlev)
+            inner = torch.sort(torch.randn(nlev - 1, generator=g, device=DEV))[0].to(dtype)
+            inner = torch.unique(inner)
+            levels = torch.randn(inner.numel() + 1, generator=g, device=DEV).to(dtype)
+            k = cabi.bitwidth(levels.numel())
+            x = (torch.randn(n, generator=g, device=DEV) * 1.5).to(dtype)
+            gy = torch.randn(n, generator=g, device=DEV).to(dtype)
+            y, state = cabi.quantize_forward('identity', x, inner)
+            codes = torch.bucketize(x.float(), inner.float(), out_int32=True)
+            assert torch.equal(state, cabi.pack_codes(codes, k)), (n, dtype, nlev)
+            assert torch.equal(y.view(torch.uint8), x.view(torch.uint8))
+            assert_bit_equal(cabi.quantize_backward(gy, state, levels), (levels.float()[codes.long()] * gy.float()).to(dtype))
+        xh = torch.randn(n, generator=g, device=DEV).to(torch.bfloat16)
+        yh, sth = cabi.stepwise1_forward('leaky_relu', xh, 0.25)
+        assert torch.equal(sth, cabi.pack_codes((xh < 0).to(torch.int32), 1))
+        assert torch.equal(yh, torch.nn.functional.leaky_relu(xh, 0.25))
         x = torch.randn(n, generator=g, device=DEV)
         gy = torch.randn(n, generator=g, device=DEV)
         y, st = cabi.stepwise1_forward('relu', x)
