@@ -54,4 +54,4 @@ from .modules import *  # noqa: E402,F401,F403
 from .linear import LinearCRS, LinearGRP, RandomizedLinear  # noqa: E402,F401
 from .util import map_module, memory_usage_hooks  # noqa: E402,F401
 
-__version__ = '0.1.0'
+__version__ = '0.2.0'
