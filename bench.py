@@ -351,6 +351,9 @@ def main():
                                                  'per-kernel HIP-event timings (fwd_us, bwd_us)',
                          'cache_state': 'warm (x and gy are served from the Infinity Cache; writes go to HBM)'},
         }
+        line['evidence'] = {'rocprofv3_kernel_stats': 'profiles/r02_bench_kernel_stats.csv (this command with --no-extras)',
+                            'pmc_traffic': 'profiles/r02_pmc_traffic.json', 'per_config_rocprofv3_and_pmc': 'profiles/r02_configs.json',
+                            'copy_floor_at_this_size': 'profiles/r02_stream_bench_32MiB.txt', 'regenerate': 'bash tools/profile_round.sh r02'}
         if world == 1 and not args.no_extras:
             cold = measure_config(cfg, device, cold=True)
             line['cold'] = dict(cold, note='same workload, rotating through independent buffer sets so nothing is re-used '
