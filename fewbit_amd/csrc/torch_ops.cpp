@@ -202,12 +202,17 @@ Tensor host_pack(const Tensor &codes, int nbits) {
 // (`pair`: the two fp32 multipliers of the 1-bit family instead of a level table in the tensor dtype)
 Tensor host_unpack_mul(const Tensor &grad, const Tensor &state, const Tensor &table, int nbits, const float *pair = nullptr) {
     const Tensor gy = grad.contiguous();
+    TORCH_CHECK(gy.is_floating_point(), "fewbit: unsupported gradient dtype ", gy.scalar_type());
+    if (!pair) {
+        TORCH_CHECK(table.defined() && table.device().is_cpu() && table.is_contiguous() && table.scalar_type() == gy.scalar_type(),
+                    "fewbit: `levels` must be a contiguous host tensor of the gradient's dtype (", gy.scalar_type(), ")");
+    }
     TORCH_CHECK(state.device().is_cpu() && state.scalar_type() == torch::kUInt8 && state.is_contiguous(),
                 "fewbit: state must be a contiguous uint8 host tensor");
     const int64_t n = gy.numel(), groups = (n + 7) / 8;
     TORCH_CHECK(state.numel() >= (static_cast<int64_t>(nbits) * n + 7) / 8, "fewbit: state buffer too small for ", n,
                 " elements at ", nbits, " bits");
-    const int64_t nstate = state.numel();
+    const int64_t nstate = state.numel(), nlev = pair ? 2 : table.numel();
     Tensor gx = torch::empty_like(gy);
     const uint8_t *in = state.data_ptr<uint8_t>();
     const uint64_t mask = (1ull << nbits) - 1ull;
@@ -223,7 +228,9 @@ Tensor host_unpack_mul(const Tensor &grad, const Tensor &state, const Tensor &ta
                 const int64_t e0 = gr * 8, m = std::min<int64_t>(8, n - e0);
                 for (int64_t i = 0; i < m; ++i) {
                     const auto code = (w >> (nbits * i)) & mask;
-                    const acc_t level = pair ? static_cast<acc_t>(pair[code]) : static_cast<acc_t>(lv[code]);
+                    // (a code beyond the table -- only a foreign or corrupted state has one -- reads as level 0, as in the kernels)
+                    const acc_t level = pair ? static_cast<acc_t>(pair[code])
+                                             : (static_cast<int64_t>(code) < nlev ? static_cast<acc_t>(lv[code]) : acc_t(0));
                     o[e0 + i] = static_cast<scalar_t>(level * static_cast<acc_t>(g[e0 + i]));
                 }
             }
