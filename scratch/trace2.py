@@ -39,3 +39,8 @@ for which in ('fwd', 'bwd'):
     xcd = (wid // wpb) % 8
     print('  finish time by XCD (median / max):', [f'{np.median(last[xcd==k]):.2f}/{last[xcd==k].max():.2f}' for k in range(8)])
     print('  start  time by XCD (median / max):', [f'{np.median(rel[xcd==k,0]):.2f}/{rel[xcd==k,0].max():.2f}' for k in range(8)])
+    st = rel[:, 0]
+    print('  fraction of waves starting after 1 / 2 / 4 us:', [round(float((st > v).mean()), 4) for v in (1, 2, 4)])
+    blk = wid // wpb
+    lateb = sorted(set(blk[st > 2.0].tolist()))
+    print('  blocks with a wave starting after 2 us:', len(lateb), 'of', len(set(blk.tolist())), ' first ids', lateb[:24], ' last ids', lateb[-8:])
