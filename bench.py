@@ -58,6 +58,14 @@ CONFIGS = {
                   label='fewbit.silu bits=4 on 8192x8192 fp16'),
     'c2_fp32': dict(fn='gelu', bits=3, rows=4096, cols=4096, dtype='f32', kind='continuous',
                     label='fewbit.gelu bits=3 on 4096x4096 fp32'),
+    # the only op-level timing the reference publishes (notebooks/few-bit-backward/
+    # memory-usage-operation-only.py:41,70,80-85 -- torch.ops.fewbit.gelu with 3-bit tables on 128*2^20 fp32 elements,
+    # forward 2.862 + backward 1.563 = 4.425, unit assumed ms, GPU not stated => ~473 GiB/s in this metric)
+    'ref_notebook': dict(fn='gelu', bits=3, rows=131072, cols=1024, dtype='f32', kind='continuous',
+                         label='fewbit.gelu bits=3 on 128*2^20 fp32 elements (shape of the reference notebook timing)',
+                         reference_published={'fwd_plus_bwd': 4.425, 'unit': 'ms (assumed; not stated)', 'GiB_s': 473.0,
+                                              'hardware': 'not stated (an NVIDIA GPU)',
+                                              'source': 'notebooks/few-bit-backward/memory-usage-operation-only.py:41,70,80-85'}),
 }
 
 
@@ -365,7 +373,12 @@ def main():
                 if name == args.config:
                     continue
                 others[name] = {'workload': c['label'], 'bytes_per_step': int(step_bytes(c)[0]),
-                                'warm': measure_config(c, device, cold=False), 'cold': measure_config(c, device, cold=True)}
+                                'warm': measure_config(c, device, cold=False)}
+                if step_bytes(c)[0] < 8 * INFINITY_CACHE_BYTES:      # beyond that one buffer set is cache-cold by itself
+                    others[name]['cold'] = measure_config(c, device, cold=True)
+                if 'reference_published' in c:
+                    others[name]['reference_published'] = c['reference_published']
+                    others[name]['vs_reference_published'] = round(others[name]['warm']['GiB_s'] / c['reference_published']['GiB_s'], 2)
             line['configs'] = others
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)

@@ -30,7 +30,8 @@ def main():
     torch.cuda.set_device(device)
     phases = []
     for name, cfg in bench.CONFIGS.items():
-        for mode in ('warm', 'cold'):
+        big = bench.step_bytes(cfg)[0] >= 8 * bench.INFINITY_CACHE_BYTES      # one buffer set is cache-cold by itself
+        for mode in (('warm', ) if big else ('warm', 'cold')):
             nsets = bench.nsets_for_cold(cfg) if mode == 'cold' else 1
             w = bench.Workload(cfg, device, nsets=nsets, seed=3, host_seeded=False)
             steps = w.steps()
