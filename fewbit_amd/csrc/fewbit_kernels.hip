@@ -307,7 +307,10 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
 #ifndef FEWBIT_LUT_WPS
 #define FEWBIT_LUT_WPS 8      // waves per SIMD the table kernel is compiled for (two 16-wave blocks per CU)
 #endif
-constexpr int kLutBlock = 1024;
+#ifndef FEWBIT_LUT_BLOCK
+#define FEWBIT_LUT_BLOCK 1024   // threads per block of the pattern-table kernels (a multiple of 64)
+#endif
+constexpr int kLutBlock = FEWBIT_LUT_BLOCK;
 constexpr int kLutWaves = kLutBlock / kWave;
 
 template <int DT> __device__ __forceinline__ float value_of_pattern(uint32_t r) {
@@ -341,22 +344,26 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
         float b[NBMAX];
 #pragma unroll
         for (int j = 0; j < NBMAX; ++j) b[j] = bits_f32(__builtin_amdgcn_readlane(f32_bits(mine), j));
-        // pass 1: chunk of 64 patterns per thread; a chunk that starts on a NaN pattern is all NaN -> nborders
-        const uint32_t r0 = threadIdx.x * 64u;
-        const uint32_t c_first = ((r0 & 0x7fffu) > kInf) ? static_cast<uint32_t>(nborders)
-                                                        : count_below<NBMAX>(b, value_of_pattern<DT>(r0));
-        const uint32_t c0 = c_first * 0x01010101u;
-        u32x4 fill = {c0, c0, c0, c0};
-        u32x4 *dst = reinterpret_cast<u32x4 *>(lut + r0);
-        dst[0] = fill; dst[1] = fill; dst[2] = fill; dst[3] = fill;
+        // pass 1: chunks of 64 patterns, one per thread (1024-thread blocks); a chunk that starts on a NaN pattern is all
+        // NaN -> nborders
+#pragma unroll
+        for (uint32_t c = threadIdx.x; c < 1024u; c += kLutBlock) {
+            const uint32_t r0 = c * 64u;
+            const uint32_t c_first = ((r0 & 0x7fffu) > kInf) ? static_cast<uint32_t>(nborders)
+                                                            : count_below<NBMAX>(b, value_of_pattern<DT>(r0));
+            const uint32_t c0 = c_first * 0x01010101u;
+            u32x4 fill = {c0, c0, c0, c0};
+            u32x4 *dst = reinterpret_cast<u32x4 *>(lut + r0);
+            dst[0] = fill; dst[1] = fill; dst[2] = fill; dst[3] = fill;
+        }
         __syncthreads();
         // pass 2: wave j corrects border j's chunk, all borders at once: lane l owns the l-th pattern past the border
         // and adds/subtracts 1 in its byte with an LDS dword atomic (no carry: codes stay within 0..15).  NaN patterns
         // are never touched here; the last wave rewrites the 63 NaN patterns that share a chunk with +-inf.
         const int wv = threadIdx.x >> 6;
         uint32_t *lut32 = reinterpret_cast<uint32_t *>(lut);
-        if (wv < nborders) {
-            const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine_raw), wv));
+        for (int j = wv; j < nborders; j += kLutWaves) {                   // wave-uniform; one round with 16 waves and K <= 4
+            const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine_raw), j));
             const uint32_t mag = bits & 0x7fffu;
             const bool neg = (bits >> 15) != 0 && mag != 0;               // -0 behaves as +0
             if (mag <= kInf) {                                              // a NaN border is counted for every x already
@@ -521,13 +528,15 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
             sr[threadIdx.x] = static_cast<uint16_t>(mine_raw);
         }
         __syncthreads();
-        const uint32_t r0 = threadIdx.x * 64u;
-        const uint32_t c_first = ((r0 & 0x7fffu) > kInf) ? static_cast<uint32_t>(nborders)
-                                                        : tree_code(sb, value_of_pattern<DT>(r0), nbits, static_cast<uint32_t>(nborders));
-        const uint32_t c0 = c_first * 0x01010101u;
-        u32x4 fill = {c0, c0, c0, c0};
-        u32x4 *dst = reinterpret_cast<u32x4 *>(lut + r0);
-        dst[0] = fill; dst[1] = fill; dst[2] = fill; dst[3] = fill;
+        for (uint32_t c = threadIdx.x; c < 1024u; c += kLutBlock) {
+            const uint32_t r0 = c * 64u;
+            const uint32_t c_first = ((r0 & 0x7fffu) > kInf) ? static_cast<uint32_t>(nborders)
+                                                            : tree_code(sb, value_of_pattern<DT>(r0), nbits, static_cast<uint32_t>(nborders));
+            const uint32_t c0 = c_first * 0x01010101u;
+            u32x4 fill = {c0, c0, c0, c0};
+            u32x4 *dst = reinterpret_cast<u32x4 *>(lut + r0);
+            dst[0] = fill; dst[1] = fill; dst[2] = fill; dst[3] = fill;
+        }
         __syncthreads();
         uint32_t *lut32 = reinterpret_cast<uint32_t *>(lut);
         for (int j = threadIdx.x >> 6; j < nborders; j += kLutWaves) {     // wave-uniform loop
