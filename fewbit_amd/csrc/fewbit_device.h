@@ -326,11 +326,19 @@ __device__ __forceinline__ void store_state_wide(uint8_t *state, size_t g, int n
         for (int j = 0; j < nbits; ++j) p[j] = static_cast<uint8_t>(w >> (8 * j));
         return;
     }
+    // as few store instructions as the width allows (any address is fine on gfx950): 4 -> dword, 5 -> dword + byte,
+    // 6 -> dword + short, 7 -> dword + short + byte, 8 -> one 8-byte store (bf16 8-bit forward 20.7 -> see DESIGN.md)
+    if (nbits == 8) {
+        store_as<false, 1>(p, w);
+        return;
+    }
     store_as<false, 1>(p, static_cast<uint32_t>(w));
-    uint32_t hi = static_cast<uint32_t>(w >> 32);
-    for (int j = 4; j < nbits; ++j) {
-        p[j] = static_cast<uint8_t>(hi);
-        hi >>= 8;
+    const uint32_t hi = static_cast<uint32_t>(w >> 32);
+    if (nbits >= 6) {
+        store_as<false, 1>(p + 4, static_cast<uint16_t>(hi));
+        if (nbits == 7) p[6] = static_cast<uint8_t>(hi >> 16);
+    } else if (nbits == 5) {
+        p[4] = static_cast<uint8_t>(hi);
     }
 }
 

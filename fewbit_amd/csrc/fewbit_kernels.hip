@@ -484,12 +484,16 @@ __global__ __launch_bounds__(kBlock, 6) void quantize_forward_wide_kernel(const 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) pos[i] += !(sb[pos[i] + step - 1] >= Act<FN, kFast>::key(v[i], p0)) ? step : 0u;
             }
-            uint64_t w = 0;
+            // two 32-bit halves (4 codes of <= 8 bits each) and ONE 64-bit shift instead of eight
+            uint32_t wlo = 0, whi = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                w |= static_cast<uint64_t>(min(pos[i], static_cast<uint32_t>(nborders))) << (nbits * i);
-                v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
+            for (int i = 0; i < 4; ++i) {
+                wlo |= min(pos[i], static_cast<uint32_t>(nborders)) << (nbits * i);
+                whi |= min(pos[4 + i], static_cast<uint32_t>(nborders)) << (nbits * i);
             }
+            const uint64_t w = static_cast<uint64_t>(wlo) | (static_cast<uint64_t>(whi) << (4 * nbits));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
             const size_t g = t * kWave + s.lane;
             GroupIO<DT>::template store<kFast>(y, g, v);
             store_state_wide(state, g, nbits, w);
@@ -563,13 +567,16 @@ __global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lu
     pipeline2<Buf, true>(
         s, build, [&](size_t t, int ln, Buf &buf) { buf.r = GroupIO<DT>::load_raw(x, t * kWave + ln); },
         [&](size_t t, const Buf &buf) {
-            uint64_t w = 0;
+            uint32_t wlo = 0, whi = 0;        // elements 0..3 | 4..7: 32-bit halves, one 64-bit shift to join them
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t d = buf.r.q[i];
-                w |= static_cast<uint64_t>(lut[d & 0xffffu]) << (nbits * (2 * i));
-                w |= static_cast<uint64_t>(lut[d >> 16]) << (nbits * (2 * i + 1));
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t d0 = buf.r.q[i], d1 = buf.r.q[2 + i];
+                wlo |= static_cast<uint32_t>(lut[d0 & 0xffffu]) << (nbits * (2 * i));
+                wlo |= static_cast<uint32_t>(lut[d0 >> 16]) << (nbits * (2 * i + 1));
+                whi |= static_cast<uint32_t>(lut[d1 & 0xffffu]) << (nbits * (2 * i));
+                whi |= static_cast<uint32_t>(lut[d1 >> 16]) << (nbits * (2 * i + 1));
             }
+            const uint64_t w = static_cast<uint64_t>(wlo) | (static_cast<uint64_t>(whi) << (4 * nbits));
             float v[8];
             GroupIO<DT>::unpack(buf.r, v);
 #pragma unroll
@@ -606,8 +613,12 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_
         [&](size_t t, const Buf &buf) {
             float v[8];
             GroupIO<DT>::unpack(buf.r, v);
+            const uint32_t wlo = static_cast<uint32_t>(buf.w), whi = static_cast<uint32_t>(buf.w >> (4 * nbits));   // codes 0..3 | 4..7
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = lut[static_cast<uint32_t>(buf.w >> (nbits * i)) & mask] * v[i];
+            for (int i = 0; i < 4; ++i) {
+                v[i] = lut[(wlo >> (nbits * i)) & mask] * v[i];
+                v[4 + i] = lut[(whi >> (nbits * i)) & mask] * v[4 + i];
+            }
             GroupIO<DT>::template store<(DT != FEWBIT_F32)>(gx, t * kWave + s.lane, v);
         });
     if (!s.tail_owner) return;
