@@ -49,7 +49,7 @@ else:
 
 from . import functional  # noqa: E402,F401
 from . import modules  # noqa: E402,F401
-from . import approx, cli, fft, linear, variance  # noqa: E402,F401
+from . import approx, cli, compat, fft, linear, variance  # noqa: E402,F401
 from .modules import *  # noqa: E402,F401,F403
 from .linear import LinearCRS, LinearGRP, RandomizedLinear  # noqa: E402,F401
 from .util import map_module, memory_usage_hooks  # noqa: E402,F401

@@ -285,3 +285,18 @@ def test_host_path_refuses_tables_its_byte_codes_cannot_hold():
     code = torch.searchsorted(half_b, xx.detach().abs())
     want = torch.where(xx.detach() > 0, half_l[code], -half_l[code])
     assert torch.equal(xx.grad, want)
+
+
+def test_reference_submodule_paths_resolve():
+    """Every import path of the reference package resolves on the alias (users import e.g.
+    ``from fewbit.functional.activations import store`` or ``from fewbit.compat import removeprefix``)."""
+    import importlib
+    for path in ('fewbit.functional.activations', 'fewbit.functional.linear', 'fewbit.functional.variance',
+                 'fewbit.modules.activations', 'fewbit.modules.linear', 'fewbit.modules.variance', 'fewbit.util', 'fewbit.fft',
+                 'fewbit.approx', 'fewbit.cli', 'fewbit.compat'):
+        importlib.import_module(path)
+    from fewbit.compat import removeprefix
+    from fewbit.functional.activations import store
+    from fewbit.modules.variance import VarianceEstimator  # noqa: F401
+    assert removeprefix('module.weight', 'module.') == 'weight' and removeprefix('abc', 'x') == 'abc'
+    assert ('gelu', 3) in store
