@@ -34,7 +34,11 @@ def offset_copy(t, off_elems, extra=16):
     return view
 
 
-@pytest.mark.parametrize('seed', range(12))
+# FEWBIT_FUZZ_SEEDS=N widens the sweep (a one-off soak run; the default keeps the suite short)
+N_SEEDS = int(__import__('os').environ.get('FEWBIT_FUZZ_SEEDS', '12'))
+
+
+@pytest.mark.parametrize('seed', range(N_SEEDS))
 def test_fuzz_quantize_paths(seed):
     g = torch.Generator().manual_seed(1000 + seed)
     rng = np.random.default_rng(seed)
@@ -76,7 +80,7 @@ def test_fuzz_quantize_paths(seed):
         assert_bit_equal(gx.cpu(), gx_o, tag + ' gx')
 
 
-@pytest.mark.parametrize('seed', range(4))
+@pytest.mark.parametrize('seed', range(max(4, N_SEEDS // 3)))
 def test_fuzz_one_bit_family(seed):
     g = torch.Generator().manual_seed(2000 + seed)
     rng = np.random.default_rng(100 + seed)
