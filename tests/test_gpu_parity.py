@@ -580,3 +580,34 @@ def test_wide_tables_full_size(dt, nlev):
         tail = slice(n - 1000, n)
         _, s_t, _ = oracle.quantize('silu', x[(n - 1000) // 8 * 8:], inner)
         assert torch.equal(state[k * ((n - 1000) // 8):].cpu(), s_t)
+
+
+def test_every_fp32_pattern_through_the_search_kernels():
+    """All 2^32 fp32 bit patterns (every NaN payload, every denormal, both zeros and infinities) through the fp32
+    forward (register search, split layout) and the backward, for the four built-in gelu tables and a table whose
+    borders sit on special values: codes against an independent formulation on the GPU -- #{b < x}, NaN -> last code, the
+    torch.searchsorted CPU rule the reference follows (fewbit/cpu/gelu.cc:17) --, y == x bit for bit (identity functor),
+    gradients == levels[code] * gy.  A few seconds on an MI355X."""
+    chunk = 1 << 28
+    tables = []
+    for k in (1, 2, 3, 4):
+        b, l = store.get('gelu', k, DEV, torch.float32)
+        tables.append((b[1:-1].contiguous(), l))
+    edge = torch.tensor([-float('inf'), -1.0, -1e-45, -0.0, 1e-45, 1.0, float('inf')], device=DEV)
+    tables.append((edge, torch.arange(8.0, device=DEV)))
+    for inner, levels in tables:
+        k = cabi.bitwidth(levels.numel())
+        for c in range(16):
+            bits = torch.arange(c * chunk, (c + 1) * chunk, device=DEV, dtype=torch.int64).to(torch.int32)
+            x = bits.view(torch.float32)
+            y, st = cabi.quantize_forward('identity', x, inner)
+            codes = cabi.unpack_codes(st, chunk, k)
+            want = torch.zeros(chunk, dtype=torch.int32, device=DEV)
+            for j in range(inner.numel()):
+                want += (inner[j] < x).to(torch.int32)
+            want = torch.where(torch.isnan(x), torch.full_like(want, inner.numel()), want)
+            assert torch.equal(codes, want), (k, c)
+            assert torch.equal(y.view(torch.int32), bits)
+            gy = torch.full((chunk,), 1.5, device=DEV)
+            assert torch.equal(cabi.quantize_backward(gy, st, levels), levels[want.long()] * 1.5)
+            del bits, x, y, st, codes, want, gy
