@@ -395,14 +395,18 @@ __device__ __forceinline__ float erf_precise(float z) {
     r = __builtin_fmaf(r, s, -3.761249483e-01f);
     r = __builtin_fmaf(r, s, 1.283791512e-01f);
     const float small = __builtin_fmaf(r, t, t);
+    // erf(|z| >= 4) is 1 in fp32; without the clamp the degree-8 product overflows from |z| ~ 3e5 on and the hi/lo split
+    // below turns inf - inf into NaN (found by running all 2^32 inputs, scratch/all_fp32_gelu.py).  v_min_f32 returns
+    // the other operand for a NaN, which is harmless here: the caller multiplies by x, NaN stays NaN.
+    const float tc = __builtin_fminf(t, 6.0f);
     float q = 1.130373221e-05f;
-    q = __builtin_fmaf(q, t, -3.235284530e-04f);
-    q = __builtin_fmaf(q, t, 3.645403776e-03f);
-    q = __builtin_fmaf(q, t, -2.376828715e-02f);
-    q = __builtin_fmaf(q, t, 1.062441021e-01f);
-    q = __builtin_fmaf(q, t, 6.351469755e-01f);
-    q = __builtin_fmaf(q, t, 1.286495626e-01f);
-    const float p = __builtin_fmaf(q, t, t);
+    q = __builtin_fmaf(q, tc, -3.235284530e-04f);
+    q = __builtin_fmaf(q, tc, 3.645403776e-03f);
+    q = __builtin_fmaf(q, tc, -2.376828715e-02f);
+    q = __builtin_fmaf(q, tc, 1.062441021e-01f);
+    q = __builtin_fmaf(q, tc, 6.351469755e-01f);
+    q = __builtin_fmaf(q, tc, 1.286495626e-01f);
+    const float p = __builtin_fmaf(q, tc, tc);
     const float kL = 1.44269502162933349609375f;       // fp32(log2 e)
     const float kLlo = 1.92596299112661746e-08f;       // log2 e - fp32(log2 e)
     const float u = p * kL;
