@@ -611,3 +611,43 @@ def test_every_fp32_pattern_through_the_search_kernels():
             gy = torch.full((chunk,), 1.5, device=DEV)
             assert torch.equal(cabi.quantize_backward(gy, st, levels), levels[want.long()] * 1.5)
             del bits, x, y, st, codes, want, gy
+
+
+def test_exhaustive_bits_wide_codes_and_backward_products():
+    """Three sweeps over complete input spaces (a few seconds on an MI355X):
+    (1) the derivative-branch bit of all eight 1-bit functions for every fp32 pattern, against the comparison rules of
+        fewbit/cuda/codec.cu:298-487 evaluated by torch on the GPU;
+    (2) the wide-table fp32 forward (LDS tree search, run-time bit width) for every fp32 pattern, 255 borders;
+    (3) the backward product for every (16-bit gy pattern, level) pair -- 256, 8 and 2 levels, i.e. the wide, the 3-bit and
+        the 1-bit-wide table kernels -- against fp32 multiply + round-to-nearest-even, sign of zero included."""
+    chunk = 1 << 27
+    rules = {'hardshrink': ((0.5,), lambda x: (x < -0.5) | (x > 0.5)), 'hardsigmoid': ((), lambda x: ~((x <= -3) | (x >= 3))),
+             'hardtanh': ((-1.0, 1.0), lambda x: ~((x <= -1) | (x >= 1))), 'leaky_relu': ((0.01,), lambda x: ~(x >= 0)),
+             'relu': ((), lambda x: ~(x <= 0)), 'relu6': ((), lambda x: ~((x <= 0) | (x >= 6))),
+             'softshrink': ((0.5,), lambda x: (x < -0.5) | (x > 0.5)), 'threshold': ((0.25, -3.0), lambda x: ~(x <= 0.25))}
+    g = torch.Generator(device=DEV).manual_seed(1)
+    inner = torch.unique(torch.sort(torch.randn(255, generator=g, device=DEV) * 2)[0])
+    kw = cabi.bitwidth(inner.numel() + 1)
+    for c in range(32):
+        bits = torch.arange(c * chunk, (c + 1) * chunk, device=DEV, dtype=torch.int64).to(torch.int32)
+        x = bits.view(torch.float32)
+        for name, (p, rule) in rules.items():
+            _, st = cabi.stepwise1_forward(name, x, *p)
+            assert torch.equal(cabi.unpack_codes(st, chunk, 1), rule(x).to(torch.int32)), (name, c)
+        _, st = cabi.quantize_forward('identity', x, inner)
+        want = torch.where(torch.isnan(x), torch.full((chunk,), inner.numel(), dtype=torch.int32, device=DEV),
+                           torch.bucketize(x, inner, out_int32=True))
+        assert torch.equal(cabi.unpack_codes(st, chunk, kw), want), c
+        del bits, x, st, want
+    for dtype in (torch.bfloat16, torch.float16):
+        pat = torch.arange(65536, device=DEV, dtype=torch.int32).to(torch.int16).view(dtype)
+        levels = torch.cat([torch.tensor([0.0, -0.0, 1.0, -1.0, 0.5, 3.0, 1e-3, -2.5e-2], device=DEV),
+                            torch.randn(248, generator=g, device=DEV)]).to(dtype)
+        for k, nl in ((8, 256), (3, 8), (1, 2)):
+            lv = levels[:nl].contiguous()
+            codes = torch.arange(nl, device=DEV, dtype=torch.int32).repeat_interleave(65536)
+            gy = pat.repeat(nl)
+            gx = cabi.quantize_backward(gy, cabi.pack_codes(codes, k), lv)
+            want = (lv.float()[codes.long()] * gy.float()).to(dtype)
+            neq = (gx.view(torch.int16) != want.view(torch.int16)) & ~(torch.isnan(gx) & torch.isnan(want))
+            assert not bool(neq.any()), (dtype, nl)
