@@ -651,3 +651,21 @@ def test_exhaustive_bits_wide_codes_and_backward_products():
             want = (lv.float()[codes.long()] * gy.float()).to(dtype)
             neq = (gx.view(torch.int16) != want.view(torch.int16)) & ~(torch.isnan(gx) & torch.isnan(want))
             assert not bool(neq.any()), (dtype, nl)
+
+
+def test_folded_key_every_fp32_pattern():
+    """The even-parity fold (FEWBIT_IDENTITY_FOLD: code from the fp32 key |x - shift_x|) for every fp32 pattern and three
+    shifts, against the same expression evaluated by torch on the GPU."""
+    chunk = 1 << 27
+    inner = torch.tensor([0.0, 0.125, 0.5, 1.0, 2.0, 3.5, 1e3], device=DEV)
+    for shift in (0.0, 0.375, -2.5):
+        for c in range(32):
+            bits = torch.arange(c * chunk, (c + 1) * chunk, device=DEV, dtype=torch.int64).to(torch.int32)
+            x = bits.view(torch.float32)
+            y, st = cabi.quantize_forward('identity_fold', x, inner, shift, 0.0)
+            key = (x - shift).abs()
+            want = torch.where(torch.isnan(key), torch.full((chunk,), 7, dtype=torch.int32, device=DEV),
+                               torch.bucketize(key, inner, out_int32=True))
+            assert torch.equal(cabi.unpack_codes(st, chunk, 3), want), (shift, c)
+            assert torch.equal(y.view(torch.int32), bits)
+            del bits, x, y, st, key, want

@@ -170,3 +170,25 @@ def test_full_size_c2_digest_of_the_reference_run_on_the_host():
     _, state_o, _ = oracle.quantize('gelu', x, inner)
     assert sha256_of(state_o) == want['state']
     assert sha256_of(oracle.quantize_backward(gy, state_o, levels)) == want['gx']
+
+
+@pytest.mark.parametrize('dtype', (torch.bfloat16, torch.float16))
+def test_host_ops_every_16bit_pattern(dtype):
+    """All 65 536 patterns of a 16-bit dtype through the host operators (gelu k = 1..4, a custom table with borders on
+    special values): packed state and gradient bit-identical to the oracle."""
+    x = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(dtype)
+    gy = torch.full((65536,), 1.5).to(dtype)
+    for bits in (1, 2, 3, 4):
+        inner, levels = store.get_inner('gelu', bits, torch.device('cpu'), dtype)
+        _, state = torch.ops.fewbit.quantize(x, inner)
+        _, state_o, _ = oracle.quantize('gelu', x, inner)
+        assert torch.equal(state, state_o), bits
+        assert_bit_equal(torch.ops.fewbit.quantize_backward(gy, state, levels), oracle.quantize_backward(gy, state_o, levels))
+    edge = torch.tensor([-float('inf'), -1.0, -0.0, 6e-8, 1.0, float('inf')]).to(dtype)
+    levels = torch.arange(7.0).to(dtype)
+    xx = x.clone().requires_grad_()
+    saved = []
+    with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(t), t)[1], lambda t: t):
+        torch.ops.fewbit.stepwise(xx.clone(), edge, levels)
+    _, state_o, _ = oracle.quantize('identity', x, edge)
+    assert torch.equal([t for t in saved if t.dtype == torch.uint8][0], state_o)
