@@ -190,3 +190,30 @@ def test_gelu_fp32_every_input():
     big = torch.tensor([1e3, 4e5, 1e6, 1e20, 3e38, -1e3, -4e5, -1e6, -3e38], device=DEV)
     y, _ = cabi.quantize_forward('gelu', big, inner)
     assert torch.equal(y[:5], big[:5]) and torch.equal(y[5:], torch.zeros(4, device=DEV)) and bool(torch.signbit(y[5:]).all())
+
+
+@pytest.mark.parametrize('name', ('celu', 'elu', 'gelu', 'hardswish', 'logsigmoid', 'mish', 'selu', 'sigmoid', 'silu', 'softplus',
+                                  'softsign', 'tanh', 'tanhshrink'))
+def test_every_fp32_input_against_aten(name):
+    """All 2^32 fp32 inputs through the precise-class forward of each continuous functor against ATen's own fp32 kernel on
+    the same GPU: NaN and infinity in exactly the same places, and every finite result within 4 fp32 steps or 1e-6
+    (absolute) of ATen's -- the tolerance the seeded fuzz uses, here over the complete input space (~1 s per functor)."""
+    import torch.nn.functional as F
+    ref = {'celu': lambda x: F.celu(x, 1.3), 'elu': lambda x: F.elu(x, 0.7), 'gelu': F.gelu, 'hardswish': F.hardswish,
+           'logsigmoid': F.logsigmoid, 'mish': F.mish, 'selu': F.selu, 'sigmoid': torch.sigmoid, 'silu': F.silu,
+           'softplus': lambda x: F.softplus(x, 2.0, 5.0), 'softsign': F.softsign, 'tanh': torch.tanh, 'tanhshrink': F.tanhshrink}[name]
+    par = {'celu': (1.3, 0.0), 'elu': (0.7, 0.0), 'softplus': (2.0, 5.0)}.get(name, (0.0, 0.0))
+    inner = torch.tensor([-1.0, 0.0, 1.0], device=DEV)
+    chunk = 1 << 27
+    for c in range(32):
+        bits = torch.arange(c * chunk, (c + 1) * chunk, device=DEV, dtype=torch.int64).to(torch.int32)
+        x = bits.view(torch.float32)
+        y, _ = cabi.quantize_forward(name, x, inner, *par)
+        e = ref(x)
+        assert torch.equal(torch.isnan(y), torch.isnan(e)) and torch.equal(torch.isinf(y), torch.isinf(e)), (name, c)
+        both = torch.isfinite(y) & torch.isfinite(e)
+        yi, ei = y.view(torch.int32).long(), e.view(torch.int32).long()
+        steps = (torch.where(yi < 0, -(yi & 0x7fffffff), yi) - torch.where(ei < 0, -(ei & 0x7fffffff), ei)).abs()
+        bad = both & (steps > 4) & ((y.double() - e.double()).abs() > 1e-6)
+        assert not bool(bad.any()), (name, c, x[bad][:4].tolist(), y[bad][:4].tolist(), e[bad][:4].tolist())
+        del bits, x, y, e, yi, ei, steps, bad, both
