@@ -13,7 +13,8 @@ import torch
 __all__ = [
     'CONTINUOUS', 'STEPWISE1', 'LIB_PATH', 'lib', 'loaded', 'bitwidth', 'state_nbytes', 'quantize_forward',
     'quantize_backward', 'bind_forward', 'bind_backward', 'bind_stepwise1_forward', 'bind_stepwise1_backward',
-    'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError',
+    'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError', 'describe_forward',
+    'describe_backward', 'describe_stepwise1_forward', 'describe_stepwise1_backward', 'tune',
 ]
 
 import os
@@ -30,7 +31,9 @@ DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 # every symbol include/fewbit_hip.h declares
 SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwidth', 'fewbit_hip_state_nbytes',
            'fewbit_hip_quantize_forward', 'fewbit_hip_quantize_backward', 'fewbit_hip_stepwise1_forward',
-           'fewbit_hip_stepwise1_backward', 'fewbit_hip_pack_codes', 'fewbit_hip_unpack_codes')
+           'fewbit_hip_stepwise1_backward', 'fewbit_hip_pack_codes', 'fewbit_hip_unpack_codes',
+           'fewbit_hip_describe_quantize_forward', 'fewbit_hip_describe_quantize_backward',
+           'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune')
 
 
 class FewbitHipError(RuntimeError):
@@ -68,6 +71,17 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_pack_codes.argtypes = [vp, vp, sz, i32, vp]
         L.fewbit_hip_unpack_codes.restype = i32
         L.fewbit_hip_unpack_codes.argtypes = [vp, vp, sz, i32, vp]
+        cp = ctypes.c_char_p
+        L.fewbit_hip_describe_quantize_forward.restype = i32
+        L.fewbit_hip_describe_quantize_forward.argtypes = [i32, i32, sz, i32, cp, sz]
+        L.fewbit_hip_describe_quantize_backward.restype = i32
+        L.fewbit_hip_describe_quantize_backward.argtypes = [i32, sz, i32, cp, sz]
+        L.fewbit_hip_describe_stepwise1_forward.restype = i32
+        L.fewbit_hip_describe_stepwise1_forward.argtypes = [i32, i32, sz, cp, sz]
+        L.fewbit_hip_describe_stepwise1_backward.restype = i32
+        L.fewbit_hip_describe_stepwise1_backward.argtypes = [i32, i32, sz, cp, sz]
+        L.fewbit_hip_tune.restype = i32
+        L.fewbit_hip_tune.argtypes = [cp, ctypes.c_longlong]
         _lib = L
     return _lib
 
@@ -89,8 +103,36 @@ def _dev(t: torch.Tensor, what: str) -> torch.Tensor:
     return t
 
 
-def _stream(stream: Optional[int]) -> int:
-    return torch.cuda.current_stream().cuda_stream if stream is None else stream
+def _stream(stream: Optional[int], device: Optional[torch.device] = None) -> int:
+    """``stream`` or torch's current stream ON THE TENSORS' DEVICE (not on whatever device happens to be current)."""
+    return torch.cuda.current_stream(device).cuda_stream if stream is None else stream
+
+
+class _on:
+    """Make the tensors' device current around a launch: the library launches on the calling thread's current device
+    (include/fewbit_hip.h), so a tensor on cuda:3 must not be launched while cuda:0 is current.  A no-op (no runtime
+    call at all) in the common case that the device is current already."""
+    __slots__ = ('index', 'prev')
+
+    def __init__(self, device: torch.device):
+        self.index = device.index if device.index is not None else torch.cuda.current_device()
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.prev != self.index:
+            torch.cuda.set_device(self.index)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != self.index:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def _same_device(first: torch.Tensor, *others: torch.Tensor):
+    for t in others:
+        if t.device != first.device:
+            raise FewbitHipError(f'tensors live on different devices ({first.device} and {t.device})')
 
 
 def bitwidth(nlevels: int) -> int:
@@ -109,12 +151,14 @@ def quantize_forward(fn: str, x: torch.Tensor, borders: torch.Tensor, p0: float 
     if borders.dtype != x.dtype:
         raise FewbitHipError(f'borders dtype {borders.dtype} != input dtype {x.dtype}')
     k = bitwidth(borders.numel() + 1)
-    y = torch.empty_like(x) if out is None else _dev(out, 'out')
-    if state is None:
-        state = torch.empty(state_nbytes(x.numel(), k), dtype=torch.uint8, device=x.device)
-    _check(lib().fewbit_hip_quantize_forward(CONTINUOUS.index(fn), DTYPES[x.dtype], x.data_ptr(), y.data_ptr(),
-                                             state.data_ptr(), x.numel(), borders.data_ptr(), borders.numel(),
-                                             p0, p1, _stream(stream)))
+    with _on(x.device):
+        y = torch.empty_like(x) if out is None else _dev(out, 'out')
+        if state is None:
+            state = torch.empty(state_nbytes(x.numel(), k), dtype=torch.uint8, device=x.device)
+        _same_device(x, borders, y, state)
+        _check(lib().fewbit_hip_quantize_forward(CONTINUOUS.index(fn), DTYPES[x.dtype], x.data_ptr(), y.data_ptr(),
+                                                 state.data_ptr(), x.numel(), borders.data_ptr(), borders.numel(),
+                                                 p0, p1, _stream(stream, x.device)))
     return y, state
 
 
@@ -126,31 +170,51 @@ def quantize_backward(gy: torch.Tensor, state: torch.Tensor, levels: torch.Tenso
     k = bitwidth(levels.numel())
     if state.numel() < state_nbytes(gy.numel(), k):
         raise FewbitHipError('state buffer too small')
-    gx = torch.empty_like(gy) if out is None else _dev(out, 'out')
-    _check(lib().fewbit_hip_quantize_backward(DTYPES[gy.dtype], gy.data_ptr(), state.data_ptr(), gx.data_ptr(),
-                                              gy.numel(), levels.data_ptr(), levels.numel(), _stream(stream)))
+    with _on(gy.device):
+        gx = torch.empty_like(gy) if out is None else _dev(out, 'out')
+        _same_device(gy, state, levels, gx)
+        _check(lib().fewbit_hip_quantize_backward(DTYPES[gy.dtype], gy.data_ptr(), state.data_ptr(), gx.data_ptr(),
+                                                  gy.numel(), levels.data_ptr(), levels.numel(),
+                                                  _stream(stream, gy.device)))
     return gx
+
+
+def _bound(f, args, device: torch.device, keepalive):
+    """zero-argument launch of ``f(*args)`` with ``device`` current (see _on); one integer compare when it already is"""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    current, set_device = torch.cuda.current_device, torch.cuda.set_device
+
+    def launch():
+        prev = current()
+        if prev != index:
+            set_device(index)
+            try:
+                rc = f(*args)
+            finally:
+                set_device(prev)
+        else:
+            rc = f(*args)
+        if rc:
+            _check(rc)
+    launch.keepalive = keepalive
+    return launch
 
 
 def bind_forward(fn: str, x: torch.Tensor, borders: torch.Tensor, out: torch.Tensor, state: torch.Tensor,
                  p0: float = 0.0, p1: float = 0.0, stream: Optional[int] = None):
     """Pre-resolved launch: returns a zero-argument callable that enqueues exactly this forward (same pointers,
-    same stream) -- for loops where the per-call Python argument handling would otherwise out-weigh a ~10 us kernel."""
+    same stream, on the tensors' device) -- for loops where the per-call Python argument handling would otherwise
+    out-weigh a ~10 us kernel."""
     x, borders, out, state = _dev(x, 'x'), _dev(borders, 'borders'), _dev(out, 'out'), _dev(state, 'state')
     if borders.dtype != x.dtype or out.dtype != x.dtype:
         raise FewbitHipError('x, borders and out must share one dtype')
+    _same_device(x, borders, out, state)
     k = bitwidth(borders.numel() + 1)
     if state.numel() < state_nbytes(x.numel(), k) or out.numel() != x.numel():
         raise FewbitHipError('out/state buffers do not match the input size')
-    f = lib().fewbit_hip_quantize_forward
     args = (CONTINUOUS.index(fn), DTYPES[x.dtype], x.data_ptr(), out.data_ptr(), state.data_ptr(), x.numel(),
-            borders.data_ptr(), borders.numel(), p0, p1, _stream(stream))
-
-    def launch():
-        if f(*args):
-            _check(-1)
-    launch.keepalive = (x, borders, out, state)
-    return launch
+            borders.data_ptr(), borders.numel(), p0, p1, _stream(stream, x.device))
+    return _bound(lib().fewbit_hip_quantize_forward, args, x.device, (x, borders, out, state))
 
 
 def bind_backward(gy: torch.Tensor, state: torch.Tensor, levels: torch.Tensor, out: torch.Tensor,
@@ -159,18 +223,13 @@ def bind_backward(gy: torch.Tensor, state: torch.Tensor, levels: torch.Tensor, o
     gy, state, levels, out = _dev(gy, 'gy'), _dev(state, 'state'), _dev(levels, 'levels'), _dev(out, 'out')
     if levels.dtype != gy.dtype or out.dtype != gy.dtype:
         raise FewbitHipError('gy, levels and out must share one dtype')
+    _same_device(gy, state, levels, out)
     k = bitwidth(levels.numel())
     if state.numel() < state_nbytes(gy.numel(), k) or out.numel() != gy.numel():
         raise FewbitHipError('out/state buffers do not match the input size')
-    f = lib().fewbit_hip_quantize_backward
     args = (DTYPES[gy.dtype], gy.data_ptr(), state.data_ptr(), out.data_ptr(), gy.numel(), levels.data_ptr(),
-            levels.numel(), _stream(stream))
-
-    def launch():
-        if f(*args):
-            _check(-1)
-    launch.keepalive = (gy, state, levels, out)
-    return launch
+            levels.numel(), _stream(stream, gy.device))
+    return _bound(lib().fewbit_hip_quantize_backward, args, gy.device, (gy, state, levels, out))
 
 
 def bind_stepwise1_forward(fn: str, x: torch.Tensor, out: torch.Tensor, state: torch.Tensor, p0: float = 0.0,
@@ -179,15 +238,10 @@ def bind_stepwise1_forward(fn: str, x: torch.Tensor, out: torch.Tensor, state: t
     x, out, state = _dev(x, 'x'), _dev(out, 'out'), _dev(state, 'state')
     if out.dtype != x.dtype or out.numel() != x.numel() or state.numel() < state_nbytes(x.numel(), 1):
         raise FewbitHipError('out/state buffers do not match the input')
-    f = lib().fewbit_hip_stepwise1_forward
+    _same_device(x, out, state)
     args = (STEPWISE1.index(fn), DTYPES[x.dtype], x.data_ptr(), out.data_ptr(), state.data_ptr(), x.numel(), p0, p1,
-            _stream(stream))
-
-    def launch():
-        if f(*args):
-            _check(-1)
-    launch.keepalive = (x, out, state)
-    return launch
+            _stream(stream, x.device))
+    return _bound(lib().fewbit_hip_stepwise1_forward, args, x.device, (x, out, state))
 
 
 def bind_stepwise1_backward(fn: str, gy: torch.Tensor, state: torch.Tensor, out: torch.Tensor, p0: float = 0.0,
@@ -196,48 +250,83 @@ def bind_stepwise1_backward(fn: str, gy: torch.Tensor, state: torch.Tensor, out:
     gy, state, out = _dev(gy, 'gy'), _dev(state, 'state'), _dev(out, 'out')
     if out.dtype != gy.dtype or out.numel() != gy.numel() or state.numel() < state_nbytes(gy.numel(), 1):
         raise FewbitHipError('out/state buffers do not match the gradient')
-    f = lib().fewbit_hip_stepwise1_backward
+    _same_device(gy, state, out)
     args = (STEPWISE1.index(fn), DTYPES[gy.dtype], gy.data_ptr(), state.data_ptr(), out.data_ptr(), gy.numel(), p0,
-            _stream(stream))
-
-    def launch():
-        if f(*args):
-            _check(-1)
-    launch.keepalive = (gy, state, out)
-    return launch
+            _stream(stream, gy.device))
+    return _bound(lib().fewbit_hip_stepwise1_backward, args, gy.device, (gy, state, out))
 
 
 def stepwise1_forward(fn: str, x: torch.Tensor, p0: float = 0.0, p1: float = 0.0,
                       out: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None,
                       stream: Optional[int] = None):
     x = _dev(x, 'x')
-    y = torch.empty_like(x) if out is None else _dev(out, 'out')
-    if state is None:
-        state = torch.empty(state_nbytes(x.numel(), 1), dtype=torch.uint8, device=x.device)
-    _check(lib().fewbit_hip_stepwise1_forward(STEPWISE1.index(fn), DTYPES[x.dtype], x.data_ptr(), y.data_ptr(),
-                                              state.data_ptr(), x.numel(), p0, p1, _stream(stream)))
+    with _on(x.device):
+        y = torch.empty_like(x) if out is None else _dev(out, 'out')
+        if state is None:
+            state = torch.empty(state_nbytes(x.numel(), 1), dtype=torch.uint8, device=x.device)
+        _same_device(x, y, state)
+        _check(lib().fewbit_hip_stepwise1_forward(STEPWISE1.index(fn), DTYPES[x.dtype], x.data_ptr(), y.data_ptr(),
+                                                  state.data_ptr(), x.numel(), p0, p1, _stream(stream, x.device)))
     return y, state
 
 
 def stepwise1_backward(fn: str, gy: torch.Tensor, state: torch.Tensor, p0: float = 0.0,
                        out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
     gy, state = _dev(gy, 'gy'), _dev(state, 'state')
-    gx = torch.empty_like(gy) if out is None else _dev(out, 'out')
-    _check(lib().fewbit_hip_stepwise1_backward(STEPWISE1.index(fn), DTYPES[gy.dtype], gy.data_ptr(),
-                                               state.data_ptr(), gx.data_ptr(), gy.numel(), p0, _stream(stream)))
+    with _on(gy.device):
+        gx = torch.empty_like(gy) if out is None else _dev(out, 'out')
+        _same_device(gy, state, gx)
+        _check(lib().fewbit_hip_stepwise1_backward(STEPWISE1.index(fn), DTYPES[gy.dtype], gy.data_ptr(),
+                                                   state.data_ptr(), gx.data_ptr(), gy.numel(), p0,
+                                                   _stream(stream, gy.device)))
     return gx
 
 
 def pack_codes(codes: torch.Tensor, nbits: int, stream: Optional[int] = None) -> torch.Tensor:
     codes = _dev(codes, 'codes')
     assert codes.dtype == torch.int32
-    state = torch.empty(state_nbytes(codes.numel(), nbits), dtype=torch.uint8, device=codes.device)
-    _check(lib().fewbit_hip_pack_codes(codes.data_ptr(), state.data_ptr(), codes.numel(), nbits, _stream(stream)))
+    with _on(codes.device):
+        state = torch.empty(state_nbytes(codes.numel(), nbits), dtype=torch.uint8, device=codes.device)
+        _check(lib().fewbit_hip_pack_codes(codes.data_ptr(), state.data_ptr(), codes.numel(), nbits,
+                                           _stream(stream, codes.device)))
     return state
 
 
 def unpack_codes(state: torch.Tensor, n: int, nbits: int, stream: Optional[int] = None) -> torch.Tensor:
     state = _dev(state, 'state')
-    codes = torch.empty(n, dtype=torch.int32, device=state.device)
-    _check(lib().fewbit_hip_unpack_codes(state.data_ptr(), codes.data_ptr(), n, nbits, _stream(stream)))
+    with _on(state.device):
+        codes = torch.empty(n, dtype=torch.int32, device=state.device)
+        _check(lib().fewbit_hip_unpack_codes(state.data_ptr(), codes.data_ptr(), n, nbits, _stream(stream, state.device)))
     return codes
+
+
+# ---- what a call would launch (kernel instantiation + launch shape), and run-time launch tuning -------------------
+def _describe(call, *args, device=None) -> dict:
+    import json
+    buf = ctypes.create_string_buffer(512)
+    with _on(torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)):
+        _check(call(*args, buf, len(buf)))
+    return json.loads(buf.value.decode())
+
+
+def describe_forward(fn: str, dtype: torch.dtype, n: int, nborders: int, device=None) -> dict:
+    """Kernel and launch shape ``quantize_forward`` would use for ``n`` elements (nothing is launched)."""
+    return _describe(lib().fewbit_hip_describe_quantize_forward, CONTINUOUS.index(fn), DTYPES[dtype], n, nborders, device=device)
+
+
+def describe_backward(dtype: torch.dtype, n: int, nlevels: int, device=None) -> dict:
+    return _describe(lib().fewbit_hip_describe_quantize_backward, DTYPES[dtype], n, nlevels, device=device)
+
+
+def describe_stepwise1_forward(fn: str, dtype: torch.dtype, n: int, device=None) -> dict:
+    return _describe(lib().fewbit_hip_describe_stepwise1_forward, STEPWISE1.index(fn), DTYPES[dtype], n, device=device)
+
+
+def describe_stepwise1_backward(fn: str, dtype: torch.dtype, n: int, device=None) -> dict:
+    return _describe(lib().fewbit_hip_describe_stepwise1_backward, STEPWISE1.index(fn), DTYPES[dtype], n, device=device)
+
+
+def tune(**settings: int) -> None:
+    """Set launch-tuning keys of the library (see fewbit_hip_tune in include/fewbit_hip.h); -1 = built-in policy."""
+    for key, value in settings.items():
+        _check(lib().fewbit_hip_tune(key.encode(), int(value)))

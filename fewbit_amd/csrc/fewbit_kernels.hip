@@ -27,6 +27,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <type_traits>
 
 #include "fewbit_codepack.h"
 #include "fewbit_device.h"
@@ -193,8 +195,14 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
 // occupancy each forward instantiation is compiled for: 8 waves/SIMD (<= 64 VGPRs) where the table and
 // the two prefetch buffers fit without spilling, 6 (<= 80) for 4-bit tables (15 border VGPRs), fp32
 // groups (8 VGPRs per buffer) and mish (ocml log1p+exp+tanh).  The launcher sizes the grid from the occupancy the runtime reports.
-template <int FN, int DT, int K> constexpr int forward_waves_per_simd() {
+template <int FN, int DT, int K, int U = 1> constexpr int forward_waves_per_simd() {
+    if (U >= 4) return 4;                      // 2 x 4 raw groups per lane in flight: <= 128 VGPRs
+    if (U == 2) return (K == 4 || DT == FEWBIT_F32 || FN == FEWBIT_MISH) ? 4 : 6;
     return (K == 4 || DT == FEWBIT_F32 || FN == FEWBIT_MISH) ? 6 : kWavesPerSimd;
+}
+// backward / 1-bit kernels: 8 waves per SIMD up to two groups per lane per stage, 6 (<= 80 VGPRs) beyond
+template <int DT, int U> constexpr int stream_waves_per_simd() {
+    return (U >= 4 || (U >= 2 && DT == FEWBIT_F32)) ? 6 : kWavesPerSimd;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,7 +211,7 @@ template <int FN, int DT, int K> constexpr int forward_waves_per_simd() {
 // Replaces StepwiseKernel<Fn> + BinarySearch + DeflateWarpKernel (fewbit/cuda/codec.cu:489-504,
 // :118-131, :142-165).
 template <int FN, int DT, int K, int U>
-__global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void quantize_forward_kernel(const void *x, void *y,
+__global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) void quantize_forward_kernel(const void *x, void *y,
                                                                   uint8_t *__restrict__ state, size_t n,
                                                                   const void *__restrict__ borders, float p0,
                                                                   float p1, int chunk) {
@@ -304,24 +312,24 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K>())) void
 // instructions -- independent of K -- and runs on the otherwise idle LDS unit, which takes the forward from
 // VALU-bound back to memory-bound.  Blocks are 1024 threads (16 waves) so that two of them (2 x 64 KiB of LDS) fill
 // a CU with 32 waves.
-#ifndef FEWBIT_LUT_WPS
-#define FEWBIT_LUT_WPS 8      // waves per SIMD the table kernel is compiled for (two 16-wave blocks per CU)
-#endif
 #ifndef FEWBIT_LUT_BLOCK
-#define FEWBIT_LUT_BLOCK 1024   // threads per block of the pattern-table kernels (a multiple of 64)
+#define FEWBIT_LUT_BLOCK 1024   // threads per block of the pattern-table kernels (512 or 1024)
 #endif
 constexpr int kLutBlock = FEWBIT_LUT_BLOCK;
 constexpr int kLutWaves = kLutBlock / kWave;
+// two blocks per CU (2 x 64 KiB of LDS): 1024 threads -> 8 waves per SIMD (<= 64 VGPRs), 512 threads -> 4 (<= 128)
+template <int BLOCK> constexpr int lut_waves_per_simd() { return 2 * BLOCK / 256; }
 
 template <int DT> __device__ __forceinline__ float value_of_pattern(uint32_t r) {
     if constexpr (DT == FEWBIT_BF16) return bits_f32(r << 16);
     else return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(r)));
 }
 
-template <int FN, int DT, int K, int U>
-__global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lut_kernel(const void *x, void *y, uint8_t *state,
+template <int FN, int DT, int K, int U, int BLOCK = kLutBlock>
+__global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize_forward_lut_kernel(const void *x, void *y, uint8_t *state,
                                                                             size_t n, const void *borders,
                                                                             int nborders, float p0, float p1, int chunk) {
+    constexpr int kLutBlock = BLOCK, kLutWaves = BLOCK / kWave;        // (shadow the file-level defaults)
     static_assert(DT != FEWBIT_F32, "the pattern table exists for 16-bit dtypes only");
     constexpr int NBMAX = (1 << K) - 1;
     constexpr uint32_t kInf = (DT == FEWBIT_BF16) ? 0x7f80u : 0x7c00u;
@@ -508,7 +516,7 @@ __global__ __launch_bounds__(kBlock, 6) void quantize_forward_wide_kernel(const 
 // staged in LDS (float for the tree descent of pass 1, raw pattern for the fix-up of pass 2, which loops over them
 // 16 waves at a time); everything else as in quantize_forward_lut_kernel.
 template <int FN, int DT>
-__global__ __launch_bounds__(kLutBlock, FEWBIT_LUT_WPS) void quantize_forward_lut_wide_kernel(const void *x, void *y,
+__global__ __launch_bounds__(kLutBlock, (lut_waves_per_simd<kLutBlock>())) void quantize_forward_lut_wide_kernel(const void *x, void *y,
                                                                                  uint8_t *state, size_t n,
                                                                                  const void *borders, int nborders,
                                                                                  int nbits, float p0, float p1, int chunk) {
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_
 // Fused backward: unpack + level gather (LDS) + multiply, same software pipeline.
 // Replaces StepwiseBackwardKernel + InflateWarpKernel (fewbit/cuda/codec.cu:655-663, :184-203).
 template <int DT, int K, int U>
-__global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kernel(const void *gy,
+__global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quantize_backward_kernel(const void *gy,
                                                                    const uint8_t *state, void *gx,
                                                                    size_t n, const void *__restrict__ levels,
                                                                    int nlevels, int chunk) {
@@ -712,7 +720,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_kerne
 // 1-bit family (ReLU & co): exact derivative, one bit per element.
 // Replaces the eight <Name>Kernel / <Name>BackwardKernel pairs, fewbit/cuda/codec.cu:298-487.
 template <int FN, int DT, int U>
-__global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kernel(const void *x, void *y,
+__global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void stepwise1_forward_kernel(const void *x, void *y,
                                                                    uint8_t *__restrict__ state, size_t n, float p0,
                                                                    float p1, int chunk) {
     typedef typename GroupIO<DT>::Raw Raw;
@@ -771,7 +779,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_forward_kerne
 }
 
 template <int DT, int U>
-__global__ __launch_bounds__(kBlock, kWavesPerSimd) void stepwise1_backward_kernel(const void *gy,
+__global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void stepwise1_backward_kernel(const void *gy,
                                                                     const uint8_t *state, void *gx,
                                                                     size_t n, float m0, float m1, int chunk) {
     typedef typename GroupIO<DT>::Raw Raw;
@@ -911,93 +919,117 @@ size_t dtype_size(int dtype) { return dtype == FEWBIT_F32 ? 4 : 2; }
         if (rc_ != FEWBIT_OK) return rc_;                            \
     } while (0)
 
-// groups per lane per pipeline stage (tunable, FEWBIT_HIP_U) and resident waves per CU the grid is
-// sized for (FEWBIT_HIP_WAVES_PER_CU); defaults from measurements on MI355X, see DESIGN.md
-#ifndef FEWBIT_U16
-#define FEWBIT_U16 1
-#endif
-#ifndef FEWBIT_U32
-#define FEWBIT_U32 1
-#endif
-#ifndef FEWBIT_U16_BWD
-#define FEWBIT_U16_BWD 2
-#endif
-#ifndef FEWBIT_U16_LUT
-#define FEWBIT_U16_LUT 1
-#endif
-// forward: 1 group per lane per stage (VALU-heavy, register budget); backward: 2 (memory-bound, deeper loads:
-// 8192x8192 fp16 backward 47.3 -> 43.0 us, no change at 4096x4096)
-template <int DT> struct Tile {
-    static constexpr int U = (DT == FEWBIT_F32) ? FEWBIT_U32 : FEWBIT_U16;
-    static constexpr int UB = (DT == FEWBIT_F32) ? FEWBIT_U32 : FEWBIT_U16_BWD;
+// ------------------------------------------------------------------------------------------------
+// Run-time tuning.  Every key is -1 ("built-in policy") unless its environment variable is set when the library makes
+// its first launch, or fewbit_hip_tune() sets it later (measurement scripts sweep shapes inside one process that way).
+enum TuneKey {
+    T_WAVES_PER_CU,        // cap on the resident waves per CU a streaming kernel's grid is sized for
+    T_CHUNK,               // search / backward / 1-bit kernels: 0 = resident shape, T = chunked with T tiles per wave
+    T_LUT_CHUNK,           // the same for the pattern-table forward
+    T_LUT_BLOCKS_PER_CU,   // cap on resident pattern-table blocks per CU (at most 2 fit: 64 KiB of LDS each)
+    T_LUT_MIN,             // smallest tensor (elements) that takes the pattern-table forward; 0 = always
+    T_LUT_BLOCK,           // threads per pattern-table block (512 or 1024), where the build has both
+    T_U_FWD, T_U_BWD, T_U_LUT, T_U_STEP1,     // groups per lane per pipeline stage (1, 2 or 4), where the build has them
+    T_COUNT
 };
+struct TuneSpec { const char *key, *env; };
+constexpr TuneSpec kTuneSpec[T_COUNT] = {
+    {"waves_per_cu", "FEWBIT_HIP_WAVES_PER_CU"}, {"chunk", "FEWBIT_HIP_CHUNK"}, {"lut_chunk", "FEWBIT_HIP_LUT_CHUNK"},
+    {"lut_blocks_per_cu", "FEWBIT_HIP_LUT_BLOCKS_PER_CU"}, {"lut_min", "FEWBIT_HIP_LUT_MIN"}, {"lut_block", "FEWBIT_HIP_LUT_BLOCK"},
+    {"u_fwd", "FEWBIT_HIP_U_FWD"}, {"u_bwd", "FEWBIT_HIP_U_BWD"}, {"u_lut", "FEWBIT_HIP_U_LUT"}, {"u_step1", "FEWBIT_HIP_U_STEP1"},
+};
+std::atomic<long long> g_tune[T_COUNT];
+std::once_flag g_tune_once;
 
-// Launch geometry is cached PER DEVICE (index of the calling thread's current device: the torch glue and the ctypes
-// binding both launch with the tensors' device current).  Plain relaxed atomics: two threads racing on a first use store
-// the same value.
-constexpr int kMaxDevices = 64;
-
-int current_device() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
-    return dev;
+void tune_init() {
+    std::call_once(g_tune_once, [] {
+        for (int i = 0; i < T_COUNT; ++i) {
+            const char *e = getenv(kTuneSpec[i].env);
+            g_tune[i].store(e && *e ? atoll(e) : -1ll, std::memory_order_relaxed);
+        }
+    });
+}
+long long tune(TuneKey k) {
+    tune_init();
+    return g_tune[k].load(std::memory_order_relaxed);
 }
 
-int device_cus() {
+// ------------------------------------------------------------------------------------------------
+// The device a call launches on = the calling thread's current device, resolved ONCE per call (the torch glue and the
+// ctypes binding both make the tensors' device current first).  Geometry is cached per device index.
+constexpr int kMaxDevices = 64;
+struct Device { int index = 0, cus = 256; };
+
+int get_device(Device &d) {
     static std::atomic<int> cus[kMaxDevices];
-    const int dev = current_device();
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FEWBIT_ERR_LAUNCH, "hipGetDevice failed: no current HIP device");
+    }
+    if (dev < 0 || dev >= kMaxDevices) return fail(FEWBIT_ERR_UNSUPPORTED, "device index %d outside [0, %d)", dev, kMaxDevices);
     int v = cus[dev].load(std::memory_order_relaxed);
     if (v == 0) {
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cus[dev].store(v, std::memory_order_relaxed);
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) {
+            (void)hipGetLastError();
+            v = 256;
+        }
+        cus[dev].store(v, std::memory_order_relaxed);     // (two threads racing on a first use store the same value)
     }
-    return v;
+    d.index = dev;
+    d.cus = v;
+    return FEWBIT_OK;
 }
 
-// resident blocks per CU of a kernel (runtime's occupancy answer, cached per kernel and device); the streaming
-// kernels are launched with exactly one resident generation of waves, which then loop over tiles.
-// FEWBIT_HIP_WAVES_PER_CU (tuning hook) caps it.
-template <auto Kern> int resident_blocks_per_cu() {
-    static std::atomic<int> cached[kMaxDevices];  // one array per kernel instantiation
-    const int dev = current_device();
-    int nb = cached[dev].load(std::memory_order_relaxed);
+// resident blocks per CU of a kernel instantiation: the runtime's occupancy answer, cached per kernel and device
+template <auto Kern> int occupancy_blocks_per_cu(const Device &d, int threads) {
+    static std::atomic<int> cached[kMaxDevices];
+    int nb = cached[d.index].load(std::memory_order_relaxed);
     if (nb == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kern, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
-        if (nb > 8) nb = 8;
-        const char *e = getenv("FEWBIT_HIP_WAVES_PER_CU");
-        if (e && atoi(e) >= kWavesPerBlock && atoi(e) / kWavesPerBlock < nb) nb = atoi(e) / kWavesPerBlock;
-        cached[dev].store(nb, std::memory_order_relaxed);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kern, threads, 0) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 1;
+        }
+        cached[d.index].store(nb, std::memory_order_relaxed);
     }
     return nb;
 }
 
+// What a call launched (or would launch: fewbit_hip_describe_*): kernel instantiation and launch shape.
+struct Plan {
+    char kernel[128];
+    unsigned blocks;
+    int threads, chunk, u, k, blocks_per_cu;
+};
+
+const char *const kFnNames[FEWBIT_CONTINUOUS_COUNT] = {"celu", "elu", "gelu", "hardswish", "logsigmoid", "mish", "selu", "sigmoid",
+                                                       "silu", "softplus", "softsign", "tanh", "tanhshrink", "identity",
+                                                       "identity_fold"};
+const char *const kStepNames[FEWBIT_STEPWISE_COUNT] = {"hardshrink", "hardsigmoid", "hardtanh", "leaky_relu", "relu", "relu6",
+                                                       "softshrink", "threshold"};
+const char *dtype_name(int dt) { return dt == FEWBIT_F32 ? "f32" : dt == FEWBIT_F16 ? "f16" : "bf16"; }
+
 // Launch shape of a streaming kernel (see Span): RESIDENT (chunk = 0: one wave per tile until the chip is full, then the
 // resident waves loop round-robin) or CHUNKED (chunk = T tiles per wave, block-contiguous, as many blocks as that takes).
 struct Shape { unsigned blocks; int chunk; };
-
-// tiles per wave of the chunked shape; 0 = resident.  FEWBIT_HIP_CHUNK / FEWBIT_HIP_LUT_CHUNK (tuning hooks): -1 or unset =
-// the built-in policy, 0 = always resident, T = chunk of T wherever the tensor has more tiles than resident waves.
-int chunk_setting(const char *var) {
-    const char *e = getenv(var);
-    return e ? atoi(e) : -1;
-}
 
 // Built-in policy (measured on MI355X, scratch/headvar.py with SIZES=...): the resident shape wins
 // while a wave has only a few tiles (4096x4096 bf16: 11.2 vs 11.6 us), the chunked shape wins once the tensor is many
 // times the resident generation, where statically assigned waves drift apart and the launch waits for the slowest
 // (2^28 bf16 elements: backward 235 -> 197 us, pattern-table forward 224 -> 197 us; RoBERTa-size fp32, 5*10^7 elements:
 // forward+backward 169 -> 151 us).  `min_ratio` = tiles per resident wave from which the chunked shape is used.
-Shape launch_shape(size_t ntiles, int waves_per_block, size_t resident_blocks, int setting, int auto_chunk, size_t min_ratio) {
+// `setting`: -1 = that policy, 0 = always resident, T = chunk of T wherever the tensor has more tiles than resident waves.
+Shape launch_shape(size_t ntiles, int waves_per_block, size_t resident_blocks, long long setting, int auto_chunk, size_t min_ratio) {
     const size_t wpb = static_cast<size_t>(waves_per_block);
     size_t blocks = (ntiles + wpb - 1) / wpb;                      // one tile per wave
     int chunk = 0;
     if (blocks > resident_blocks) {
-        int t = setting;
+        long long t = setting;
         if (t < 0) t = ntiles >= min_ratio * resident_blocks * wpb ? auto_chunk : 0;
         const size_t chunked = t > 0 ? (ntiles + wpb * t - 1) / (wpb * t) : 0;
         if (t > 0 && chunked > resident_blocks) {
             blocks = chunked;
-            chunk = t;
+            chunk = static_cast<int>(t);
         } else {
             blocks = resident_blocks;
         }
@@ -1022,138 +1054,343 @@ Shape launch_shape(size_t ntiles, int waves_per_block, size_t resident_blocks, i
 #define FEWBIT_AUTO_LUT_CHUNK_RATIO 12
 #endif
 
-template <auto Kern> Shape tile_shape(size_t n, int U) {
-    static const int setting = chunk_setting("FEWBIT_HIP_CHUNK");
+// launch (or, dry, only describe) a 256-thread streaming kernel instantiation; the kernels' last parameter is the chunk
+template <auto Kern, typename... Args>
+void launch_tiled(Plan *plan, bool dry, const Device &dev, size_t n, int U, hipStream_t s, Args... args) {
+    int per_cu = occupancy_blocks_per_cu<Kern>(dev, kBlock);
+    if (per_cu > 8) per_cu = 8;
+    const long long cap = tune(T_WAVES_PER_CU);
+    if (cap >= kWavesPerBlock && cap / kWavesPerBlock < per_cu) per_cu = static_cast<int>(cap / kWavesPerBlock);
     const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
-    return launch_shape(ntiles, kWavesPerBlock, static_cast<size_t>(device_cus()) * resident_blocks_per_cu<Kern>(), setting,
-                        FEWBIT_AUTO_CHUNK, FEWBIT_AUTO_CHUNK_RATIO);
+    const Shape sh = launch_shape(ntiles, kWavesPerBlock, static_cast<size_t>(dev.cus) * per_cu, tune(T_CHUNK), FEWBIT_AUTO_CHUNK,
+                                  FEWBIT_AUTO_CHUNK_RATIO);
+    if (plan) {
+        plan->blocks = sh.blocks;
+        plan->threads = kBlock;
+        plan->chunk = sh.chunk;
+        plan->u = U;
+        plan->blocks_per_cu = per_cu;
+    }
+    if (!dry) hipLaunchKernelGGL(Kern, dim3(sh.blocks), dim3(kBlock), 0, s, args..., sh.chunk);
 }
 
-// launch a streaming kernel instantiation (the kernels' last parameter is the chunk)
-#define FB_LAUNCH_TILED(KERN, N, U, STREAM, ...)                                                                   \
-    do {                                                                                                           \
-        const Shape sh_ = tile_shape<(KERN)>((N), (U));                                                            \
-        hipLaunchKernelGGL((KERN), dim3(sh_.blocks), dim3(kBlock), 0, (STREAM), __VA_ARGS__, sh_.chunk);           \
-    } while (0)
+// pattern-table forward: BLOCK-thread blocks, at most two resident per CU (LDS), each wave loops over its tiles
+template <auto Kern, int BLOCK, typename... Args>
+void launch_lut(Plan *plan, bool dry, const Device &dev, size_t n, int U, hipStream_t s, Args... args) {
+    int per_cu = occupancy_blocks_per_cu<Kern>(dev, BLOCK);
+    if (per_cu > 2) per_cu = 2;
+    const long long cap = tune(T_LUT_BLOCKS_PER_CU);
+    if (cap >= 1 && cap < per_cu) per_cu = static_cast<int>(cap);
+    const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
+    const Shape sh = launch_shape(ntiles, BLOCK / kWave, static_cast<size_t>(dev.cus) * per_cu, tune(T_LUT_CHUNK),
+                                  FEWBIT_AUTO_LUT_CHUNK, FEWBIT_AUTO_LUT_CHUNK_RATIO);
+    if (plan) {
+        plan->blocks = sh.blocks;
+        plan->threads = BLOCK;
+        plan->chunk = sh.chunk;
+        plan->u = U;
+        plan->blocks_per_cu = per_cu;
+    }
+    if (!dry) hipLaunchKernelGGL(Kern, dim3(sh.blocks), dim3(BLOCK), 0, s, args..., sh.chunk);
+}
 
-// pattern-table forward: 1024-thread blocks, two resident per CU (LDS), each wave loops over its tiles
-// Smallest tensor that takes it: building the table costs the same whatever the table, the register search it replaces
-// costs 2^k - 1 + k slow-class VALU per element -- measured crossover (scratch/xover.py, round 2): 6 Mi elements for
-// k <= 3 (6.39 vs 6.43 us), 4.5 Mi for k = 4 (5 Mi: 6.48 vs 6.68 us).  FEWBIT_HIP_LUT_MIN (tuning hook) overrides both; a
-// huge value disables the kernel.
+// Smallest tensor that takes the pattern-table forward: building the table costs the same whatever the table, the register
+// search it replaces costs 2^k - 1 + k slow-class VALU per element -- measured crossover (scratch/xover.py, round 2):
+// 6 Mi elements for k <= 3 (6.39 vs 6.43 us), 4.5 Mi for k = 4 (5 Mi: 6.48 vs 6.68 us).  lut_min overrides both; a huge
+// value disables the kernel.
 size_t lut_min_elements(int k) {
-    static const long long forced = [] {
-        const char *e = getenv("FEWBIT_HIP_LUT_MIN");
-        return e ? atoll(e) : -1ll;
-    }();
+    const long long forced = tune(T_LUT_MIN);
     if (forced >= 0) return forced == 0 ? 1 : static_cast<size_t>(forced);
     return k == 4 ? (static_cast<size_t>(9) << 19) : (static_cast<size_t>(6) << 20);
 }
 
-template <auto Kern> Shape lut_shape(size_t n, int U) {
-    static std::atomic<int> cached[kMaxDevices];
-    static const int setting = chunk_setting("FEWBIT_HIP_LUT_CHUNK");
-    const int dev = current_device();
-    int per_cu = cached[dev].load(std::memory_order_relaxed);
-    if (per_cu == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kern, kLutBlock, 0) != hipSuccess || nb < 1) nb = 1;
-        per_cu = nb > 2 ? 2 : nb;
-        if (const char *e = getenv("FEWBIT_HIP_LUT_BLOCKS_PER_CU")) {   // tuning hook
-            const int v = atoi(e);
-            if (v >= 1 && v < per_cu) per_cu = v;
+// Groups per lane per pipeline stage.  Which values a build holds: the cheap kernels (backward, 1-bit) always 1, 2 and 4;
+// the forward kernels (15 functors x 3 dtypes x 4 widths each) only the policy's own unless built with -DFEWBIT_SWEEP
+// (scratch measurement build: fewer functors, every U, both table block sizes).
+template <int... Us> struct UList {};
+#ifdef FEWBIT_SWEEP
+typedef UList<1, 2, 4> FwdUs16;
+typedef UList<1, 2> FwdUs32;
+typedef UList<1, 2, 4> LutUs;
+#else
+typedef UList<1> FwdUs16;
+typedef UList<1> FwdUs32;
+typedef UList<1> LutUs;
+#endif
+typedef UList<1, 2, 4> StreamUs16;
+typedef UList<1, 2> StreamUs32;
+
+// call f(integral_constant<U>) for the U of the list that `want` names (the list's first entry if it names none)
+template <int U0, int... Us, typename F> void with_u(UList<U0, Us...>, long long want, F &&f) {
+    bool done = false;
+    auto one = [&](auto tag) {
+        if (!done && want == decltype(tag)::value) {
+            done = true;
+            f(tag);
         }
-        cached[dev].store(per_cu, std::memory_order_relaxed);
-    }
-    const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
-    return launch_shape(ntiles, kLutWaves, static_cast<size_t>(device_cus()) * per_cu, setting, FEWBIT_AUTO_LUT_CHUNK,
-                        FEWBIT_AUTO_LUT_CHUNK_RATIO);
+    };
+    one(std::integral_constant<int, U0>{});
+    (one(std::integral_constant<int, Us>{}), ...);
+    if (!done) f(std::integral_constant<int, U0>{});
 }
 
-#define FB_LAUNCH_LUT(KERN, N, U, STREAM, ...)                                                                     \
-    do {                                                                                                           \
-        const Shape sh_ = lut_shape<(KERN)>((N), (U));                                                             \
-        hipLaunchKernelGGL((KERN), dim3(sh_.blocks), dim3(kLutBlock), 0, (STREAM), __VA_ARGS__, sh_.chunk);        \
-    } while (0)
+// built-in U policy (MI355X measurements, profiles/r03_shape_sweep_*.txt)
+template <int DT> long long policy_u_fwd(size_t) { return 1; }
+template <int DT> long long policy_u_lut(size_t) { return 1; }
+template <int DT> long long policy_u_bwd(size_t) { return DT == FEWBIT_F32 ? 1 : 2; }
+template <int DT> long long policy_u_step1_fwd(size_t) { return 1; }
+template <int DT> long long policy_u_step1_bwd(size_t) { return DT == FEWBIT_F32 ? 1 : 2; }
+long long tuned(TuneKey key, long long policy) {
+    const long long t = tune(key);
+    return t > 0 ? t : policy;
+}
 
 unsigned group_grid(size_t n) { return static_cast<unsigned>(((n + 7) / 8 + kBlock - 1) / kBlock); }
 
 template <int FN, int DT>
-int launch_forward(const void *x, void *y, uint8_t *state, size_t n, const void *borders, int nborders, int k,
-                   float p0, float p1, hipStream_t s) {
-    constexpr int U = Tile<DT>::U;
+int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state, size_t n, const void *borders, int nborders,
+                   int k, float p0, float p1, hipStream_t s) {
+    Device dev;
+    if (const int rc = get_device(dev)) return rc;
     const bool pow2 = nborders == (1 << k) - 1;
+    if (plan) plan->k = k;
+    auto name = [&](const char *kern, int U, int block) {
+        if (plan) snprintf(plan->kernel, sizeof plan->kernel, "%s<%s, %s, %d bits, U=%d, block=%d>", kern, kFnNames[FN], dtype_name(DT), k, U, block);
+    };
     // (a folded key |x - shift| is an fp32 value, not one of the 65 536 input patterns: search kernels only)
     if constexpr (DT != FEWBIT_F32 && FN != FEWBIT_IDENTITY_FOLD) {
         // 16-bit dtypes, any table (power of two or not): pattern-table kernel once the tensor is big enough to pay for
         // building the table in every block
         if (n >= lut_min_elements(k)) {
-            constexpr int UL = FEWBIT_U16_LUT;
-            switch (k) {
-            case 1: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 1, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
-            case 2: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 2, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
-            case 3: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 3, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
-            case 4: FB_LAUNCH_LUT((quantize_forward_lut_kernel<FN, DT, 4, UL>), n, UL, s, x, y, state, n, borders, nborders, p0, p1); break;
-            default:
-                FB_LAUNCH_LUT((quantize_forward_lut_wide_kernel<FN, DT>), n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
+            if (k > 4) {
+                launch_lut<quantize_forward_lut_wide_kernel<FN, DT>, kLutBlock>(plan, dry, dev, n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
+                name("quantize_forward_lut_wide_kernel", 1, kLutBlock);
+                return dry ? FEWBIT_OK : check_launch("quantize_forward(lut)");
             }
-            return check_launch("quantize_forward(lut)");
+            with_u(LutUs{}, tuned(T_U_LUT, policy_u_lut<DT>(n)), [&](auto tag) {
+                constexpr int U = decltype(tag)::value;
+                auto go = [&](auto btag) {
+                    constexpr int B = decltype(btag)::value;
+                    switch (k) {
+                    case 1: launch_lut<quantize_forward_lut_kernel<FN, DT, 1, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    case 2: launch_lut<quantize_forward_lut_kernel<FN, DT, 2, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    case 3: launch_lut<quantize_forward_lut_kernel<FN, DT, 3, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    default: launch_lut<quantize_forward_lut_kernel<FN, DT, 4, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    }
+                    name("quantize_forward_lut_kernel", U, B);
+                };
+#ifdef FEWBIT_SWEEP
+                if (tune(T_LUT_BLOCK) == 512) go(std::integral_constant<int, 512>{});
+                else go(std::integral_constant<int, 1024>{});
+#else
+                go(std::integral_constant<int, kLutBlock>{});
+#endif
+            });
+            return dry ? FEWBIT_OK : check_launch("quantize_forward(lut)");
         }
     }
     if (pow2 && k <= 4) {          // full 1..4-bit tables: borders in registers
-        switch (k) {
-        case 1: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 1, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
-        case 2: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 2, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
-        case 3: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 3, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
-        default: FB_LAUNCH_TILED((quantize_forward_kernel<FN, DT, 4, U>), n, U, s, x, y, state, n, borders, p0, p1); break;
-        }
+        typedef typename std::conditional<DT == FEWBIT_F32, FwdUs32, FwdUs16>::type Us;
+        with_u(Us{}, tuned(T_U_FWD, policy_u_fwd<DT>(n)), [&](auto tag) {
+            constexpr int U = decltype(tag)::value;
+            switch (k) {
+            case 1: launch_tiled<quantize_forward_kernel<FN, DT, 1, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
+            case 2: launch_tiled<quantize_forward_kernel<FN, DT, 2, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
+            case 3: launch_tiled<quantize_forward_kernel<FN, DT, 3, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
+            default: launch_tiled<quantize_forward_kernel<FN, DT, 4, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
+            }
+            name("quantize_forward_kernel", U, kBlock);
+        });
     } else {                       // 5..8-bit tables and tables that do not fill their bit width: borders in LDS
-        FB_LAUNCH_TILED((quantize_forward_wide_kernel<FN, DT>), n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
+        launch_tiled<quantize_forward_wide_kernel<FN, DT>>(plan, dry, dev, n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
+        name("quantize_forward_wide_kernel", 1, kBlock);
     }
-    return check_launch("quantize_forward");
+    return dry ? FEWBIT_OK : check_launch("quantize_forward");
 }
 
 template <int FN>
-int dispatch_forward_dtype(int dtype, const void *x, void *y, uint8_t *state, size_t n, const void *borders,
+int dispatch_forward_dtype(Plan *plan, bool dry, int dtype, const void *x, void *y, uint8_t *state, size_t n, const void *borders,
                            int nborders, int k, float p0, float p1, hipStream_t s) {
     switch (dtype) {
-    case FEWBIT_F32: return launch_forward<FN, FEWBIT_F32>(x, y, state, n, borders, nborders, k, p0, p1, s);
-    case FEWBIT_F16: return launch_forward<FN, FEWBIT_F16>(x, y, state, n, borders, nborders, k, p0, p1, s);
-    case FEWBIT_BF16: return launch_forward<FN, FEWBIT_BF16>(x, y, state, n, borders, nborders, k, p0, p1, s);
+    case FEWBIT_F32: return launch_forward<FN, FEWBIT_F32>(plan, dry, x, y, state, n, borders, nborders, k, p0, p1, s);
+    case FEWBIT_F16: return launch_forward<FN, FEWBIT_F16>(plan, dry, x, y, state, n, borders, nborders, k, p0, p1, s);
+    case FEWBIT_BF16: return launch_forward<FN, FEWBIT_BF16>(plan, dry, x, y, state, n, borders, nborders, k, p0, p1, s);
     default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
     }
 }
 
 template <int DT>
-int launch_backward(const void *gy, const uint8_t *state, void *gx, size_t n, const void *levels, int nlevels, int k,
-                    hipStream_t s) {
-    constexpr int U = Tile<DT>::UB;
-    switch (k) {
-    case 1: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 1, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
-    case 2: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 2, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
-    case 3: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 3, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
-    case 4: FB_LAUNCH_TILED((quantize_backward_kernel<DT, 4, U>), n, U, s, gy, state, gx, n, levels, nlevels); break;
-    default: FB_LAUNCH_TILED((quantize_backward_wide_kernel<DT>), n, 1, s, gy, state, gx, n, levels, nlevels, k);
+int launch_backward(Plan *plan, bool dry, const void *gy, const uint8_t *state, void *gx, size_t n, const void *levels, int nlevels,
+                    int k, hipStream_t s) {
+    Device dev;
+    if (const int rc = get_device(dev)) return rc;
+    if (plan) plan->k = k;
+    if (k > 4) {
+        launch_tiled<quantize_backward_wide_kernel<DT>>(plan, dry, dev, n, 1, s, gy, state, gx, n, levels, nlevels, k);
+        if (plan) snprintf(plan->kernel, sizeof plan->kernel, "quantize_backward_wide_kernel<%s, %d bits>", dtype_name(DT), k);
+        return dry ? FEWBIT_OK : check_launch("quantize_backward");
     }
-    return check_launch("quantize_backward");
+    typedef typename std::conditional<DT == FEWBIT_F32, StreamUs32, StreamUs16>::type Us;
+    with_u(Us{}, tuned(T_U_BWD, policy_u_bwd<DT>(n)), [&](auto tag) {
+        constexpr int U = decltype(tag)::value;
+        switch (k) {
+        case 1: launch_tiled<quantize_backward_kernel<DT, 1, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
+        case 2: launch_tiled<quantize_backward_kernel<DT, 2, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
+        case 3: launch_tiled<quantize_backward_kernel<DT, 3, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
+        default: launch_tiled<quantize_backward_kernel<DT, 4, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
+        }
+        if (plan) snprintf(plan->kernel, sizeof plan->kernel, "quantize_backward_kernel<%s, %d bits, U=%d>", dtype_name(DT), k, U);
+    });
+    return dry ? FEWBIT_OK : check_launch("quantize_backward");
 }
 
 template <int FN, int DT>
-int launch_step1_forward(const void *x, void *y, uint8_t *state, size_t n, float p0, float p1, hipStream_t s) {
-    constexpr int U = Tile<DT>::U;
-    FB_LAUNCH_TILED((stepwise1_forward_kernel<FN, DT, U>), n, U, s, x, y, state, n, p0, p1);
-    return check_launch("stepwise1_forward");
+int launch_step1_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state, size_t n, float p0, float p1, hipStream_t s) {
+    Device dev;
+    if (const int rc = get_device(dev)) return rc;
+    if (plan) plan->k = 1;
+    typedef typename std::conditional<DT == FEWBIT_F32, StreamUs32, StreamUs16>::type Us;
+    with_u(Us{}, tuned(T_U_STEP1, policy_u_step1_fwd<DT>(n)), [&](auto tag) {
+        constexpr int U = decltype(tag)::value;
+        launch_tiled<stepwise1_forward_kernel<FN, DT, U>>(plan, dry, dev, n, U, s, x, y, state, n, p0, p1);
+        if (plan) snprintf(plan->kernel, sizeof plan->kernel, "stepwise1_forward_kernel<%s, %s, U=%d>", kStepNames[FN], dtype_name(DT), U);
+    });
+    return dry ? FEWBIT_OK : check_launch("stepwise1_forward");
 }
 
 template <int FN>
-int dispatch_step1_dtype(int dtype, const void *x, void *y, uint8_t *state, size_t n, float p0, float p1,
+int dispatch_step1_dtype(Plan *plan, bool dry, int dtype, const void *x, void *y, uint8_t *state, size_t n, float p0, float p1,
                          hipStream_t s) {
     switch (dtype) {
-    case FEWBIT_F32: return launch_step1_forward<FN, FEWBIT_F32>(x, y, state, n, p0, p1, s);
-    case FEWBIT_F16: return launch_step1_forward<FN, FEWBIT_F16>(x, y, state, n, p0, p1, s);
-    case FEWBIT_BF16: return launch_step1_forward<FN, FEWBIT_BF16>(x, y, state, n, p0, p1, s);
+    case FEWBIT_F32: return launch_step1_forward<FN, FEWBIT_F32>(plan, dry, x, y, state, n, p0, p1, s);
+    case FEWBIT_F16: return launch_step1_forward<FN, FEWBIT_F16>(plan, dry, x, y, state, n, p0, p1, s);
+    case FEWBIT_BF16: return launch_step1_forward<FN, FEWBIT_BF16>(plan, dry, x, y, state, n, p0, p1, s);
     default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
     }
+}
+
+template <int DT>
+int launch_step1_backward(Plan *plan, bool dry, const void *gy, const uint8_t *state, void *gx, size_t n, float m0, float m1,
+                          hipStream_t s) {
+    Device dev;
+    if (const int rc = get_device(dev)) return rc;
+    if (plan) plan->k = 1;
+    typedef typename std::conditional<DT == FEWBIT_F32, StreamUs32, StreamUs16>::type Us;
+    with_u(Us{}, tuned(T_U_STEP1, policy_u_step1_bwd<DT>(n)), [&](auto tag) {
+        constexpr int U = decltype(tag)::value;
+        launch_tiled<stepwise1_backward_kernel<DT, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, m0, m1);
+        if (plan) snprintf(plan->kernel, sizeof plan->kernel, "stepwise1_backward_kernel<%s, U=%d>", dtype_name(DT), U);
+    });
+    return dry ? FEWBIT_OK : check_launch("stepwise1_backward");
+}
+
+// the functors a build holds (-DFEWBIT_SWEEP: measurement build, three of them)
+#ifdef FEWBIT_SWEEP
+#define FB_CONTINUOUS_CASES FB_CASE(FEWBIT_GELU) FB_CASE(FEWBIT_SILU)
+#define FB_STEPWISE_CASES FB_CASE(FEWBIT_RELU)
+#else
+#define FB_CONTINUOUS_CASES                                                                                  \
+    FB_CASE(FEWBIT_CELU) FB_CASE(FEWBIT_ELU) FB_CASE(FEWBIT_GELU) FB_CASE(FEWBIT_HARDSWISH)                 \
+    FB_CASE(FEWBIT_LOGSIGMOID) FB_CASE(FEWBIT_MISH) FB_CASE(FEWBIT_SELU) FB_CASE(FEWBIT_SIGMOID)            \
+    FB_CASE(FEWBIT_SILU) FB_CASE(FEWBIT_SOFTPLUS) FB_CASE(FEWBIT_SOFTSIGN) FB_CASE(FEWBIT_TANH)             \
+    FB_CASE(FEWBIT_TANHSHRINK) FB_CASE(FEWBIT_IDENTITY) FB_CASE(FEWBIT_IDENTITY_FOLD)
+#define FB_STEPWISE_CASES                                                                                    \
+    FB_CASE(FEWBIT_HARDSHRINK) FB_CASE(FEWBIT_HARDSIGMOID) FB_CASE(FEWBIT_HARDTANH) FB_CASE(FEWBIT_LEAKY_RELU) \
+    FB_CASE(FEWBIT_RELU) FB_CASE(FEWBIT_RELU6) FB_CASE(FEWBIT_SOFTSHRINK) FB_CASE(FEWBIT_THRESHOLD)
+#endif
+
+// ---- the four entry points with a `dry` flag (describe = the same dispatch without the launch) ----
+int do_quantize_forward(Plan *plan, bool dry, int fn, int dtype, const void *x, void *y, uint8_t *state, size_t n,
+                        const void *borders, int nborders, double p0, double p1, void *stream) {
+    if (nborders < 1 || nborders > 255) return fail(FEWBIT_ERR_UNSUPPORTED, "nborders=%d outside [1,255]", nborders);
+    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    const int k = fewbit_hip_bitwidth(nborders + 1);
+    if (!dry) {
+        if (n == 0) return FEWBIT_OK;
+        if (!x || !y || !state || !borders) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+        FB_VALIDATE("x", x, n * dtype_size(dtype));
+        FB_VALIDATE("y", y, n * dtype_size(dtype));
+        FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, k));
+        FB_VALIDATE("borders", borders, static_cast<size_t>(nborders) * dtype_size(dtype));
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float a = static_cast<float>(p0), b = static_cast<float>(p1);
+#define FB_CASE(F) case F: return dispatch_forward_dtype<F>(plan, dry, dtype, x, y, state, n, borders, nborders, k, a, b, s);
+    switch (fn) {
+        FB_CONTINUOUS_CASES
+    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown continuous fn %d", fn);
+    }
+#undef FB_CASE
+}
+
+int do_quantize_backward(Plan *plan, bool dry, int dtype, const void *gy, const uint8_t *state, void *gx, size_t n,
+                         const void *levels, int nlevels, void *stream) {
+    if (nlevels < 2 || nlevels > 256) return fail(FEWBIT_ERR_UNSUPPORTED, "nlevels=%d outside [2,256]", nlevels);
+    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    const int k = fewbit_hip_bitwidth(nlevels);
+    if (!dry) {
+        if (n == 0) return FEWBIT_OK;
+        if (!gy || !gx || !state || !levels) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+        FB_VALIDATE("gy", gy, n * dtype_size(dtype));
+        FB_VALIDATE("gx", gx, n * dtype_size(dtype));
+        FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, k));
+        FB_VALIDATE("levels", levels, static_cast<size_t>(nlevels) * dtype_size(dtype));
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case FEWBIT_F32: return launch_backward<FEWBIT_F32>(plan, dry, gy, state, gx, n, levels, nlevels, k, s);
+    case FEWBIT_F16: return launch_backward<FEWBIT_F16>(plan, dry, gy, state, gx, n, levels, nlevels, k, s);
+    default: return launch_backward<FEWBIT_BF16>(plan, dry, gy, state, gx, n, levels, nlevels, k, s);
+    }
+}
+
+int do_stepwise1_forward(Plan *plan, bool dry, int fn, int dtype, const void *x, void *y, uint8_t *state, size_t n, double p0,
+                         double p1, void *stream) {
+    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    if (!dry) {
+        if (n == 0) return FEWBIT_OK;
+        if (!x || !y || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+        FB_VALIDATE("x", x, n * dtype_size(dtype));
+        FB_VALIDATE("y", y, n * dtype_size(dtype));
+        FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, 1));
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float a = static_cast<float>(p0), b = static_cast<float>(p1);
+#define FB_CASE(F) case F: return dispatch_step1_dtype<F>(plan, dry, dtype, x, y, state, n, a, b, s);
+    switch (fn) {
+        FB_STEPWISE_CASES
+    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown stepwise fn %d", fn);
+    }
+#undef FB_CASE
+}
+
+int do_stepwise1_backward(Plan *plan, bool dry, int fn, int dtype, const void *gy, const uint8_t *state, void *gx, size_t n,
+                          double p0, void *stream) {
+    if (fn < 0 || fn >= FEWBIT_STEPWISE_COUNT) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown stepwise fn %d", fn);
+    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    if (!dry) {
+        if (n == 0) return FEWBIT_OK;
+        if (!gy || !gx || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
+        FB_VALIDATE("gy", gy, n * dtype_size(dtype));
+        FB_VALIDATE("gx", gx, n * dtype_size(dtype));
+        FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, 1));
+    }
+    float m0 = 0.0f, m1 = 1.0f;
+    if (fn == FEWBIT_HARDSIGMOID) m1 = 1.0f / 6.0f;
+    if (fn == FEWBIT_LEAKY_RELU) { m0 = 1.0f; m1 = static_cast<float>(p0); }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+    case FEWBIT_F32: return launch_step1_backward<FEWBIT_F32>(plan, dry, gy, state, gx, n, m0, m1, s);
+    case FEWBIT_F16: return launch_step1_backward<FEWBIT_F16>(plan, dry, gy, state, gx, n, m0, m1, s);
+    default: return launch_step1_backward<FEWBIT_BF16>(plan, dry, gy, state, gx, n, m0, m1, s);
+    }
+}
+
+int write_plan(const Plan &p, char *buf, size_t len) {
+    if (!buf || len == 0) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "describe: no output buffer");
+    snprintf(buf, len, "{\"kernel\": \"%s\", \"blocks\": %u, \"threads\": %d, \"blocks_per_cu\": %d, \"chunk\": %d, \"u\": %d, \"bits\": %d}",
+             p.kernel, p.blocks, p.threads, p.blocks_per_cu, p.chunk, p.u, p.k);
+    return FEWBIT_OK;
 }
 
 }  // namespace
@@ -1186,93 +1423,58 @@ size_t fewbit_hip_state_nbytes(size_t n, int nbits) { return static_cast<size_t>
 
 int fewbit_hip_quantize_forward(int fn, int dtype, const void *x, void *y, uint8_t *state, size_t n,
                                 const void *borders, int nborders, double p0, double p1, void *stream) {
-    if (nborders < 1 || nborders > 255) return fail(FEWBIT_ERR_UNSUPPORTED, "nborders=%d outside [1,255]", nborders);
-    if (n == 0) return FEWBIT_OK;
-    if (!x || !y || !state || !borders) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
-    const int k = fewbit_hip_bitwidth(nborders + 1);
-    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
-    FB_VALIDATE("x", x, n * dtype_size(dtype));
-    FB_VALIDATE("y", y, n * dtype_size(dtype));
-    FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, k));
-    FB_VALIDATE("borders", borders, static_cast<size_t>(nborders) * dtype_size(dtype));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const float a = static_cast<float>(p0), b = static_cast<float>(p1);
-#define FB_CASE(F) case F: return dispatch_forward_dtype<F>(dtype, x, y, state, n, borders, nborders, k, a, b, s);
-    switch (fn) {
-        FB_CASE(FEWBIT_CELU) FB_CASE(FEWBIT_ELU) FB_CASE(FEWBIT_GELU) FB_CASE(FEWBIT_HARDSWISH)
-        FB_CASE(FEWBIT_LOGSIGMOID) FB_CASE(FEWBIT_MISH) FB_CASE(FEWBIT_SELU) FB_CASE(FEWBIT_SIGMOID)
-        FB_CASE(FEWBIT_SILU) FB_CASE(FEWBIT_SOFTPLUS) FB_CASE(FEWBIT_SOFTSIGN) FB_CASE(FEWBIT_TANH)
-        FB_CASE(FEWBIT_TANHSHRINK) FB_CASE(FEWBIT_IDENTITY) FB_CASE(FEWBIT_IDENTITY_FOLD)
-    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown continuous fn %d", fn);
-    }
-#undef FB_CASE
+    return do_quantize_forward(nullptr, false, fn, dtype, x, y, state, n, borders, nborders, p0, p1, stream);
 }
 
 int fewbit_hip_quantize_backward(int dtype, const void *gy, const uint8_t *state, void *gx, size_t n,
                                  const void *levels, int nlevels, void *stream) {
-    if (nlevels < 2 || nlevels > 256) return fail(FEWBIT_ERR_UNSUPPORTED, "nlevels=%d outside [2,256]", nlevels);
-    if (n == 0) return FEWBIT_OK;
-    if (!gy || !gx || !state || !levels) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
-    const int k = fewbit_hip_bitwidth(nlevels);
-    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
-    FB_VALIDATE("gy", gy, n * dtype_size(dtype));
-    FB_VALIDATE("gx", gx, n * dtype_size(dtype));
-    FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, k));
-    FB_VALIDATE("levels", levels, static_cast<size_t>(nlevels) * dtype_size(dtype));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (dtype) {
-    case FEWBIT_F32: return launch_backward<FEWBIT_F32>(gy, state, gx, n, levels, nlevels, k, s);
-    case FEWBIT_F16: return launch_backward<FEWBIT_F16>(gy, state, gx, n, levels, nlevels, k, s);
-    case FEWBIT_BF16: return launch_backward<FEWBIT_BF16>(gy, state, gx, n, levels, nlevels, k, s);
-    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
-    }
+    return do_quantize_backward(nullptr, false, dtype, gy, state, gx, n, levels, nlevels, stream);
 }
 
 int fewbit_hip_stepwise1_forward(int fn, int dtype, const void *x, void *y, uint8_t *state, size_t n, double p0,
                                  double p1, void *stream) {
-    if (n == 0) return FEWBIT_OK;
-    if (!x || !y || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
-    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
-    FB_VALIDATE("x", x, n * dtype_size(dtype));
-    FB_VALIDATE("y", y, n * dtype_size(dtype));
-    FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, 1));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const float a = static_cast<float>(p0), b = static_cast<float>(p1);
-#define FB_CASE(F) case F: return dispatch_step1_dtype<F>(dtype, x, y, state, n, a, b, s);
-    switch (fn) {
-        FB_CASE(FEWBIT_HARDSHRINK) FB_CASE(FEWBIT_HARDSIGMOID) FB_CASE(FEWBIT_HARDTANH) FB_CASE(FEWBIT_LEAKY_RELU)
-        FB_CASE(FEWBIT_RELU) FB_CASE(FEWBIT_RELU6) FB_CASE(FEWBIT_SOFTSHRINK) FB_CASE(FEWBIT_THRESHOLD)
-    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown stepwise fn %d", fn);
-    }
-#undef FB_CASE
+    return do_stepwise1_forward(nullptr, false, fn, dtype, x, y, state, n, p0, p1, stream);
 }
 
 int fewbit_hip_stepwise1_backward(int fn, int dtype, const void *gy, const uint8_t *state, void *gx, size_t n,
                                   double p0, void *stream) {
-    if (fn < 0 || fn >= FEWBIT_STEPWISE_COUNT) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown stepwise fn %d", fn);
-    if (n == 0) return FEWBIT_OK;
-    if (!gy || !gx || !state) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "null pointer argument");
-    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
-    FB_VALIDATE("gy", gy, n * dtype_size(dtype));
-    FB_VALIDATE("gx", gx, n * dtype_size(dtype));
-    FB_VALIDATE("state", state, fewbit_hip_state_nbytes(n, 1));
-    float m0 = 0.0f, m1 = 1.0f;
-    if (fn == FEWBIT_HARDSIGMOID) m1 = 1.0f / 6.0f;
-    if (fn == FEWBIT_LEAKY_RELU) { m0 = 1.0f; m1 = static_cast<float>(p0); }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (dtype) {
-    case FEWBIT_F32:
-        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_F32, Tile<FEWBIT_F32>::UB>), n, Tile<FEWBIT_F32>::UB, s, gy, state, gx, n, m0, m1);
-        break;
-    case FEWBIT_F16:
-        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_F16, Tile<FEWBIT_F16>::UB>), n, Tile<FEWBIT_F16>::UB, s, gy, state, gx, n, m0, m1);
-        break;
-    case FEWBIT_BF16:
-        FB_LAUNCH_TILED((stepwise1_backward_kernel<FEWBIT_BF16, Tile<FEWBIT_BF16>::UB>), n, Tile<FEWBIT_BF16>::UB, s, gy, state, gx, n, m0, m1);
-        break;
-    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    return do_stepwise1_backward(nullptr, false, fn, dtype, gy, state, gx, n, p0, stream);
+}
+
+int fewbit_hip_describe_quantize_forward(int fn, int dtype, size_t n, int nborders, char *buf, size_t len) {
+    Plan p{};
+    const int rc = do_quantize_forward(&p, true, fn, dtype, nullptr, nullptr, nullptr, n, nullptr, nborders, 0.0, 0.0, nullptr);
+    return rc ? rc : write_plan(p, buf, len);
+}
+
+int fewbit_hip_describe_quantize_backward(int dtype, size_t n, int nlevels, char *buf, size_t len) {
+    Plan p{};
+    const int rc = do_quantize_backward(&p, true, dtype, nullptr, nullptr, nullptr, n, nullptr, nlevels, nullptr);
+    return rc ? rc : write_plan(p, buf, len);
+}
+
+int fewbit_hip_describe_stepwise1_forward(int fn, int dtype, size_t n, char *buf, size_t len) {
+    Plan p{};
+    const int rc = do_stepwise1_forward(&p, true, fn, dtype, nullptr, nullptr, nullptr, n, 0.0, 0.0, nullptr);
+    return rc ? rc : write_plan(p, buf, len);
+}
+
+int fewbit_hip_describe_stepwise1_backward(int fn, int dtype, size_t n, char *buf, size_t len) {
+    Plan p{};
+    const int rc = do_stepwise1_backward(&p, true, fn, dtype, nullptr, nullptr, nullptr, n, 0.0, nullptr);
+    return rc ? rc : write_plan(p, buf, len);
+}
+
+int fewbit_hip_tune(const char *key, long long value) {
+    if (!key) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "tune: null key");
+    tune_init();
+    for (int i = 0; i < T_COUNT; ++i) {
+        if (strcmp(key, kTuneSpec[i].key) == 0) {
+            g_tune[i].store(value, std::memory_order_relaxed);
+            return FEWBIT_OK;
+        }
     }
-    return check_launch("stepwise1_backward");
+    return fail(FEWBIT_ERR_INVALID_ARGUMENT, "tune: unknown key '%s'", key);
 }
 
 int fewbit_hip_pack_codes(const int32_t *codes, uint8_t *state, size_t n, int nbits, void *stream) {

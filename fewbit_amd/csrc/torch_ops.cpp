@@ -17,7 +17,7 @@
 //   CUDA          the same launches without an autograd node (torch.inference_mode(), where the Autograd keys are
 //                 excluded); quantize / quantize_backward
 //   AutogradCPU   host tensors: this file's own ATen-level implementation with the same PACKED state (section "host
-//                 tensors" below).  The reference registers `gelu` only, as an autograd Function under the CPU key
+//                 tensors" below); OUT OF PLACE and layout-agnostic like the reference's host operator.  The reference registers `gelu` only, as an autograd Function under the CPU key
 //                 (fewbit/cpu/gelu.cc:47-76), plus quantize / quantize_backward (fewbit/fewbit.cc:6-7); here every
 //                 operator has one.  Product code; it never touches oracle/.
 //   CPU           the same without an autograd node (plain activation), quantize / quantize_backward
@@ -267,36 +267,35 @@ void check_host_table(const Tensor &self, const Tensor &table, const char *name)
                 ", input ", self.scalar_type());
 }
 
-// y = fn(self) into `out` (may be `self`); returns the packed state
+// y = fn(self) as a FRESH tensor (the reference's host operator leaves its input intact, fewbit/cpu/gelu.cc:7-31,
+// although the schema says Tensor(a!)); any layout is accepted: codes and state follow the logical row-major order
+// (hard part 7: what the reference's CPU path does for a strided input).  Returns the packed state.
 Tensor host_quantize(int fn, const Tensor &self, Tensor &out, const Tensor &bounds, double p0, double p1) {
-    TORCH_CHECK(self.is_contiguous(), "fewbit: `self` must be contiguous");
     TORCH_CHECK(self.is_floating_point(), "fewbit: unsupported dtype ", self.scalar_type());
     check_host_table(self, bounds, "bounds");
     const Tensor b = bounds.contiguous();
     TORCH_CHECK(b.numel() >= 1 && b.numel() <= 255, "fewbit: number of borders must be in [1, 255], got ", b.numel());
     const int nbits = bitwidth_of(b.numel() + 1);
-    const Tensor flat = self.reshape({-1});
+    const Tensor x = self.contiguous();
+    const Tensor flat = x.reshape({-1});
     // the even-parity fold of a custom table searches the fp32 distance |x - shift_x| (see stepwise_folded)
     const Tensor codes = fn == FEWBIT_IDENTITY_FOLD
                              ? torch::searchsorted(b.to(torch::kFloat), flat.to(torch::kFloat).sub(p0).abs(), /*out_int32=*/true)
                              : torch::searchsorted(b, flat, /*out_int32=*/true);
     Tensor state = host_pack(codes, nbits);
-    const Tensor y = host_activation(fn, self, p0, p1);      // before `self` may be overwritten below
-    if (out.is_same(self)) out.copy_(y);
-    else out = y;
+    out = host_activation(fn, x, p0, p1);
     return state;
 }
 
 struct HostContinuousFunction : public torch::autograd::Function<HostContinuousFunction> {
-    static Tensor forward(AutogradContext *ctx, Tensor self, const Tensor &bounds, const Tensor &levels, int64_t fn,
-                          double p0, double p1, bool inplace) {
+    static Tensor forward(AutogradContext *ctx, const Tensor &self, const Tensor &bounds, const Tensor &levels, int64_t fn,
+                          double p0, double p1) {
         TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
                     "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(),
                     " and ", levels.numel());
         check_host_table(self, levels, "levels");
-        Tensor out = inplace ? self : Tensor();
+        Tensor out;
         Tensor state = host_quantize(static_cast<int>(fn), self, out, bounds, p0, p1);
-        if (inplace) ctx->mark_dirty({self});
         ctx->save_for_backward({state, levels});
         return out;
     }
@@ -305,7 +304,7 @@ struct HostContinuousFunction : public torch::autograd::Function<HostContinuousF
         const auto saved = ctx->get_saved_variables();
         const Tensor lv = saved[1].contiguous();
         return {host_unpack_mul(grad_output[0], saved[0], lv, bitwidth_of(lv.numel())), Tensor(), Tensor(), Tensor(),
-                Tensor(), Tensor(), Tensor()};
+                Tensor(), Tensor()};
     }
 };
 
@@ -342,16 +341,11 @@ Tensor host_step1_bits(int fn, const Tensor &x, double p0, double p1) {
 }
 
 struct HostStepwise1Function : public torch::autograd::Function<HostStepwise1Function> {
-    static Tensor forward(AutogradContext *ctx, Tensor self, int64_t fn, double p0, double p1, bool inplace) {
-        TORCH_CHECK(self.is_contiguous(), "fewbit: `self` must be contiguous");
+    static Tensor forward(AutogradContext *ctx, const Tensor &self, int64_t fn, double p0, double p1) {
         TORCH_CHECK(self.is_floating_point(), "fewbit: unsupported dtype ", self.scalar_type());
-        Tensor state = host_pack(host_step1_bits(static_cast<int>(fn), self, p0, p1), 1);
-        Tensor y = host_step1_activation(static_cast<int>(fn), self, p0, p1);
-        if (inplace) {
-            self.copy_(y);
-            ctx->mark_dirty({self});
-            y = self;
-        }
+        const Tensor x = self.contiguous();
+        Tensor state = host_pack(host_step1_bits(static_cast<int>(fn), x, p0, p1), 1);
+        Tensor y = host_step1_activation(static_cast<int>(fn), x, p0, p1);
         ctx->save_for_backward({state});
         ctx->saved_data["fn"] = fn;
         ctx->saved_data["p0"] = p0;
@@ -365,7 +359,7 @@ struct HostStepwise1Function : public torch::autograd::Function<HostStepwise1Fun
         float pair[2] = {0.0f, 1.0f};       // as fewbit_hip_stepwise1_backward: (m0, m1) in fp32
         if (fn == FEWBIT_HARDSIGMOID) pair[1] = 1.0f / 6.0f;
         if (fn == FEWBIT_LEAKY_RELU) { pair[0] = 1.0f; pair[1] = static_cast<float>(p0); }
-        return {host_unpack_mul(grad_output[0], saved[0], Tensor(), 1, pair), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {host_unpack_mul(grad_output[0], saved[0], Tensor(), 1, pair), Tensor(), Tensor(), Tensor()};
     }
 };
 
@@ -378,6 +372,22 @@ void note_inplace_write(const Tensor &self) {
     if (!self.is_inference()) self.unsafeGetTensorImpl()->bump_version();
 }
 
+// In place on a VIEW that covers its whole base -- what the reference's callers do: the 3-D output of nn.Linear is a view
+// of its 2-D addmm result, and benchmark/bench-roberta.py:138-147 hands it straight to torch.ops.fewbit.gelu.  Marking
+// the view itself dirty makes autograd rebase it (CopySlices: a zero-fill plus three full-size copies around our
+// backward).  Marking the BASE dirty instead is the same write to the same memory, and autograd re-derives the view's
+// grad_fn from the base's new one by itself (the standard "base modified after the view was taken" path) -- same graph
+// semantics, nothing saved but {state, levels}, no copies.  Returns the undefined tensor when `self` is not such a view.
+Tensor whole_view_base(const Tensor &self) {
+    if (!self.is_view()) return Tensor();
+    const Tensor base(self._base());      // (TensorBase::_base returns a const TensorBase &)
+    if (!base.defined() || !base.requires_grad() || base.is_leaf() || !base.is_contiguous() || !self.is_contiguous() ||
+        base.numel() != self.numel() || base.storage_offset() != self.storage_offset() || base.scalar_type() != self.scalar_type() ||
+        base.device() != self.device())
+        return Tensor();
+    return base;
+}
+
 // ---- the three flavours every operator is registered in --------------------------------------------
 enum class Where { AutogradGpu, RawGpu, AutogradHost, RawHost };
 
@@ -387,15 +397,23 @@ Tensor continuous(int fn, const Tensor &self, const Tensor &bounds, const Tensor
     if constexpr (W == Where::AutogradGpu) {
         // nothing will ever ask for this call's gradient: skip the autograd node (and its ~4 us of host time)
         if (!needs_node(self)) return continuous<Where::RawGpu>(fn, self, bounds, levels, p0, p1, inplace);
+        if (inplace) {
+            if (const Tensor base = whole_view_base(self); base.defined()) {
+                ContinuousFunction::apply(base, bounds, levels, static_cast<int64_t>(fn), p0, p1, true);
+                return self;
+            }
+        }
         return ContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, inplace);
     } else if constexpr (W == Where::AutogradHost) {
-        return HostContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, inplace);
+        // host tensors: always a fresh result, like the reference's host operator (see host_quantize)
+        return HostContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1);
     } else if constexpr (W == Where::RawHost) {     // no autograd node: nothing to save, plain activation
         TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
                     "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(), " and ",
                     levels.numel());
-        const Tensor y = host_activation(fn, self, p0, p1);
-        return inplace ? self.copy_(y) : y;
+        check_host_table(self, bounds, "bounds");      // the same argument errors with and without autograd
+        check_host_table(self, levels, "levels");
+        return host_activation(fn, self, p0, p1);
     } else {
         // no autograd node (inference_mode): same kernel, the packed state goes to a scratch buffer and is dropped
         TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
@@ -411,12 +429,17 @@ Tensor continuous(int fn, const Tensor &self, const Tensor &bounds, const Tensor
 template <Where W> Tensor stepwise1(int fn, const Tensor &self, double p0 = 0.0, double p1 = 0.0, bool inplace = true) {
     if constexpr (W == Where::AutogradGpu) {
         if (!needs_node(self)) return stepwise1<Where::RawGpu>(fn, self, p0, p1, inplace);
+        if (inplace) {
+            if (const Tensor base = whole_view_base(self); base.defined()) {       // see whole_view_base
+                Stepwise1Function::apply(base, static_cast<int64_t>(fn), p0, p1, true);
+                return self;
+            }
+        }
         return Stepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, inplace);
     } else if constexpr (W == Where::AutogradHost) {
-        return HostStepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, inplace);
+        return HostStepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1);
     } else if constexpr (W == Where::RawHost) {
-        const Tensor y = host_step1_activation(fn, self, p0, p1);
-        return inplace ? self.copy_(y) : y;
+        return host_step1_activation(fn, self, p0, p1);
     } else {
         check_input(self, "self");
         Tensor out = inplace ? self : torch::empty_like(self);
@@ -536,9 +559,8 @@ Tensor quantize_backward(const Tensor &grads, const Tensor &buffer, const Tensor
 
 // ... and for host tensors (the reference's own home for these two, fewbit/fewbit.cc:6-7)
 std::tuple<Tensor, Tensor> quantize_host(const Tensor &inputs, const Tensor &bounds) {
-    const Tensor x = inputs.contiguous();
     Tensor outputs;
-    Tensor state = host_quantize(FEWBIT_GELU, x, outputs, bounds, 0.0, 0.0);
+    Tensor state = host_quantize(FEWBIT_GELU, inputs, outputs, bounds, 0.0, 0.0);
     return std::make_tuple(outputs, state);
 }
 

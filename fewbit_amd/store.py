@@ -61,7 +61,11 @@ class StepwiseStore:
         leaf = self._store.get((name, bits))
         if leaf is None:
             raise KeyError(f'There is not {bits}-bit quantized gradients for activation function {name}.')
-        cast = tuple(el.to(device, dtype) for el in leaf)
+        # The cast outlives this call, so it must be an ordinary tensor even when the first call for this key happens under
+        # torch.inference_mode(): a cached *inference* tensor could never be saved for backward by a later training call
+        # ("Inference tensors cannot be saved for backward").
+        with torch.inference_mode(False):
+            cast = tuple(el.to(device, dtype, copy=True) if el.is_inference() else el.to(device, dtype) for el in leaf)
         self._cache[key] = cast
         return cast
 
@@ -72,7 +76,8 @@ class StepwiseStore:
         hit = self._inner.get(key)
         if hit is None:
             borders, levels = self.get(name, bits, device, dtype)
-            hit = self._inner[key] = (borders[1:-1].contiguous(), levels)
+            with torch.inference_mode(False):        # see get(): cached tensors must not be inference tensors
+                hit = self._inner[key] = (borders[1:-1].contiguous(), levels)
         return hit
 
     def items(self, cached: bool = False) -> Iterator:

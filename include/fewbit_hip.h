@@ -133,6 +133,26 @@ int fewbit_hip_stepwise1_forward(int fn, int dtype, const void *x, void *y, uint
 int fewbit_hip_stepwise1_backward(int fn, int dtype, const void *gy, const uint8_t *state, void *gx, size_t n,
                                   double p0, void *stream);
 
+/*
+ * What a call WOULD launch, without launching it: the same dispatch as the entry point of the same name, for `n`
+ * elements on the calling thread's current device, written to `buf` as one JSON object
+ *   {"kernel": "...", "blocks": B, "threads": T, "blocks_per_cu": C, "chunk": X, "u": U, "bits": k}
+ * (bench.py takes the name of the dominant kernel from here; the reference has no counterpart -- its launch
+ * topology is one macro, fewbit/cuda/codec.cu:229-239).
+ */
+int fewbit_hip_describe_quantize_forward(int fn, int dtype, size_t n, int nborders, char *buf, size_t len);
+int fewbit_hip_describe_quantize_backward(int dtype, size_t n, int nlevels, char *buf, size_t len);
+int fewbit_hip_describe_stepwise1_forward(int fn, int dtype, size_t n, char *buf, size_t len);
+int fewbit_hip_describe_stepwise1_backward(int fn, int dtype, size_t n, char *buf, size_t len);
+
+/*
+ * Launch-shape tuning at run time (measurement scripts; not needed for correctness -- every setting computes the same
+ * bytes).  Keys: "waves_per_cu", "chunk", "lut_chunk", "lut_blocks_per_cu", "lut_min", "lut_block", "u_fwd", "u_bwd",
+ * "u_lut", "u_step1"; value -1 restores the built-in policy.  The same keys are read once from the environment
+ * (FEWBIT_HIP_<KEY in upper case>) at the first launch.
+ */
+int fewbit_hip_tune(const char *key, long long value);
+
 /* stand-alone codec (test seam): int32 codes <-> packed state, 1 <= nbits <= 8 */
 int fewbit_hip_pack_codes(const int32_t *codes, uint8_t *state, size_t n, int nbits, void *stream);
 int fewbit_hip_unpack_codes(const uint8_t *state, int32_t *codes, size_t n, int nbits, void *stream);

@@ -106,6 +106,11 @@ int main(int argc, char **argv) {
         {"persistent U1 8blk/CU read-only nt", run_persistent<1, true, false, 1>, 8, one},
         {"persistent U1 8blk/CU write-only", run_persistent<1, false, false, 2>, 8, one},
         {"persistent U1 8blk/CU write-only nt", run_persistent<1, false, true, 2>, 8, one},
+        {"persistent U2 8blk/CU write-only nt", run_persistent<2, false, true, 2>, 8, one},
+        {"persistent U4 4blk/CU write-only nt", run_persistent<4, false, true, 2>, 4, one},
+        {"persistent U4 2blk/CU write-only nt", run_persistent<4, false, true, 2>, 2, one},
+        {"persistent U4 4blk/CU write-only", run_persistent<4, false, false, 2>, 4, one},
+        {"persistent U4 4blk/CU read-only", run_persistent<4, false, false, 1>, 4, one},
     };
     printf("%zu MiB per buffer, %d rotating sets; us per launch (GB/s, %% of 8 TB/s)\n", mib, nsets);
     for (auto &r : rows) {

@@ -300,3 +300,31 @@ def test_reference_submodule_paths_resolve():
     from fewbit.modules.variance import VarianceEstimator  # noqa: F401
     assert removeprefix('module.weight', 'module.') == 'weight' and removeprefix('abc', 'x') == 'abc'
     assert ('gelu', 3) in store
+
+
+def test_inference_mode_first_then_training():
+    """A table cast that is first made under torch.inference_mode() must still be an ordinary tensor: it is cached and a
+    later training call saves it for backward (advisor finding, round 2)."""
+    from fewbit_amd.store import StepwiseStore, BUILTIN_TABLES
+    fresh = StepwiseStore().load(BUILTIN_TABLES)
+    with torch.inference_mode():
+        b, l = fresh.get('gelu', 3, 'cpu', torch.bfloat16)
+        bi, li = fresh.get_inner('gelu', 3, torch.device('cpu'), torch.bfloat16)
+    assert not any(t.is_inference() for t in (b, l, bi, li))
+    # end to end on the shared store: module, functional and raw operator, each first under inference_mode
+    x = torch.randn(257)
+    module = fewbit.Mish(bits=2)
+    with torch.inference_mode():
+        module(x.clone())
+        fewbit.functional.softsign(x.clone(), bits=4)
+        inner, levels = fewbit.functional.store.get_inner('selu', 3, torch.device('cpu'), torch.float32)
+        if fewbit_amd.native_loaded():
+            torch.ops.fewbit.selu(x.clone(), inner, levels)
+    for call in (module, lambda t: fewbit.functional.softsign(t, bits=4)):
+        xg = x.clone().requires_grad_()
+        call(xg).sum().backward()
+        assert xg.grad is not None and torch.isfinite(xg.grad).all()
+    if fewbit_amd.native_loaded():
+        xg = x.clone().requires_grad_()
+        torch.ops.fewbit.selu(xg.clone(), inner, levels).sum().backward()
+        assert torch.equal(xg.grad, levels[torch.searchsorted(inner, x)])

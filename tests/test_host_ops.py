@@ -50,8 +50,11 @@ def test_quantize_ops_match_reference_run_bitwise(qref):
                 assert_bit_equal(y, from_raw(qref[key + '_y'], dtype), key + ' y')
                 xx = x.clone().requires_grad_()
                 inp = xx.clone()
-                out = torch.ops.fewbit.gelu(inp, b, l)                     # in place on its input, like the reference op
-                assert out.data_ptr() == inp.data_ptr()
+                out = torch.ops.fewbit.gelu(inp, b, l)
+                # host tensors: a fresh result, the input stays intact -- what the reference's CPU operator does
+                # (fewbit/cpu/gelu.cc:7-31,47-56) whatever the schema's Tensor(a!) says
+                assert out.data_ptr() != inp.data_ptr()
+                assert_bit_equal(inp.detach(), x, key + ' input left intact')
                 out.backward(gy)
                 assert_bit_equal(xx.grad, want_gx, key + ' autograd')
             seen += 1
@@ -151,8 +154,19 @@ def test_host_ops_without_autograd_and_errors():
         torch.ops.fewbit.gelu(x.clone(), inner.double(), levels.double())  # dtype mismatch
     with pytest.raises(RuntimeError):
         torch.ops.fewbit.quantize_backward(x, torch.zeros(3, dtype=torch.uint8), levels)   # state too small
-    with pytest.raises(RuntimeError):
-        torch.ops.fewbit.gelu(torch.randn(4, 4).t(), inner, levels)       # not contiguous
+    with torch.inference_mode(), pytest.raises(RuntimeError):
+        torch.ops.fewbit.gelu(x.clone(), inner.double(), levels.double())  # the same check without an autograd node
+    # host tensors of any layout are accepted, like the reference's CPU operator: logical (row-major) element order
+    xt = torch.randn(6, 10).t()
+    xg = xt.clone().requires_grad_()                                      # (clone keeps the transposed strides)
+    assert not xg.is_contiguous()
+    y = torch.ops.fewbit.silu(xg, inner, levels)
+    assert torch.equal(y, F.silu(xt.contiguous()))          # (ATen's strided and contiguous silu differ by an ulp)
+    y.sum().backward()
+    assert torch.equal(xg.grad, levels[torch.searchsorted(inner, xt.contiguous())])
+    _, state_t = torch.ops.fewbit.quantize(xt, inner)
+    _, state_c = torch.ops.fewbit.quantize(xt.contiguous(), inner)
+    assert torch.equal(state_t, state_c)
 
 
 def test_full_size_c2_digest_of_the_reference_run_on_the_host():
