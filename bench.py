@@ -10,27 +10,42 @@ backward of fewbit.gelu(bits=3), both through the C-ABI (include/fewbit_hip.h) o
   --config c2 (default)  4096x4096 bf16 per GPU              (BASELINE.json configs[1], the headline metric)
   --config c4            8192x4096 bf16 per GPU = the shard one GPU owns of BASELINE.json configs[3]
                          (4 x (16384x4096) bf16 over 8 GPUs, cut by fewbit_amd.sharding.shard_range)
-With N > 1 every rank runs the same per-GPU workload on its own shard (weak scaling, no collective on the data
-path; torch.distributed carries only the barrier before and the max-over-ranks after the timed region).
 
-Timed region: W warm-up steps, barrier + synchronize, a short untimed pre-roll that fills the launch queue,
-then EXACTLY K steps between two HIP events recorded on the launch stream, synchronize (+ barrier).  ms_per_step is
-the event time / K (max over ranks); the host wall clock around the same region is reported beside it.
+N > 1: every rank runs the same per-GPU workload on its own shard (weak scaling); the path has NO exchange step, so no
+collective is involved anywhere.  Two ways to start it, same worker code:
+  * `python bench.py --gpus N` by itself: this process starts N fresh children (one per device, the reference's own
+    model: benchmark/README.md:18, benchmark/benchmark.py:149-162), BEFORE it touches the GPU; the barriers around the
+    timed region are files in a private temporary directory; the parent prints the one JSON line.  A failed rank makes
+    the parent exit non-zero.  Children are never exec'ed over a process that initialised the GPU.
+  * under torch.distributed.run: torch.distributed carries the barrier and the max over ranks only -- over gloo (CPU)
+    by default, because there is nothing for RCCL to move (FEWBIT_BENCH_BACKEND=nccl uses RCCL for the same two calls).
+Ranks take device `local_rank % device_count`, so more ranks than GPUs share devices (a validation hook for 1-GPU
+boxes; the line then says "shared_gpu": true).
+
+Timed region (the driver's contract): exactly W warm-up steps, barrier + synchronize, host clock, EXACTLY K steps,
+synchronize, host clock, barrier.  `value` / `ms_per_step` = wall time of those K steps, max over ranks.  A second,
+identical K-step region between two HIP events gives the GPU-side time of such a region (`timing.event_ms_per_step`; it
+excludes the first launch's latency from an idle queue and the wake-up after the final synchronize, ~18 us = 4 % of a
+20-step region).
+`--settle-ms T` (default 0 = off) extends the warm-up until the GPU has been busy T ms (clock transient after idle).
 
 metric = algorithmic bytes / time; algorithmic bytes per element = 4*s + k/4 (fwd: read x, write y, write state;
 bwd: read gy, read state, write gx; s = element size, k = bits) -- SURVEY.md 8(d).
 
-Rank 0 prints ONE JSON line.  Besides the contract fields it carries (N = 1, unless --no-extras):
+Besides the contract fields the line carries (N = 1, unless --no-extras):
+  roofline   dominant kernel (name from fewbit_hip_describe_*), its algorithmic GB/s against the 8 TB/s HBM peak
   cold       the same workload rotating through > 1 GiB of independent buffer sets (Infinity Cache out of the picture)
-  configs    every other BASELINE config on one GPU (c1 relu fp32 1024^2, c3 silu k=2/k=4 fp16 8192^2, c4 shard,
-             c2 in fp32), each cache-warm and cache-cold: us_fwd / us_bwd / us_step / GiB_s / frac of 8 TB/s
-  cpu_baseline, cpu_baseline_1thread   the reference's own CPU path (oracle/_ref) on the host cores
+  configs    every other BASELINE config on one GPU, warm and cold, with kernel names and its own cpu_baseline
+  op_level   clone + torch.ops.fewbit.gelu + autograd.grad at this size beside torch.nn.functional.gelu
+  cpu_baseline, cpu_baseline_1thread   the reference's own CPU path (oracle/_ref) on the host cores, bounded samples
 """
 import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -67,6 +82,8 @@ CONFIGS = {
                                               'hardware': 'not stated (an NVIDIA GPU)',
                                               'source': 'notebooks/few-bit-backward/memory-usage-operation-only.py:41,70,80-85'}),
 }
+# bounded CPU-baseline samples per config: (repetitions at all threads, repetitions at one thread); ~25 s of CPU in all
+CPU_SAMPLES = {'c2': (12, 6), 'c4': (5, 0), 'c1': (40, 0), 'c3_k2': (3, 0), 'c3_k4': (3, 0), 'c2_fp32': (6, 0)}
 
 
 def load_tables(cfg, device):
@@ -82,6 +99,15 @@ def step_bytes(cfg):
     es = torch.empty(0, dtype=DTYPES[cfg['dtype']]).element_size()
     n = cfg['rows'] * cfg['cols']
     return n * (4 * es + cfg['bits'] / 4), n * (2 * es + cfg['bits'] / 8)
+
+
+def describe(cfg):
+    """kernel instantiation + launch shape the library uses for this config on the current device (nothing is launched)"""
+    from fewbit_amd import cabi
+    dt, n = DTYPES[cfg['dtype']], cfg['rows'] * cfg['cols']
+    if cfg['kind'] == 'continuous':
+        return (cabi.describe_forward(cfg['fn'], dt, n, 2 ** cfg['bits'] - 1), cabi.describe_backward(dt, n, 2 ** cfg['bits']))
+    return cabi.describe_stepwise1_forward(cfg['fn'], dt, n), cabi.describe_stepwise1_backward(cfg['fn'], dt, n)
 
 
 class Workload:
@@ -170,85 +196,221 @@ def measure_config(cfg, device, cold):
     return out
 
 
-def cpu_baseline(cfg, threads=None):
-    """Reference CPU path (oracle/_ref, kind 'reference') or, without it, the C restatement (kind 'port')."""
+def graph_step_us(cfg, device, steps=50, replays=20):
+    """GPU-side time of one fwd+bwd step with the host out of the picture: `steps` steps captured into ONE hipGraph on a side
+    stream and replayed.  For tensors this small the eager loop measures the host's launch rate (~2.7 us per launch even
+    from C++, profiles/r03_stream_bench_4MiB.txt), not the kernels."""
+    side = torch.cuda.Stream(device)
+    with torch.cuda.stream(side):
+        w = Workload(cfg, device, nsets=1, seed=7, host_seeded=False)       # launches bound to the side stream
+        for f in w.steps():
+            f()
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(steps):
+            for f in w.steps():
+                f()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(replays):
+        g.replay()
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / replays / steps * 1e6
+    del g, w
+    return us
+
+
+def measure_op_level(cfg, device, reps=200):
+    """The operator path a model sees: `clone` (the op works in place) + torch.ops.fewbit.<fn> + autograd.grad, beside the same
+    three calls with torch.nn.functional.<fn> (kernel-only AND op-level numbers).  Eager (GPU time between two
+    events, and host wall time per iteration: when the two agree the loop is HOST-bound -- dispatcher + autograd engine, not
+    kernels) and as a hipGraph replay (the GPU-side time of the same launches with the host out of the picture)."""
+    import torch.nn.functional as F
+    import fewbit_amd
+    if not fewbit_amd.native_loaded():
+        return {'error': fewbit_amd.native_error()}
+    dt = DTYPES[cfg['dtype']]
+    borders, levels = load_tables(cfg, device)
+    x = torch.randn(cfg['rows'], cfg['cols'], device=device).to(dt).requires_grad_()
+    gy = torch.randn(cfg['rows'], cfg['cols'], device=device).to(dt)
+    op = getattr(torch.ops.fewbit, cfg['fn']).default
+    ref = getattr(F, cfg['fn'])
+
+    def fewbit_step():
+        return torch.autograd.grad(op(x.clone(), borders, levels), x, gy)
+
+    def vanilla_step():
+        return torch.autograd.grad(ref(x.clone()), x, gy)
+
+    def clone_only():
+        return x.detach().clone()
+
+    out = {}
+    for name, f in (('fewbit', fewbit_step), ('vanilla', vanilla_step), ('clone_alone', clone_only)):
+        for _ in range(10):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(reps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps * 1e6
+        out[name] = {'us_gpu': round(e0.elapsed_time(e1) * 1e3 / reps, 2), 'us_wall': round(wall, 2)}
+        try:                                            # the same launches captured once and replayed
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    f()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                keep = f()                              # noqa: F841  (outputs live in the graph's pool)
+            for _ in range(10):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                g.replay()
+            torch.cuda.synchronize()
+            out[name]['us_graph_replay'] = round((time.perf_counter() - t0) / reps * 1e6, 2)
+            del g, keep
+        except Exception as e:  # noqa: BLE001
+            out[name]['us_graph_replay'] = None
+            out[name]['graph_error'] = f'{type(e).__name__}: {e}'[:200]
+    sb, _ = step_bytes(cfg)
+    key = 'us_graph_replay' if out['fewbit'].get('us_graph_replay') and out['clone_alone'].get('us_graph_replay') else 'us_gpu'
+    net = out['fewbit'][key] - out['clone_alone'][key]
+    out['fewbit_minus_clone'] = {'from': key, 'us': round(net, 2), 'GiB_s': round(sb / (net * 1e-6) / 2**30, 1),
+                                 'frac': round(sb / (net * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    out['speedup_vs_vanilla'] = {k: round(out['vanilla'][k] / out['fewbit'][k], 3) for k in ('us_gpu', 'us_graph_replay')
+                                 if out['vanilla'].get(k) and out['fewbit'].get(k)}
+    out['note'] = (f"{reps} iterations of x.clone() + torch.ops.fewbit.{cfg['fn']}(clone, borders, levels) + torch.autograd.grad on "
+                   f"{cfg['rows']}x{cfg['cols']} {cfg['dtype']}; `vanilla` = the same with torch.nn.functional.{cfg['fn']}; us_gpu: between two "
+                   "events on the stream, eager; us_wall: host time per eager iteration (us_wall ~ us_gpu => host-bound); us_graph_replay: "
+                   "one hipGraph replay of the same launches (three kernels + their boundaries, ~1.8 us each, which a graph does not remove)")
+    return out
+
+
+def cpu_baseline(name, cfg, reps, threads=None):
+    """Reference CPU path on this host (oracle/_ref, kind 'reference': the reference's quantize/quantize_backward for the
+    table configs, its bit codec Deflate/Inflate(..., 1) for the 1-bit config, exactly what BASELINE.md section 2 timed) or,
+    without the prebuilt reference, the C restatement (kind 'port').  Bounded: `reps` repetitions of the full tensor."""
     tables = str(ROOT / 'fewbit_amd' / 'data' / 'builtin.npz')
-    ref = ROOT / 'oracle' / '_ref' / 'libfewbit_ref.so'
+    ref_dir = ROOT / 'oracle' / '_ref'
     rows, cols, bits, dname = cfg['rows'], cfg['cols'], cfg['bits'], cfg['dtype']
     nbytes, _ = step_bytes(cfg)
-    if ref.exists():
-        reps = 8 if threads == 1 else 20
+    have_ref = (ref_dir / ('libcodec_ref.so' if cfg['kind'] == 'stepwise1' else 'libfewbit_ref.so')).exists()
+    if have_ref:
         try:
-            cmd = [sys.executable, str(ROOT / 'oracle' / 'ref_bench.py'), str(rows), str(cols), dname, str(bits), str(reps), tables]
-            if threads:
-                cmd.append(str(threads))
+            cmd = [sys.executable, str(ROOT / 'oracle' / 'ref_bench.py'), str(rows), str(cols), dname, str(bits), str(reps), tables,
+                   str(threads or 0), cfg['fn']]
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True)
             r = json.loads(out.stdout.strip().splitlines()[-1])
             return {'value': round(r['gib_per_s'], 4), 'unit': 'GiB/s', 'cores': r['threads'], 'kind': 'reference',
-                    'host_cpus': r['cores'],
-                    'sample': f'{reps} x (quantize + quantize_backward) of the full {rows}x{cols} {dname} tensor, median; '
-                              f'reference fewbit/cpu path built with g++ against libtorch, {r["threads"]} intra-op thread(s) '
-                              f'(the pack/unpack loops are single-threaded in the reference)',
-                    'ms_per_step': round(r['seconds_per_step'] * 1e3, 2)}
+                    'host_cpus': r['cores'], 'ms_per_step': round(r['seconds_per_step'] * 1e3, 2),
+                    'sample': f'{reps} x ({r["what"]}) of the full {rows}x{cols} {dname} tensor, median; {r["threads"]} thread(s)'}
         except Exception as e:  # noqa: BLE001
-            sys.stderr.write(f'[bench] reference CPU baseline failed ({e}); falling back to the C port\n')
+            sys.stderr.write(f'[bench] reference CPU baseline for {name} failed ({e}); falling back to the C port\n')
     import oracle  # the checker, timed as the CPU baseline only
     dt = DTYPES[dname]
-    with np.load(tables) as z:
-        borders = torch.tensor(z[f"{cfg['fn']}{bits:02d}-borders"]).to(dt)[1:-1].contiguous()
-        levels = torch.tensor(z[f"{cfg['fn']}{bits:02d}-levels"]).to(dt)
     torch.manual_seed(0)
     x = torch.randn(rows, cols).to(dt)
     torch.manual_seed(1)
     gy = torch.randn(rows, cols).to(dt)
+    if cfg['kind'] == 'continuous':
+        with np.load(tables) as z:
+            borders = torch.tensor(z[f"{cfg['fn']}{bits:02d}-borders"]).to(dt)[1:-1].contiguous()
+            levels = torch.tensor(z[f"{cfg['fn']}{bits:02d}-levels"]).to(dt)
     times = []
-    for i in range(4):
+    for i in range(min(reps, 3) + 1):
         t0 = time.perf_counter()
-        _, state, _ = oracle.quantize(cfg['fn'], x, borders)
-        oracle.quantize_backward(gy, state, levels)
+        if cfg['kind'] == 'continuous':
+            _, state, _ = oracle.quantize(cfg['fn'], x, borders)
+            oracle.quantize_backward(gy, state, levels)
+        else:
+            _, state = oracle.stepwise1_forward(cfg['fn'], x)
+            oracle.stepwise1_backward(cfg['fn'], gy, state)
         t1 = time.perf_counter()
         if i:
             times.append(t1 - t0)
     best = float(np.median(times))
     return {'value': round(nbytes / best / 2**30, 4), 'unit': 'GiB/s', 'cores': 1, 'kind': 'port',
-            'sample': f'3 x (quantize + quantize_backward) of the full {rows}x{cols} {dname} tensor, median; '
+            'sample': f'{len(times)} x (forward + backward) of the full {rows}x{cols} {dname} tensor, median; '
                       'oracle/fewbit_oracle.c, scalar, 1 thread', 'ms_per_step': round(best * 1e3, 2)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--config', choices=('c2', 'c4'), default='c2', help='headline workload per GPU (see module docstring)')
-    ap.add_argument('--settle-ms', type=float, default=40.0,
-                    help='keep issuing untimed warm-up steps until the GPU has been busy this long (0 = exactly W steps): '
-                         'MI355X drops its clocks 1.5-10 ms after load begins and recovers by ~15 ms (scratch/timeline.py)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extras', action='store_true', help='timed region only (what the rocprofv3 passes run)')
-    args = ap.parse_args()
+# ---- synchronisation of the ranks around the timed region (control plane only; the data path has no exchange) ----
+class NoSync:
+    def barrier(self, tag):
+        pass
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
-        args.gpus = world
+    def max(self, values):
+        return values
+
+    def close(self):
+        pass
+
+
+class FileSync:
+    """Barrier through files in a directory the parent created (self-launched N > 1): rank r creates `<tag>.<r>` and spins
+    until all `world` files exist.  No sockets, no RCCL."""
+
+    def __init__(self, directory, rank, world, timeout=300.0):
+        self.dir, self.rank, self.world, self.timeout = Path(directory), rank, world, timeout
+
+    def barrier(self, tag):
+        (self.dir / f'{tag}.{self.rank}').touch()
+        names = [self.dir / f'{tag}.{r}' for r in range(self.world)]
+        t0 = time.perf_counter()
+        while not all(p.exists() for p in names):
+            if (self.dir / 'abort').exists() or time.perf_counter() - t0 > self.timeout:
+                raise RuntimeError(f'rank {self.rank}: barrier `{tag}` failed (abort flag or timeout)')
+
+    def max(self, values):          # the parent takes the max over the ranks' result files
+        return values
+
+    def close(self):
+        pass
+
+
+class TorchSync:
+    """Under torch.distributed.run: barrier + max over ranks through a process group -- gloo on the CPU by default
+    (FEWBIT_BENCH_BACKEND=nccl: RCCL, for the same two calls)."""
+
+    def __init__(self, rank, world, device):
+        import torch.distributed as dist
+        self.dist, self.device = dist, device
+        self.backend = os.environ.get('FEWBIT_BENCH_BACKEND', 'gloo')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if self.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(self.backend, rank=rank, world_size=world)
+
+    def barrier(self, tag):
+        self.dist.barrier()
+
+    def max(self, values):
+        t = torch.tensor(values, dtype=torch.float64, device=self.device if self.backend == 'nccl' else 'cpu')
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def run_rank(args, rank, local_rank, world, make_sync):
+    """The timed region on one rank.  Returns this rank's measurements (after sync.max: the maxima over ranks)."""
     ndev = max(torch.cuda.device_count(), 1)
     device = torch.device('cuda', local_rank % ndev)
     torch.cuda.set_device(device)
-    # control plane only (barrier + max of the elapsed time): RCCL ('nccl' on ROCm).  FEWBIT_BENCH_BACKEND=gloo is a
-    # validation hook that lets several ranks share one GPU, where RCCL refuses duplicate devices.
-    backend = os.environ.get('FEWBIT_BENCH_BACKEND', 'nccl')
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
+    sync = make_sync(device)
     from fewbit_amd import cabi   # raises if libfewbit_hip.so is missing: there is no fallback
     from fewbit_amd.sharding import shard_range
     cabi.lib()
@@ -261,131 +423,298 @@ def main():
     w = Workload(cfg, device, nsets=1, seed=rank)
     fwd, bwd = w.fwd[0], w.bwd[0]
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     t_warm = time.perf_counter()
     for _ in range(args.warmup):
         fwd()
         bwd()
-    # Untimed settle: a GPU that was idle boosts for ~1.5 ms, then runs 8-12 % slower for ~10 ms, then settles (measured
-    # step by step with scratch/timeline.py); a 20-step region would sit in the boost phase, a 200-step region in the
-    # dip.  Warm-up therefore continues (same steps, untimed) until the device has been busy for --settle-ms.
-    torch.cuda.synchronize()
     settle_steps = 0
-    while (time.perf_counter() - t_warm) * 1e3 < args.settle_ms:
-        for _ in range(50):
-            fwd()
-            bwd()
-        settle_steps += 50
+    if args.settle_ms > 0:      # optional: a GPU that was idle boosts ~1.5 ms, dips ~10 ms, then settles (scratch/timeline.py)
         torch.cuda.synchronize()
-    # ---- the timed region.  barrier + synchronize; an untimed pre-roll keeps the GPU busy while the host runs ahead,
-    # so that the K timed steps execute from a filled queue (without it the first launch's host latency, ~5 us, is
-    # 1 % of a 20-step region); then exactly K steps between two events on the launch stream.  No collective and no
-    # host synchronisation inside.
-    preroll = min(8, max(args.warmup, 1))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
+        while (time.perf_counter() - t_warm) * 1e3 < args.settle_ms:
+            for _ in range(50):
+                fwd()
+                bwd()
+            settle_steps += 50
+            torch.cuda.synchronize()
+    # ---- the timed region: barrier + synchronize | host clock | EXACTLY K steps | synchronize | host clock | barrier.
+    # Nothing else inside: no collective, no event, no host synchronisation (an event record costs ~5 us of a short
+    # region, spinning on an event query instead of the blocking synchronize costs MORE: scratch/wall_overhead.py,
+    # profiles/r03_wall_overhead.txt).
+    torch.cuda.synchronize()
+    sync.barrier('start')
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(preroll):
+    for _ in range(args.steps):
         fwd()
         bwd()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    sync.barrier('stop')
+    # the same K steps once more between two HIP events on the launch stream: the GPU-side time of such a region (without
+    # the first launch's latency from an idle queue and the wake-up after the synchronize, ~18 us together)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    e1.record()
+    torch.cuda.synchronize()
     e0.record()
     for _ in range(args.steps):
         fwd()
         bwd()
     e1.record()
     torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    barrier()
-    elapsed = e0.elapsed_time(e1) * 1e-3                # seconds of GPU time for the K steps on this rank
-
-    if world > 1:
-        t = torch.tensor([elapsed, wall], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, wall = float(t[0].item()), float(t[1].item())
-
+    event = e0.elapsed_time(e1) * 1e-3
+    wall_max, event_max = sync.max([wall, event])
+    res = {'rank': rank, 'device': device.index, 'n_devices': ndev, 'wall_s': wall_max, 'event_s': event_max,
+           'own_wall_s': wall, 'own_event_s': event, 'settle_steps': settle_steps, 'set_bytes': w.set_bytes}
     if rank == 0:
-        sb, fb = step_bytes(cfg)
-        total = sb * args.steps * world
-        value = total / elapsed / 2**30
-        step_us = elapsed / args.steps * 1e6
-        # per-kernel durations: K back-to-back launches of one kernel between two events (saturated queue)
-        reps = max(200, min(args.steps, 2000))
-        fwd_us, bwd_us = event_time_us([fwd], reps), event_time_us([bwd], reps)
-        # forward's duration inside the timed region: the measured step time split in the ratio of the two kernels'
-        # stand-alone durations; rocprofv3's per-dispatch average of the same command (profiles/) is the cross-check
-        fwd_in_step_us = step_us * fwd_us / (fwd_us + bwd_us)
-        achieved = fb / (fwd_in_step_us * 1e-6) / 1e9
-        traffic, traffic_source = None, None
-        tf = ROOT / 'profiles' / 'traffic_forward.json'
-        if args.config == 'c2' and tf.exists():
-            try:
-                doc = json.loads(tf.read_text())
-                traffic = doc.get('hbm_bytes_per_launch')
-                traffic_source = (f"replayed from {doc.get('source', 'profiles/traffic_forward.json')}: rocprofv3 --pmc FETCH_SIZE / "
-                                  "WRITE_SIZE passes over `bench.py --no-extras` (tools/profile_round.sh), NOT measured in this run")
-            except Exception:  # noqa: BLE001
-                traffic = None
-        kernel = 'quantize_forward_lut_kernel<gelu, bf16, 3 bits>'
-        line = {
-            'metric': 'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4096x4096 bf16' if args.config == 'c2' else
-                      'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4x(16384x4096) bf16 sharded over 8 GPUs (per-GPU shard 8192x4096)',
-            'value': round(value, 2), 'unit': 'GiB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f"{cfg['label']} per GPU, fused quantize+pack fwd / unpack+mul bwd via the C-ABI, inputs resident in HBM",
-                       'name': args.config, 'elements_per_gpu': n, 'bytes_per_step_per_gpu': int(sb),
-                       'parallelism': f'{world} independent shard(s) of {n} elements, cut by sharding.shard_range, no collectives',
-                       'working_set_MiB_per_gpu': round(w.set_bytes / 2**20, 1),
-                       'cache_state': 'warm: one buffer set re-used every step; it fits the 256 MiB Infinity Cache (see `cold`)'
-                                      if w.set_bytes < INFINITY_CACHE_BYTES else 'one buffer set, larger than the 256 MiB Infinity Cache'},
-            'timing': {'method': 'two HIP events on the launch stream around exactly K steps, after barrier+synchronize and an '
-                                 f'untimed {preroll}-step pre-roll; max over ranks',
-                       'warmup_settle': f'{settle_steps} extra untimed steps after the {args.warmup} warm-up steps, until the GPU had '
-                                        f'been busy {args.settle_ms:g} ms (clock transient after idle)',
-                       'wall_ms_per_step': round(wall / (args.steps + preroll) * 1e3, 5),
-                       'wall_note': f'host perf_counter from the barrier to the final synchronize over K+{preroll} steps'},
-            'pct_of_hbm_roofline': round(100.0 * (total / elapsed / 1e9) / (HBM_PEAK_GBS * world), 2),
-            'fwd_us': round(fwd_us, 2), 'bwd_us': round(bwd_us, 2), 'fwd_in_step_us': round(fwd_in_step_us, 2),
-            'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': round(achieved, 1),
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': traffic, 'traffic_source': traffic_source, 'algorithmic_bytes_per_launch': int(fb),
-                         'avg_launch_us': round(fwd_in_step_us, 2),
-                         'avg_launch_us_method': 'timed-region step time (HIP events) x fwd/(fwd+bwd) of the back-to-back '
-                                                 'per-kernel HIP-event timings (fwd_us, bwd_us)',
-                         'cache_state': 'warm (x and gy are served from the Infinity Cache; writes go to HBM)'},
-        }
-        line['evidence'] = {'rocprofv3_kernel_stats': 'profiles/r02_bench_kernel_stats.csv (this command with --no-extras)',
-                            'pmc_traffic': 'profiles/r02_pmc_traffic.json', 'per_config_rocprofv3_and_pmc': 'profiles/r02_configs.json',
-                            'copy_floor_at_this_size': 'profiles/r02_stream_bench_32MiB.txt', 'regenerate': 'bash tools/profile_round.sh r02'}
-        if world == 1 and not args.no_extras:
-            cold = measure_config(cfg, device, cold=True)
-            line['cold'] = dict(cold, note='same workload, rotating through independent buffer sets so nothing is re-used '
-                                           'from L2 / Infinity Cache; frac = fwd+bwd algorithmic bytes / us_step / 8 TB/s')
-            line['roofline']['frac_cold'] = round(fb / (cold['us_fwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-            line['roofline']['avg_launch_us_cold'] = cold['us_fwd']
-            others = {}
-            for name, c in CONFIGS.items():
-                if name == args.config:
-                    continue
-                others[name] = {'workload': c['label'], 'bytes_per_step': int(step_bytes(c)[0]),
-                                'warm': measure_config(c, device, cold=False)}
-                if step_bytes(c)[0] < 8 * INFINITY_CACHE_BYTES:      # beyond that one buffer set is cache-cold by itself
-                    others[name]['cold'] = measure_config(c, device, cold=True)
-                if 'reference_published' in c:
-                    others[name]['reference_published'] = c['reference_published']
-                    others[name]['vs_reference_published'] = round(others[name]['warm']['GiB_s'] / c['reference_published']['GiB_s'], 2)
-            line['configs'] = others
-        if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(cfg)
-            line['cpu_baseline_1thread'] = cpu_baseline(cfg, threads=1)
+        # Per-kernel figures for `roofline`, measured AFTER the contract's region and settled: a GPU that was idle boosts for
+        # ~1.5 ms, then runs 8-12 % slower for ~10 ms, then settles (scratch/timeline.py), and a short timed region (the
+        # driver's K = 20 is 0.5 ms) sits inside that transient.  ~40 ms of the same steps first, then: a long alternating
+        # fwd/bwd region between two events (steady_step_us), and each kernel back to back (fwd_us, bwd_us).
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) < 0.04:
+            for _ in range(50):
+                fwd()
+                bwd()
+            torch.cuda.synchronize()
+        reps = max(400, min(args.steps, 2000))
+        res['steady_step_us'] = event_time_us([fwd, bwd], reps, preroll=4)
+        res['fwd_us'], res['bwd_us'] = event_time_us([fwd], reps), event_time_us([bwd], reps)
+        res['kernels'] = describe(cfg)
+    return res, sync, device, w
+
+
+def build_line(args, world, res, per_rank=None, launcher='single process'):
+    cfg = CONFIGS[args.config]
+    n = cfg['rows'] * cfg['cols']
+    sb, fb = step_bytes(cfg)
+    wall, event = res['wall_s'], res['event_s']
+    total = sb * args.steps * world
+    value = total / wall / 2**30
+    step_us = wall / args.steps * 1e6
+    event_step_us = event / args.steps * 1e6
+    fwd_us, bwd_us = res['fwd_us'], res['bwd_us']
+    # forward's duration inside a step: the GPU time of a step (HIP events on the launch stream around a long, settled
+    # fwd/bwd region -- see run_rank) split in the ratio of the two kernels' stand-alone durations; rocprofv3's per-dispatch
+    # average of the same command (profiles/) is the cross-check.  The same split of the contract's own K-step region is
+    # given beside it (frac_timed_region): with a short K it sits in the clock transient after idle.
+    steady = res['steady_step_us']
+    fwd_in_step_us = steady * fwd_us / (fwd_us + bwd_us)
+    achieved = fb / (fwd_in_step_us * 1e-6) / 1e9
+    fwd_in_timed_us = event_step_us * fwd_us / (fwd_us + bwd_us)
+    traffic, traffic_source = None, None
+    tf = ROOT / 'profiles' / 'traffic_forward.json'
+    if args.config == 'c2' and tf.exists():
+        try:
+            doc = json.loads(tf.read_text())
+            traffic = doc.get('hbm_bytes_per_launch')
+            traffic_source = (f"replayed from {doc.get('source', 'profiles/traffic_forward.json')}: rocprofv3 --pmc FETCH_SIZE / "
+                              "WRITE_SIZE passes over `bench.py --no-extras` (tools/profile_round.sh), NOT measured in this run")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    kf, kb = res['kernels']
+    shared = world > res['n_devices']
+    line = {
+        'metric': 'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4096x4096 bf16' if args.config == 'c2' else
+                  'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4x(16384x4096) bf16 sharded over 8 GPUs (per-GPU shard 8192x4096)',
+        'value': round(value, 2), 'unit': 'GiB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(wall / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': f"{cfg['label']} per GPU, fused quantize+pack fwd / unpack+mul bwd via the C-ABI, inputs resident in HBM",
+                   'name': args.config, 'elements_per_gpu': n, 'bytes_per_step_per_gpu': int(sb),
+                   'parallelism': f'{world} independent shard(s) of {n} elements, cut by sharding.shard_range, no collectives',
+                   'launcher': launcher,
+                   'working_set_MiB_per_gpu': round(res['set_bytes'] / 2**20, 1),
+                   'cache_state': 'warm: one buffer set re-used every step; it fits the 256 MiB Infinity Cache (see `cold`)'
+                                  if res['set_bytes'] < INFINITY_CACHE_BYTES else 'one buffer set, larger than the 256 MiB Infinity Cache'},
+        'timing': {'method': 'host wall clock around exactly K steps, bracketed by barrier + synchronize on both sides; max over ranks '
+                             '(value, ms_per_step)',
+                   'event_ms_per_step': round(event / args.steps * 1e3, 5),
+                   'event_GiB_s': round(total / event / 2**30, 2),
+                   'event_note': 'a second, identical K-step region right after the timed one, between two HIP events on the launch '
+                                 'stream: GPU-side time of such a region, without the first launch\'s latency from an idle queue and the '
+                                 'wake-up after the final synchronize (~18 us together, profiles/r03_wall_overhead.txt)',
+                   'warmup_settle': (f'{res["settle_steps"]} extra untimed steps until the GPU had been busy {args.settle_ms:g} ms'
+                                     if args.settle_ms > 0 else 'off: exactly W warm-up steps')},
+        'pct_of_hbm_roofline': round(100.0 * (total / wall / 1e9) / (HBM_PEAK_GBS * world), 2),
+        'pct_of_hbm_roofline_event_timed': round(100.0 * (total / event / 1e9) / (HBM_PEAK_GBS * world), 2),
+        'fwd_us': round(fwd_us, 2), 'bwd_us': round(bwd_us, 2), 'fwd_in_step_us': round(fwd_in_step_us, 2),
+        'roofline': {'bound': 'hbm', 'kernel': kf['kernel'], 'launch_shape': {k: kf[k] for k in ('blocks', 'threads', 'blocks_per_cu', 'chunk', 'u')},
+                     'other_kernel': kb['kernel'],
+                     'achieved': round(achieved, 1),
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                     'traffic': traffic, 'traffic_source': traffic_source, 'algorithmic_bytes_per_launch': int(fb),
+                     'avg_launch_us': round(fwd_in_step_us, 2),
+                     'avg_launch_us_method': 'GPU time per step of a settled >= 400-step fwd/bwd region (two HIP events on the launch stream, '
+                                             'after the contract\'s region and ~40 ms of the same steps) x fwd/(fwd+bwd) of the back-to-back '
+                                             'per-kernel HIP-event timings (fwd_us, bwd_us)',
+                     'steady_step_us': round(steady, 2),
+                     'frac_timed_region': round(fb / (fwd_in_timed_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     'frac_timed_region_note': f'the same split applied to a {args.steps}-step region right after the contract\'s own (event-timed, timing.event_ms_per_step)',
+                     'cache_state': 'warm (x and gy are served from the Infinity Cache; writes go to HBM); frac_cold is the figure '
+                                    'with nothing cached'},
+    }
+    if shared:
+        line['shared_gpu'] = True
+        line['config']['parallelism'] += f' -- {world} ranks on {res["n_devices"]} visible device(s): ranks SHARE a GPU (validation run)'
+    if per_rank:
+        line['per_gpu_us_per_step'] = [round(r['own_wall_s'] / args.steps * 1e6, 2) for r in per_rank]
+        line['per_gpu_event_us_per_step'] = [round(r['own_event_s'] / args.steps * 1e6, 2) for r in per_rank]
+        line['per_gpu_device'] = [r['device'] for r in per_rank]
+    line['evidence'] = {'rocprofv3_kernel_stats': 'profiles/r03_bench_kernel_stats.csv (this command with --no-extras)',
+                        'pmc_traffic': 'profiles/r03_pmc_traffic.json', 'per_config_rocprofv3_and_pmc': 'profiles/r03_configs.json',
+                        'shape_sweeps': 'profiles/r03_shape_sweep_*.txt', 'copy_floor_at_this_size': 'profiles/r03_stream_bench_32MiB.txt',
+                        'regenerate': 'bash tools/profile_round.sh r03'}
+    return line
+
+
+def add_extras(line, args, device):
+    cfg = CONFIGS[args.config]
+    _, fb = step_bytes(cfg)
+    if not args.no_extras:
+        cold = measure_config(cfg, device, cold=True)
+        line['cold'] = dict(cold, note='same workload, rotating through independent buffer sets so nothing is re-used '
+                                       'from L2 / Infinity Cache; frac = fwd+bwd algorithmic bytes / us_step / 8 TB/s')
+        line['roofline']['frac_cold'] = round(fb / (cold['us_fwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        line['roofline']['avg_launch_us_cold'] = cold['us_fwd']
+        line['op_level'] = measure_op_level(cfg, device)
+        others = {}
+        for name, c in CONFIGS.items():
+            if name == args.config:
+                continue
+            kf, kb = describe(c)
+            others[name] = {'workload': c['label'], 'bytes_per_step': int(step_bytes(c)[0]),
+                            'kernels': {'fwd': kf['kernel'], 'bwd': kb['kernel'],
+                                        'fwd_shape': {k: kf[k] for k in ('blocks', 'threads', 'chunk')},
+                                        'bwd_shape': {k: kb[k] for k in ('blocks', 'threads', 'chunk')}},
+                            'warm': measure_config(c, device, cold=False)}
+            if step_bytes(c)[0] < (64 << 20):                    # launch-bound size: add the host-free figure
+                try:
+                    us = graph_step_us(c, device)
+                    others[name]['warm_hipgraph'] = {'us_step': round(us, 2), 'GiB_s': round(step_bytes(c)[0] / (us * 1e-6) / 2**30, 1),
+                                                     'frac': round(step_bytes(c)[0] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                     'note': '50 steps captured in one hipGraph, replayed: kernels + their two dependent-launch '
+                                                             'boundaries, no host launch cost (the eager figures above are bounded by the '
+                                                             'host: two launches per step at >= 2.7 us each)'}
+                except Exception as e:  # noqa: BLE001
+                    others[name]['warm_hipgraph'] = {'error': f'{type(e).__name__}: {e}'[:200]}
+            if step_bytes(c)[0] < 8 * INFINITY_CACHE_BYTES:      # beyond that one buffer set is cache-cold by itself
+                others[name]['cold'] = measure_config(c, device, cold=True)
+            if 'reference_published' in c:
+                others[name]['reference_published'] = c['reference_published']
+                others[name]['vs_reference_published'] = round(others[name]['warm']['GiB_s'] / c['reference_published']['GiB_s'], 2)
+            if not args.no_cpu_baseline and name in CPU_SAMPLES:
+                others[name]['cpu_baseline'] = cpu_baseline(name, c, CPU_SAMPLES[name][0])
+        line['configs'] = others
+    if not args.no_cpu_baseline:
+        reps_all, reps_one = CPU_SAMPLES[args.config]
+        line['cpu_baseline'] = cpu_baseline(args.config, cfg, reps_all)
+        if reps_one:
+            line['cpu_baseline_1thread'] = cpu_baseline(args.config, cfg, reps_one, threads=1)
+
+
+def parent_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start N children (one per device) BEFORE this process touches
+    the GPU, wait for them, print the one line.  Never exec: the children are ordinary subprocesses."""
+    world = args.gpus
+    sync_dir = Path(tempfile.mkdtemp(prefix='fewbit_bench_'))
+    children = []
+    try:
+        # FEWBIT_BENCH_WORKER: a stand-in worker script speaking the same protocol (tests/test_bench_launcher.py, no GPU)
+        worker = os.environ.get('FEWBIT_BENCH_WORKER') or str(Path(__file__).resolve())
+        base = [sys.executable, worker, '--gpus', str(world), '--steps', str(args.steps), '--warmup', str(args.warmup),
+                '--config', args.config, '--settle-ms', str(args.settle_ms), '--sync-dir', str(sync_dir)]
+        env = dict(os.environ)
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+            env.pop(k, None)
+        for r in range(world):
+            children.append(subprocess.Popen(base + ['--worker-rank', str(r)], env=env, stdout=subprocess.DEVNULL))
+        deadline = time.time() + args.launch_timeout
+        failed = None
+        pending = set(range(world))
+        while pending and failed is None:
+            for r in sorted(pending):
+                rc = children[r].poll()
+                if rc is not None:
+                    pending.discard(r)
+                    if rc != 0:
+                        failed = (r, rc)
+            if time.time() > deadline:
+                failed = (-1, 'timeout')
+            time.sleep(0.02)
+        if failed is not None:
+            (sync_dir / 'abort').touch()
+            for c in children:
+                if c.poll() is None:
+                    c.terminate()            # exactly the PIDs started above
+            for c in children:
+                try:
+                    c.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    c.kill()
+            sys.exit(f'bench.py: rank {failed[0]} failed ({failed[1]}); no result')
+        per_rank = [json.loads((sync_dir / f'result.{r}.json').read_text()) for r in range(world)]
+        res = dict(per_rank[0])
+        res['wall_s'] = max(r['own_wall_s'] for r in per_rank)
+        res['event_s'] = max(r['own_event_s'] for r in per_rank)
+        line = build_line(args, world, res, per_rank,
+                          launcher=f'bench.py started {world} child processes itself (one per device, file barriers, no process group)')
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    finally:
+        shutil.rmtree(sync_dir, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--config', choices=('c2', 'c4'), default='c2', help='headline workload per GPU (see module docstring)')
+    ap.add_argument('--settle-ms', type=float, default=0.0,
+                    help='optional: keep issuing untimed warm-up steps until the GPU has been busy this long (default 0 = exactly W '
+                         'steps): MI355X drops its clocks 1.5-10 ms after load begins and recovers by ~15 ms (scratch/timeline.py)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='timed region only (what the rocprofv3 passes run)')
+    ap.add_argument('--worker-rank', type=int, default=None, help=argparse.SUPPRESS)     # set by parent_launch
+    ap.add_argument('--sync-dir', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--launch-timeout', type=float, default=900.0, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    if args.worker_rank is not None:                     # a child of parent_launch
+        rank, world = args.worker_rank, args.gpus
+        res, sync, device, w = run_rank(args, rank, rank, world, lambda device: FileSync(args.sync_dir, rank, world))
+        tmp = Path(args.sync_dir) / f'result.{rank}.json.tmp'
+        tmp.write_text(json.dumps(res))
+        tmp.rename(Path(args.sync_dir) / f'result.{rank}.json')
+        return
+
+    if 'WORLD_SIZE' in os.environ:                       # under torch.distributed.run
+        rank, local_rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ['WORLD_SIZE'])
+        args.gpus = world
+        if world > 1:
+            res, sync, device, w = run_rank(args, rank, local_rank, world, lambda device: TorchSync(rank, world, device))
+            own = torch.tensor([res['own_wall_s'], res['own_event_s'], float(res['device'])], dtype=torch.float64)
+            gathered = [torch.zeros_like(own) for _ in range(world)] if sync.backend != 'nccl' else None
+            per_rank = None
+            if gathered is not None:
+                sync.dist.all_gather(gathered, own)
+                per_rank = [{'own_wall_s': float(g[0]), 'own_event_s': float(g[1]), 'device': int(g[2])} for g in gathered]
+            if rank == 0:
+                line = build_line(args, world, res, per_rank,
+                                  launcher=f'torch.distributed.run, {world} ranks; {sync.backend} process group for the barrier and the max only')
+                print(json.dumps(line), flush=True)
+            sync.close()
+            return
+
+    if args.gpus > 1:
+        return parent_launch(args)
+
+    res, sync, device, w = run_rank(args, 0, int(os.environ.get('LOCAL_RANK', 0)), 1, lambda device: NoSync())
+    line = build_line(args, 1, res)
+    del w
+    torch.cuda.empty_cache()
+    add_extras(line, args, device)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

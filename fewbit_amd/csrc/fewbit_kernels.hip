@@ -117,6 +117,9 @@ __device__ unsigned long long g_trace[1 << 17];
 #define FEWBIT_STAMP(slot) do { } while (0)
 #endif
 
+// `flags` argument of the streaming kernels (wave-uniform)
+constexpr int kFlagStreamOut = 1;   // y / gx are written nontemporal: set unless the output aliases the input (in place)
+
 // Two-buffer software pipeline over the tiles of one wave: the loads of the next tile are issued
 // before the current tile is processed, and the two register buffers alternate (no copies), so the
 // only wait in front of process(tile i) is for loads issued a whole tile earlier.
@@ -214,13 +217,14 @@ template <int FN, int DT, int K, int U>
 __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) void quantize_forward_kernel(const void *x, void *y,
                                                                   uint8_t *__restrict__ state, size_t n,
                                                                   const void *__restrict__ borders, float p0,
-                                                                  float p1, int chunk) {
+                                                                  float p1, int chunk, int flags) {
     constexpr int NB = (1 << K) - 1;
     constexpr bool kFast = (DT != FEWBIT_F32);
     constexpr bool kSplit = (DT == FEWBIT_F32) && (FEWBIT_F32_SPLIT != 0);     // fp32: contiguous split tiles
     constexpr bool kStreamY = (DT != FEWBIT_F32) || kSplit;
     typedef typename GroupIO<DT>::Raw Raw;
     const Span s = make_span<U>(n, chunk);
+    const bool nt_out = (flags & kFlagStreamOut) != 0;
 
     float b[NB];
     const float mine = fetch_border<DT, NB>(borders);
@@ -275,8 +279,9 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) v
                 // instruction leaves holes that only L2 write-combining fills -- nontemporal there costs 4 us per pass.
                 // state: plain store -- it is what backward reads, and a backward that follows closely finds it
                 // cached (4096x4096 bf16 step 26.5 -> 25.6 us); when backward runs much later it makes no difference.
-                if constexpr (kSplit) SplitF32::store<true>(y, g, s.lane, v);
-                else GroupIO<DT>::template store<kStreamY>(y, g, v);
+                if constexpr (kSplit) SplitF32::store_sel(nt_out, y, g, s.lane, v);
+                else if constexpr (kStreamY) GroupIO<DT>::store_sel(nt_out, y, g, v);
+                else GroupIO<DT>::template store<false>(y, g, v);
                 store_state_quad<K, false>(state, g, s.lane, w);
             }
         });
@@ -328,7 +333,7 @@ template <int DT> __device__ __forceinline__ float value_of_pattern(uint32_t r) 
 template <int FN, int DT, int K, int U, int BLOCK = kLutBlock>
 __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize_forward_lut_kernel(const void *x, void *y, uint8_t *state,
                                                                             size_t n, const void *borders,
-                                                                            int nborders, float p0, float p1, int chunk) {
+                                                                            int nborders, float p0, float p1, int chunk, int flags) {
     constexpr int kLutBlock = BLOCK, kLutWaves = BLOCK / kWave;        // (shadow the file-level defaults)
     static_assert(DT != FEWBIT_F32, "the pattern table exists for 16-bit dtypes only");
     constexpr int NBMAX = (1 << K) - 1;
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ __attribute__((aligned(16))) uint8_t lut[65536];
     const Span s = make_span<U, kLutWaves>(n, chunk);
+    const bool nt_out = (flags & kFlagStreamOut) != 0;
 
     // the table's global loads go out FIRST (lane j fetches border j, as a float and as a raw pattern): the build then
     // waits only for them, not for the first tile of x that pipeline2 issues right after
@@ -392,8 +398,14 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
         __syncthreads();
     };
 
+#ifndef FEWBIT_ABLATE_LUT
+#define FEWBIT_ABLATE_LUT 0     // measurement builds only: 1 no activation, 2 no table lookup, 4 no table build, 8 no state store
+#endif
+    auto build_or_not = [&]() {
+        if constexpr ((FEWBIT_ABLATE_LUT & 4) == 0) build();
+    };
     pipeline2<Buf, true>(
-        s, build,
+        s, build_or_not,
         [&](size_t t, int ln, Buf &buf) {
 #pragma unroll
             for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + ln);
@@ -402,19 +414,26 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint32_t w = 0;
+                if constexpr ((FEWBIT_ABLATE_LUT & 2) != 0) {
+                    w = buf.r[u].q[0] ^ buf.r[u].q[1] ^ buf.r[u].q[2] ^ buf.r[u].q[3];
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t d = buf.r[u].q[i];
-                    w |= static_cast<uint32_t>(lut[d & 0xffffu]) << (K * 2 * i);
-                    w |= static_cast<uint32_t>(lut[d >> 16]) << (K * (2 * i + 1));
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t d = buf.r[u].q[i];
+                        w |= static_cast<uint32_t>(lut[d & 0xffffu]) << (K * 2 * i);
+                        w |= static_cast<uint32_t>(lut[d >> 16]) << (K * (2 * i + 1));
+                    }
                 }
                 float v[8];
                 GroupIO<DT>::unpack(buf.r[u], v);
+                if constexpr ((FEWBIT_ABLATE_LUT & 1) == 0) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
+                    for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
+                }
                 const size_t g = (t * U + u) * kWave + s.lane;
-                GroupIO<DT>::template store<true>(y, g, v);
-                store_state_quad<K, false>(state, g, s.lane, w);
+                GroupIO<DT>::store_sel(nt_out, y, g, v);
+                if constexpr ((FEWBIT_ABLATE_LUT & 8) == 0) store_state_quad<K, false>(state, g, s.lane, w);
+                else if (w == 0x12345u) store_state_quad<K, false>(state, g, s.lane, w);
             }
         });
 
@@ -469,7 +488,7 @@ __device__ __forceinline__ void wide_forward_tail(const Span &s, const void *x, 
 template <int FN, int DT>
 __global__ __launch_bounds__(kBlock, 6) void quantize_forward_wide_kernel(const void *x, void *y, uint8_t *state, size_t n,
                                                                           const void *borders, int nborders, int nbits,
-                                                                          float p0, float p1, int chunk) {
+                                                                          float p0, float p1, int chunk, int flags) {
     constexpr bool kFast = (DT != FEWBIT_F32);
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ float sb[256];
@@ -503,7 +522,8 @@ __global__ __launch_bounds__(kBlock, 6) void quantize_forward_wide_kernel(const 
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
             const size_t g = t * kWave + s.lane;
-            GroupIO<DT>::template store<kFast>(y, g, v);
+            if constexpr (kFast) GroupIO<DT>::store_sel((flags & kFlagStreamOut) != 0, y, g, v);
+            else GroupIO<DT>::template store<false>(y, g, v);
             store_state_wide(state, g, nbits, w);
         });
     if (!s.tail_owner) return;
@@ -519,7 +539,7 @@ template <int FN, int DT>
 __global__ __launch_bounds__(kLutBlock, (lut_waves_per_simd<kLutBlock>())) void quantize_forward_lut_wide_kernel(const void *x, void *y,
                                                                                  uint8_t *state, size_t n,
                                                                                  const void *borders, int nborders,
-                                                                                 int nbits, float p0, float p1, int chunk) {
+                                                                                 int nbits, float p0, float p1, int chunk, int flags) {
     static_assert(DT != FEWBIT_F32, "the pattern table exists for 16-bit dtypes only");
     constexpr uint32_t kInf = (DT == FEWBIT_BF16) ? 0x7f80u : 0x7c00u;
     typedef typename GroupIO<DT>::Raw Raw;
@@ -590,7 +610,7 @@ __global__ __launch_bounds__(kLutBlock, (lut_waves_per_simd<kLutBlock>())) void 
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
             const size_t g = t * kWave + s.lane;
-            GroupIO<DT>::template store<true>(y, g, v);
+            GroupIO<DT>::store_sel((flags & kFlagStreamOut) != 0, y, g, v);
             store_state_wide(state, g, nbits, w);
         });
     if (!s.tail_owner) return;
@@ -602,7 +622,7 @@ __global__ __launch_bounds__(kLutBlock, (lut_waves_per_simd<kLutBlock>())) void 
 template <int DT>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_kernel(const void *gy, const uint8_t *state,
                                                                                   void *gx, size_t n, const void *levels,
-                                                                                  int nlevels, int nbits, int chunk) {
+                                                                                  int nlevels, int nbits, int chunk, int flags) {
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ float lut[256];
     const Span s = make_span<1>(n, chunk, 1);
@@ -627,7 +647,8 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_
                 v[i] = lut[(wlo >> (nbits * i)) & mask] * v[i];
                 v[4 + i] = lut[(whi >> (nbits * i)) & mask] * v[4 + i];
             }
-            GroupIO<DT>::template store<(DT != FEWBIT_F32)>(gx, t * kWave + s.lane, v);
+            if constexpr (DT != FEWBIT_F32) GroupIO<DT>::store_sel((flags & kFlagStreamOut) != 0, gx, t * kWave + s.lane, v);
+            else GroupIO<DT>::template store<false>(gx, t * kWave + s.lane, v);
         });
     if (!s.tail_owner) return;
     for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
@@ -648,12 +669,13 @@ template <int DT, int K, int U>
 __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quantize_backward_kernel(const void *gy,
                                                                    const uint8_t *state, void *gx,
                                                                    size_t n, const void *__restrict__ levels,
-                                                                   int nlevels, int chunk) {
+                                                                   int nlevels, int chunk, int flags) {
     constexpr int NL = 1 << K;
     constexpr uint32_t kMask = NL - 1;
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ float lut[NL];
     const Span s = make_span<U>(n, chunk);
+    const bool nt_out = (flags & kFlagStreamOut) != 0;
 
     // the level fetch goes out before the first tiles: vmcnt counts in order, so waiting for it in init() does not
     // wait for the tiles as well
@@ -677,7 +699,11 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
                 } else {
                     buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + ln);
                 }
-                buf.w[u] = load_state_quad_raw<K>(state, (t * U + u) * kWave + ln, ln);
+#ifndef FEWBIT_ABLATE_BWD
+#define FEWBIT_ABLATE_BWD 0     // measurement builds only: 1 no level gather / multiply, 2 no state load, 4 plain gx stores
+#endif
+                if constexpr ((FEWBIT_ABLATE_BWD & 2) != 0) buf.w[u] = static_cast<uint32_t>(ln) * 0x9e3779b9u;
+                else buf.w[u] = load_state_quad_raw<K>(state, (t * U + u) * kWave + ln, ln);
             }
         },
         [&](size_t t, const Buf &buf) {
@@ -686,6 +712,11 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
                 float v[8];
                 GroupIO<DT>::unpack(buf.r[u], v);
                 const uint32_t w = load_state_quad_fix<K>(buf.w[u], s.lane);
+                if constexpr ((FEWBIT_ABLATE_BWD & 1) != 0) {
+                    if (w == 0x12345u) v[0] = 0.0f;
+                    GroupIO<DT>::template store<(FEWBIT_ABLATE_BWD & 4) == 0>(gx, (t * U + u) * kWave + s.lane, v);
+                    continue;
+                }
                 if constexpr (kSplit) {      // v[0..3] / v[4..7] are halves of two different groups (SplitF32)
                     uint32_t cA, cB;
                     split_word_to_halves<K>(w, s.lane, cA, cB);
@@ -694,7 +725,7 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
                         v[i] = lut[(cA >> (K * i)) & kMask] * v[i];
                         v[4 + i] = lut[(cB >> (K * i)) & kMask] * v[4 + i];
                     }
-                    SplitF32::store<true>(gx, (t * U + u) * kWave + s.lane, s.lane, v);
+                    SplitF32::store_sel(nt_out, gx, (t * U + u) * kWave + s.lane, s.lane, v);
                     continue;
                 }
 #pragma unroll
@@ -703,7 +734,8 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
                 // be read out of L2 / Infinity Cache and is written back during the NEXT kernel (cache-cold backward at
                 // 4096x4096 bf16 15.3 -> 13.9 us, 2^26 elements forward+backward 100.6 -> 94.1 us; RoBERTa-base step
                 // unchanged).  fp32 in the split layout (above) stores whole lines and is nontemporal too.
-                GroupIO<DT>::template store<(DT != FEWBIT_F32)>(gx, (t * U + u) * kWave + s.lane, v);
+                if constexpr (DT != FEWBIT_F32 && (FEWBIT_ABLATE_BWD & 4) == 0) GroupIO<DT>::store_sel(nt_out, gx, (t * U + u) * kWave + s.lane, v);
+                else GroupIO<DT>::template store<false>(gx, (t * U + u) * kWave + s.lane, v);
             }
         });
 
@@ -722,9 +754,10 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
 template <int FN, int DT, int U>
 __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void stepwise1_forward_kernel(const void *x, void *y,
                                                                    uint8_t *__restrict__ state, size_t n, float p0,
-                                                                   float p1, int chunk) {
+                                                                   float p1, int chunk, int flags) {
     typedef typename GroupIO<DT>::Raw Raw;
     const Span s = make_span<U>(n, chunk);
+    const bool nt_out = (flags & kFlagStreamOut) != 0;
     constexpr bool kSplit = (DT == FEWBIT_F32) && (FEWBIT_F32_SPLIT != 0);     // see SplitF32
     struct Buf { Raw r[U]; };
     pipeline2<Buf>(
@@ -756,9 +789,11 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void step
                 const size_t g = (t * U + u) * kWave + s.lane;
                 if constexpr (kSplit) {      // bits 0..3 / 4..7 of w belong to halves of two different groups
                     w = split_halves_to_word<1>(w & 15u, w >> 4, s.lane);
-                    SplitF32::store<true>(y, g, s.lane, v);
+                    SplitF32::store_sel(nt_out, y, g, s.lane, v);
+                } else if constexpr (DT != FEWBIT_F32) {
+                    GroupIO<DT>::store_sel(nt_out, y, g, v);
                 } else {
-                    GroupIO<DT>::template store<(DT != FEWBIT_F32)>(y, g, v);
+                    GroupIO<DT>::template store<false>(y, g, v);
                 }
                 store_state_quad<1, false>(state, g, s.lane, w);
             }
@@ -781,9 +816,10 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void step
 template <int DT, int U>
 __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void stepwise1_backward_kernel(const void *gy,
                                                                     const uint8_t *state, void *gx,
-                                                                    size_t n, float m0, float m1, int chunk) {
+                                                                    size_t n, float m0, float m1, int chunk, int flags) {
     typedef typename GroupIO<DT>::Raw Raw;
     const Span s = make_span<U>(n, chunk);
+    const bool nt_out = (flags & kFlagStreamOut) != 0;
     constexpr bool kSplit = (DT == FEWBIT_F32) && (FEWBIT_F32_SPLIT != 0);
     struct Buf { Raw r[U]; uint32_t w[U]; };
     pipeline2<Buf>(
@@ -814,8 +850,9 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void step
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = (((w >> i) & 1u) ? m1 : m0) * v[i];
-                if constexpr (kSplit) SplitF32::store<true>(gx, (t * U + u) * kWave + s.lane, s.lane, v);
-                else GroupIO<DT>::template store<(DT != FEWBIT_F32)>(gx, (t * U + u) * kWave + s.lane, v);
+                if constexpr (kSplit) SplitF32::store_sel(nt_out, gx, (t * U + u) * kWave + s.lane, s.lane, v);
+                else if constexpr (DT != FEWBIT_F32) GroupIO<DT>::store_sel(nt_out, gx, (t * U + u) * kWave + s.lane, v);
+                else GroupIO<DT>::template store<false>(gx, (t * U + u) * kWave + s.lane, v);
             }
         });
     if (!s.tail_owner) return;
@@ -930,6 +967,7 @@ enum TuneKey {
     T_LUT_MIN,             // smallest tensor (elements) that takes the pattern-table forward; 0 = always
     T_LUT_BLOCK,           // threads per pattern-table block (512 or 1024), where the build has both
     T_U_FWD, T_U_BWD, T_U_LUT, T_U_STEP1,     // groups per lane per pipeline stage (1, 2 or 4), where the build has them
+    T_NT_INPLACE,          // 1: nontemporal output stores even when the output aliases the input (A/B of the policy: plain)
     T_COUNT
 };
 struct TuneSpec { const char *key, *env; };
@@ -937,6 +975,7 @@ constexpr TuneSpec kTuneSpec[T_COUNT] = {
     {"waves_per_cu", "FEWBIT_HIP_WAVES_PER_CU"}, {"chunk", "FEWBIT_HIP_CHUNK"}, {"lut_chunk", "FEWBIT_HIP_LUT_CHUNK"},
     {"lut_blocks_per_cu", "FEWBIT_HIP_LUT_BLOCKS_PER_CU"}, {"lut_min", "FEWBIT_HIP_LUT_MIN"}, {"lut_block", "FEWBIT_HIP_LUT_BLOCK"},
     {"u_fwd", "FEWBIT_HIP_U_FWD"}, {"u_bwd", "FEWBIT_HIP_U_BWD"}, {"u_lut", "FEWBIT_HIP_U_LUT"}, {"u_step1", "FEWBIT_HIP_U_STEP1"},
+    {"nt_inplace", "FEWBIT_HIP_NT_INPLACE"},
 };
 std::atomic<long long> g_tune[T_COUNT];
 std::once_flag g_tune_once;
@@ -1056,7 +1095,7 @@ Shape launch_shape(size_t ntiles, int waves_per_block, size_t resident_blocks, l
 
 // launch (or, dry, only describe) a 256-thread streaming kernel instantiation; the kernels' last parameter is the chunk
 template <auto Kern, typename... Args>
-void launch_tiled(Plan *plan, bool dry, const Device &dev, size_t n, int U, hipStream_t s, Args... args) {
+void launch_tiled(Plan *plan, bool dry, const Device &dev, size_t n, int U, int flags, hipStream_t s, Args... args) {
     int per_cu = occupancy_blocks_per_cu<Kern>(dev, kBlock);
     if (per_cu > 8) per_cu = 8;
     const long long cap = tune(T_WAVES_PER_CU);
@@ -1071,12 +1110,12 @@ void launch_tiled(Plan *plan, bool dry, const Device &dev, size_t n, int U, hipS
         plan->u = U;
         plan->blocks_per_cu = per_cu;
     }
-    if (!dry) hipLaunchKernelGGL(Kern, dim3(sh.blocks), dim3(kBlock), 0, s, args..., sh.chunk);
+    if (!dry) hipLaunchKernelGGL(Kern, dim3(sh.blocks), dim3(kBlock), 0, s, args..., sh.chunk, flags);
 }
 
 // pattern-table forward: BLOCK-thread blocks, at most two resident per CU (LDS), each wave loops over its tiles
 template <auto Kern, int BLOCK, typename... Args>
-void launch_lut(Plan *plan, bool dry, const Device &dev, size_t n, int U, hipStream_t s, Args... args) {
+void launch_lut(Plan *plan, bool dry, const Device &dev, size_t n, int U, int flags, hipStream_t s, Args... args) {
     int per_cu = occupancy_blocks_per_cu<Kern>(dev, BLOCK);
     if (per_cu > 2) per_cu = 2;
     const long long cap = tune(T_LUT_BLOCKS_PER_CU);
@@ -1091,7 +1130,7 @@ void launch_lut(Plan *plan, bool dry, const Device &dev, size_t n, int U, hipStr
         plan->u = U;
         plan->blocks_per_cu = per_cu;
     }
-    if (!dry) hipLaunchKernelGGL(Kern, dim3(sh.blocks), dim3(BLOCK), 0, s, args..., sh.chunk);
+    if (!dry) hipLaunchKernelGGL(Kern, dim3(sh.blocks), dim3(BLOCK), 0, s, args..., sh.chunk, flags);
 }
 
 // Smallest tensor that takes the pattern-table forward: building the table costs the same whatever the table, the register
@@ -1114,7 +1153,7 @@ typedef UList<1, 2> FwdUs32;
 typedef UList<1, 2, 4> LutUs;
 #else
 typedef UList<1> FwdUs16;
-typedef UList<1> FwdUs32;
+typedef UList<1, 2> FwdUs32;
 typedef UList<1> LutUs;
 #endif
 typedef UList<1, 2, 4> StreamUs16;
@@ -1134,15 +1173,32 @@ template <int U0, int... Us, typename F> void with_u(UList<U0, Us...>, long long
     if (!done) f(std::integral_constant<int, U0>{});
 }
 
-// built-in U policy (MI355X measurements, profiles/r03_shape_sweep_*.txt)
-template <int DT> long long policy_u_fwd(size_t) { return 1; }
+// Built-in U policy (MI355X, round 3: profiles/r03_shape_sweep_*.txt, profiles/r03_backward_size_crossover.txt).
+//   16-bit backward / 1-bit backward: two groups per lane per stage in the resident shape up to ~1.25x the headline size
+//     (4096x4096: 11.04 us against 11.51 with one); from 20 Mi elements on ONE group per lane in the one-tile-per-wave
+//     grid (chunk = 1 follows from the shape policy): cache-cold 3.5-4.6 % faster at every size measured (8192x4096 bf16
+//     26.10 -> 24.91 us, 16384x3072 bf16 37.50 -> 35.99 us, 8192x8192 fp16 47.76 -> 45.73 us) for 0-2 % cache-warm --
+//     inside a training step the tensors are cold (profiles/r03_roberta_kernel_stats_*.csv), so cold decides.
+//   fp32 forward (register search): two groups per lane from 32 Mi elements on (16384x3072 fp32: 64.6 -> 61.0 us warm,
+//     72.2 -> 71.0 us cold; at 4096x4096 one group is better when cold: 25.7 against 27.3 us).
+//   everything else: one group per lane.
+constexpr size_t kLargeStream16 = static_cast<size_t>(20) << 20;
+constexpr size_t kLargeForward32 = static_cast<size_t>(32) << 20;
+template <int DT> long long policy_u_fwd(size_t n) { return DT == FEWBIT_F32 && n >= kLargeForward32 ? 2 : 1; }
 template <int DT> long long policy_u_lut(size_t) { return 1; }
-template <int DT> long long policy_u_bwd(size_t) { return DT == FEWBIT_F32 ? 1 : 2; }
+template <int DT> long long policy_u_bwd(size_t n) { return DT == FEWBIT_F32 || n >= kLargeStream16 ? 1 : 2; }
 template <int DT> long long policy_u_step1_fwd(size_t) { return 1; }
-template <int DT> long long policy_u_step1_bwd(size_t) { return DT == FEWBIT_F32 ? 1 : 2; }
+template <int DT> long long policy_u_step1_bwd(size_t n) { return DT == FEWBIT_F32 || n >= kLargeStream16 ? 1 : 2; }
 long long tuned(TuneKey key, long long policy) {
     const long long t = tune(key);
     return t > 0 ? t : policy;
+}
+
+// kernel `flags`: outputs go past the caches (nontemporal) unless they alias the input -- the reference operator's own
+// in-place mode --, where the line being written has just been read and a plain store is 7-15 % faster
+int out_flags(const void *in, const void *out) {
+    if (in != out) return kFlagStreamOut;
+    return tune(T_NT_INPLACE) == 1 ? kFlagStreamOut : 0;
 }
 
 unsigned group_grid(size_t n) { return static_cast<unsigned>(((n + 7) / 8 + kBlock - 1) / kBlock); }
@@ -1152,6 +1208,7 @@ int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state,
                    int k, float p0, float p1, hipStream_t s) {
     Device dev;
     if (const int rc = get_device(dev)) return rc;
+    const int flags = out_flags(x, y);
     const bool pow2 = nborders == (1 << k) - 1;
     if (plan) plan->k = k;
     auto name = [&](const char *kern, int U, int block) {
@@ -1163,7 +1220,7 @@ int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state,
         // building the table in every block
         if (n >= lut_min_elements(k)) {
             if (k > 4) {
-                launch_lut<quantize_forward_lut_wide_kernel<FN, DT>, kLutBlock>(plan, dry, dev, n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
+                launch_lut<quantize_forward_lut_wide_kernel<FN, DT>, kLutBlock>(plan, dry, dev, n, 1, flags, s, x, y, state, n, borders, nborders, k, p0, p1);
                 name("quantize_forward_lut_wide_kernel", 1, kLutBlock);
                 return dry ? FEWBIT_OK : check_launch("quantize_forward(lut)");
             }
@@ -1172,10 +1229,10 @@ int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state,
                 auto go = [&](auto btag) {
                     constexpr int B = decltype(btag)::value;
                     switch (k) {
-                    case 1: launch_lut<quantize_forward_lut_kernel<FN, DT, 1, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
-                    case 2: launch_lut<quantize_forward_lut_kernel<FN, DT, 2, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
-                    case 3: launch_lut<quantize_forward_lut_kernel<FN, DT, 3, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
-                    default: launch_lut<quantize_forward_lut_kernel<FN, DT, 4, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    case 1: launch_lut<quantize_forward_lut_kernel<FN, DT, 1, U, B>, B>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    case 2: launch_lut<quantize_forward_lut_kernel<FN, DT, 2, U, B>, B>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    case 3: launch_lut<quantize_forward_lut_kernel<FN, DT, 3, U, B>, B>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    default: launch_lut<quantize_forward_lut_kernel<FN, DT, 4, U, B>, B>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, nborders, p0, p1); break;
                     }
                     name("quantize_forward_lut_kernel", U, B);
                 };
@@ -1194,15 +1251,15 @@ int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state,
         with_u(Us{}, tuned(T_U_FWD, policy_u_fwd<DT>(n)), [&](auto tag) {
             constexpr int U = decltype(tag)::value;
             switch (k) {
-            case 1: launch_tiled<quantize_forward_kernel<FN, DT, 1, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
-            case 2: launch_tiled<quantize_forward_kernel<FN, DT, 2, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
-            case 3: launch_tiled<quantize_forward_kernel<FN, DT, 3, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
-            default: launch_tiled<quantize_forward_kernel<FN, DT, 4, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
+            case 1: launch_tiled<quantize_forward_kernel<FN, DT, 1, U>>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, p0, p1); break;
+            case 2: launch_tiled<quantize_forward_kernel<FN, DT, 2, U>>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, p0, p1); break;
+            case 3: launch_tiled<quantize_forward_kernel<FN, DT, 3, U>>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, p0, p1); break;
+            default: launch_tiled<quantize_forward_kernel<FN, DT, 4, U>>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, p0, p1); break;
             }
             name("quantize_forward_kernel", U, kBlock);
         });
     } else {                       // 5..8-bit tables and tables that do not fill their bit width: borders in LDS
-        launch_tiled<quantize_forward_wide_kernel<FN, DT>>(plan, dry, dev, n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
+        launch_tiled<quantize_forward_wide_kernel<FN, DT>>(plan, dry, dev, n, 1, flags, s, x, y, state, n, borders, nborders, k, p0, p1);
         name("quantize_forward_wide_kernel", 1, kBlock);
     }
     return dry ? FEWBIT_OK : check_launch("quantize_forward");
@@ -1224,9 +1281,10 @@ int launch_backward(Plan *plan, bool dry, const void *gy, const uint8_t *state, 
                     int k, hipStream_t s) {
     Device dev;
     if (const int rc = get_device(dev)) return rc;
+    const int flags = out_flags(gy, gx);
     if (plan) plan->k = k;
     if (k > 4) {
-        launch_tiled<quantize_backward_wide_kernel<DT>>(plan, dry, dev, n, 1, s, gy, state, gx, n, levels, nlevels, k);
+        launch_tiled<quantize_backward_wide_kernel<DT>>(plan, dry, dev, n, 1, flags, s, gy, state, gx, n, levels, nlevels, k);
         if (plan) snprintf(plan->kernel, sizeof plan->kernel, "quantize_backward_wide_kernel<%s, %d bits>", dtype_name(DT), k);
         return dry ? FEWBIT_OK : check_launch("quantize_backward");
     }
@@ -1234,10 +1292,10 @@ int launch_backward(Plan *plan, bool dry, const void *gy, const uint8_t *state, 
     with_u(Us{}, tuned(T_U_BWD, policy_u_bwd<DT>(n)), [&](auto tag) {
         constexpr int U = decltype(tag)::value;
         switch (k) {
-        case 1: launch_tiled<quantize_backward_kernel<DT, 1, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
-        case 2: launch_tiled<quantize_backward_kernel<DT, 2, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
-        case 3: launch_tiled<quantize_backward_kernel<DT, 3, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
-        default: launch_tiled<quantize_backward_kernel<DT, 4, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
+        case 1: launch_tiled<quantize_backward_kernel<DT, 1, U>>(plan, dry, dev, n, U, flags, s, gy, state, gx, n, levels, nlevels); break;
+        case 2: launch_tiled<quantize_backward_kernel<DT, 2, U>>(plan, dry, dev, n, U, flags, s, gy, state, gx, n, levels, nlevels); break;
+        case 3: launch_tiled<quantize_backward_kernel<DT, 3, U>>(plan, dry, dev, n, U, flags, s, gy, state, gx, n, levels, nlevels); break;
+        default: launch_tiled<quantize_backward_kernel<DT, 4, U>>(plan, dry, dev, n, U, flags, s, gy, state, gx, n, levels, nlevels); break;
         }
         if (plan) snprintf(plan->kernel, sizeof plan->kernel, "quantize_backward_kernel<%s, %d bits, U=%d>", dtype_name(DT), k, U);
     });
@@ -1248,11 +1306,12 @@ template <int FN, int DT>
 int launch_step1_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state, size_t n, float p0, float p1, hipStream_t s) {
     Device dev;
     if (const int rc = get_device(dev)) return rc;
+    const int flags = out_flags(x, y);
     if (plan) plan->k = 1;
     typedef typename std::conditional<DT == FEWBIT_F32, StreamUs32, StreamUs16>::type Us;
     with_u(Us{}, tuned(T_U_STEP1, policy_u_step1_fwd<DT>(n)), [&](auto tag) {
         constexpr int U = decltype(tag)::value;
-        launch_tiled<stepwise1_forward_kernel<FN, DT, U>>(plan, dry, dev, n, U, s, x, y, state, n, p0, p1);
+        launch_tiled<stepwise1_forward_kernel<FN, DT, U>>(plan, dry, dev, n, U, flags, s, x, y, state, n, p0, p1);
         if (plan) snprintf(plan->kernel, sizeof plan->kernel, "stepwise1_forward_kernel<%s, %s, U=%d>", kStepNames[FN], dtype_name(DT), U);
     });
     return dry ? FEWBIT_OK : check_launch("stepwise1_forward");
@@ -1274,11 +1333,12 @@ int launch_step1_backward(Plan *plan, bool dry, const void *gy, const uint8_t *s
                           hipStream_t s) {
     Device dev;
     if (const int rc = get_device(dev)) return rc;
+    const int flags = out_flags(gy, gx);
     if (plan) plan->k = 1;
     typedef typename std::conditional<DT == FEWBIT_F32, StreamUs32, StreamUs16>::type Us;
     with_u(Us{}, tuned(T_U_STEP1, policy_u_step1_bwd<DT>(n)), [&](auto tag) {
         constexpr int U = decltype(tag)::value;
-        launch_tiled<stepwise1_backward_kernel<DT, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, m0, m1);
+        launch_tiled<stepwise1_backward_kernel<DT, U>>(plan, dry, dev, n, U, flags, s, gy, state, gx, n, m0, m1);
         if (plan) snprintf(plan->kernel, sizeof plan->kernel, "stepwise1_backward_kernel<%s, U=%d>", dtype_name(DT), U);
     });
     return dry ? FEWBIT_OK : check_launch("stepwise1_backward");

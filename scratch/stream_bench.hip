@@ -66,6 +66,12 @@ template <int V, bool NTL, bool NTS> __global__ __launch_bounds__(256) void ones
     for (int v = 0; v < V; ++v) st<NTS>(dst + base + v * 256, r[v]);
 }
 
+// an empty kernel in the same grid: what a dependent launch costs by itself (the floor under any tiny tensor)
+__global__ __launch_bounds__(256) void nothing(const u32x4 *, u32x4 *, size_t, unsigned *) {}
+void run_nothing(const u32x4 *s, u32x4 *d, size_t nvec, unsigned *sink, int bpc, hipStream_t st_) {
+    hipLaunchKernelGGL(nothing, dim3(bpc), dim3(256), 0, st_, s, d, nvec, sink);
+}
+
 struct Case { const char *name; void (*launch)(const u32x4 *, u32x4 *, size_t, unsigned *, int, hipStream_t); int bytes_factor; };
 
 template <int U, bool NTL, bool NTS, int OP> void run_persistent(const u32x4 *s, u32x4 *d, size_t nvec, unsigned *sink, int bpc, hipStream_t st_) {
@@ -90,6 +96,8 @@ int main(int argc, char **argv) {
     struct Row { const char *name; void (*fn)(const u32x4 *, u32x4 *, size_t, unsigned *, int, hipStream_t); int bpc; double traffic; };
     const double both = 2.0 * bytes, one = 1.0 * bytes;
     std::vector<Row> rows = {
+        {"empty kernel, 512 blocks (time only)", run_nothing, 512, both},
+        {"empty kernel, 2048 blocks (time only)", run_nothing, 2048, both},
         {"persistent U1 8blk/CU copy", run_persistent<1, false, false, 0>, 8, both},
         {"persistent U1 8blk/CU copy nt-store", run_persistent<1, false, true, 0>, 8, both},
         {"persistent U1 8blk/CU copy nt-load nt-store", run_persistent<1, true, true, 0>, 8, both},

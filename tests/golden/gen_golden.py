@@ -221,6 +221,35 @@ def gen_fullsize(tables):
     (OUT / 'fullsize_digests.json').write_text(json.dumps(doc, indent=1, sort_keys=True) + '\n')
 
 
+def gen_c4(tables):
+    """BASELINE config 4 in full: the reference on each of the 4 WHOLE 16384x4096 bf16 tensors; committed are the SHA-256
+    digests of the 8 shards' slices (x, gy, packed state, gx) -- tests/golden/c4_digests.json.  tests/test_gpu_multi.py
+    regenerates the inputs (tests/helpers.py:c4_tensor_inputs), runs shard r on device r and compares digests."""
+    sys.path.insert(0, str(ROOT / 'tests'))
+    sys.path.insert(0, str(ROOT))
+    from helpers import C4_BITS, C4_COLS, C4_ROWS, C4_TENSORS, c4_shard, c4_tensor_inputs, sha256_of
+    torch.ops.load_library(str(ROOT / 'oracle/_ref/libfewbit_ref.so'))
+    doc = {'recipe': 'tests/helpers.py:c4_tensor_inputs / c4_shard; state and gx from torch.ops.fewbit.quantize / quantize_backward of '
+                     'oracle/_ref/libfewbit_ref.so (the reference compiled as is) run on each WHOLE tensor, then sliced at the '
+                     'shard offsets of fewbit_amd.sharding; sha256 over the raw little-endian bytes',
+           'config': f'{C4_TENSORS} x ({C4_ROWS}x{C4_COLS}) bf16, gelu {C4_BITS} bits, 8 shards: tensor t half h -> GPU 2t+h',
+           'torch': torch.__version__, 'tensors': {}, 'shards': {}}
+    for t in range(C4_TENSORS):
+        x, gy, b, l = c4_tensor_inputs(t, tables)
+        _, state = torch.ops.fewbit.quantize(x, b)
+        gx = torch.ops.fewbit.quantize_backward(gy, state, l)
+        doc['tensors'][str(t)] = {'x': sha256_of(x), 'gy': sha256_of(gy), 'state': sha256_of(state), 'gx': sha256_of(gx)}
+        for h in range(2):
+            r = 2 * t + h
+            tt, (e0, e1), (s0, s1) = c4_shard(r)
+            assert tt == t
+            doc['shards'][str(r)] = {'tensor': t, 'elements': [e0, e1], 'state_bytes': [s0, s1], 'x': sha256_of(x[e0:e1]),
+                                     'gy': sha256_of(gy[e0:e1]), 'state': sha256_of(state[s0:s1]), 'gx': sha256_of(gx[e0:e1]),
+                                     'state_byte_sum': int(state[s0:s1].sum(dtype=torch.int64))}
+            print('shard', r, doc['shards'][str(r)]['state'][:16], doc['shards'][str(r)]['gx'][:16])
+    (OUT / 'c4_digests.json').write_text(json.dumps(doc, indent=1, sort_keys=True) + '\n')
+
+
 def main():
     assert REF.exists(), 'the reference tree is only present in the build container'
     with np.load(REF / 'fewbit/data/builtin.npz') as z:
@@ -228,10 +257,14 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'fullsize':
         gen_fullsize(tables)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'c4':
+        gen_c4(tables)
+        return
     gen_quantize(tables)
     gen_codec()
     gen_api(tables)
     gen_fullsize(tables)
+    gen_c4(tables)
 
 
 if __name__ == '__main__':

@@ -128,6 +128,43 @@ def full_size_inputs(case: str, tables: dict):
     return x, gy, borders, levels
 
 
+# ---- BASELINE config 4 in full: 4 tensors of 16384x4096 bf16, each cut in two halves -> 8 shards, tensor t half h on GPU 2t+h
+# (SURVEY 8(e)).  The reference runs on each WHOLE tensor (tests/golden/gen_golden.py c4); a shard's expected state / gx is the
+# slice of that run at the shard's offsets, which is exactly the claim "sharding == slicing the unsharded result".
+C4_TENSORS, C4_ROWS, C4_COLS, C4_BITS = 4, 16384, 4096, 3
+
+
+def c4_tensor_inputs(t: int, tables: dict):
+    """(x, gy, inner borders, levels) of whole tensor `t` of config 4: seeded host randn, the special values spliced in at
+    both ends AND on both sides of the cut between its two shards."""
+    dtype = torch.bfloat16
+    borders = torch.tensor(tables['gelu03-borders']).to(dtype)[1:-1].contiguous()
+    levels = torch.tensor(tables['gelu03-levels']).to(dtype)
+    n = C4_ROWS * C4_COLS
+    x = torch.randn(n, generator=torch.Generator().manual_seed(400 + t)).to(dtype)
+    gy = torch.randn(n, generator=torch.Generator().manual_seed(500 + t)).to(dtype)
+    sp = border_specials(borders, dtype)
+    x[:sp.numel()] = sp
+    x[-sp.numel():] = sp
+    x[n // 2 - sp.numel():n // 2] = sp
+    x[n // 2:n // 2 + sp.numel()] = sp
+    return x, gy, borders, levels
+
+
+def c4_shard(rank: int):
+    """(tensor index, element range, state byte range) of GPU `rank`'s shard of config 4"""
+    # (sharding.py loaded by path, not through the package: tests/golden/gen_golden.py calls this with the REFERENCE's
+    # operator library loaded, which registers the same torch.ops namespace as the package's own)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_fewbit_sharding', ROOT / 'fewbit_amd' / 'sharding.py')
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    shard_range, state_range = sharding.shard_range, sharding.state_range
+    t, h = divmod(rank, 2)
+    begin, end = shard_range(C4_ROWS * C4_COLS, 2, h)
+    return t, (begin, end), state_range(begin, end, C4_BITS)
+
+
 def sha256_of(t: torch.Tensor) -> str:
     import hashlib
     t = t.detach().cpu().contiguous()

@@ -192,6 +192,103 @@ def test_view_inputs_run_out_of_place_and_match():
     assert torch.equal(r.grad.view(4, 256), (v > 0).float())
 
 
+def _graph_nodes(fn):
+    seen, stack, names = set(), [fn], []
+    while stack:
+        f = stack.pop()
+        if f is None or f in seen:
+            continue
+        seen.add(f)
+        names.append(type(f).__name__)
+        stack += [n for n, _ in f.next_functions]
+    return names
+
+
+def test_raw_operator_in_place_on_a_linear_output_view():
+    """The reference's own caller route (benchmark/bench-roberta.py:138-147): the RAW operator, in place, on the 3-D output
+    of nn.Linear -- a view of its 2-D addmm result.  The operator marks the view's BASE dirty (torch_ops.cpp,
+    whole_view_base), so autograd builds no CopySlices node; values, gradients and the saved bytes equal the 2-D route's."""
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 256).to(DEV)
+    x = torch.randn(8, 16, 64, device=DEV)
+    inner, levels = fewbit.functional.store.get_inner('gelu', 3, torch.device(DEV), torch.float32)
+    for op_name, args in (('gelu', (inner, levels)), ('relu', ()), ('leaky_relu', (0.1,))):
+        op = getattr(torch.ops.fewbit, op_name)
+        lin.zero_grad(set_to_none=True)
+        h = lin(x)
+        assert h._is_view()
+        want_ptr = h.data_ptr()
+        with fewbit.memory_usage_hooks() as usage:
+            out = op(h, *args)
+            assert out.data_ptr() == want_ptr and out.shape == h.shape           # in place, the same tensor comes back
+            loss = (out * out).sum()                                             # (saves `out` once more: counted below)
+        nodes = _graph_nodes(out.grad_fn)
+        assert 'CopySlices' not in nodes, nodes
+        loss.backward()
+        g_view, gb_view = lin.weight.grad.clone(), lin.bias.grad.clone()
+        saved_view = usage.forward
+        # the 2-D route: plain tensor, plain in-place
+        lin.zero_grad(set_to_none=True)
+        h2 = lin(x.view(-1, 64))
+        assert not h2._is_view()
+        with fewbit.memory_usage_hooks() as usage2:
+            out2 = op(h2, *args)
+            loss2 = (out2 * out2).sum()
+        loss2.backward()
+        assert torch.equal(out.view(-1, 256), out2), op_name
+        assert torch.equal(g_view, lin.weight.grad) and torch.equal(gb_view, lin.bias.grad), op_name
+        assert saved_view == usage2.forward, (op_name, saved_view, usage2.forward)
+
+
+def test_in_place_on_a_view_keeps_in_place_semantics_for_later_users():
+    """After `op(v)` (in place) every alias of the memory -- the view `v`, its base, another view of the base -- holds the
+    activation values AND carries the operator in its history, exactly as with any in-place op."""
+    inner, levels = fewbit.functional.store.get_inner('silu', 4, torch.device(DEV), torch.float32)
+    r = torch.randn(6, 40, device=DEV, requires_grad=True)
+
+    def run(route):
+        r.grad = None
+        base = r * 1.0                                   # non-leaf 2-D tensor
+        v = base.view(6, 5, 8)
+        if route == 'view':
+            out = torch.ops.fewbit.silu(v, inner, levels)
+            assert out.data_ptr() == base.data_ptr()
+        else:                                            # reference point: in place on the base itself
+            torch.ops.fewbit.silu(base, inner, levels)
+        # users of the aliases AFTER the op: the old view, the base, a fresh view
+        total = (v * 2.0).sum() + (base * 3.0).sum() + (base.view(-1)[::2] * 5.0).sum()
+        total.backward()
+        return base.detach().clone(), r.grad.clone()
+
+    y_view, g_view = run('view')
+    y_base, g_base = run('base')
+    assert torch.equal(y_view, y_base) and torch.equal(g_view, g_base)
+    assert torch.allclose(y_view, F.silu(r.detach()), rtol=1e-5, atol=1e-6)
+    code = torch.searchsorted(inner, r.detach().flatten()).view(6, 40)
+    w = torch.full((6, 40), 5.0, device=DEV)
+    w.view(-1)[1::2] = 0.0
+    assert torch.allclose(g_view, levels[code] * (w + 5.0))
+
+
+def test_partial_views_take_the_general_route_and_stay_correct():
+    """A view that does not cover its whole base (a slice) cannot use the base shortcut: autograd's own in-place-on-view
+    machinery (CopySlices) runs, and the result must still be right."""
+    inner, levels = fewbit.functional.store.get_inner('gelu', 2, torch.device(DEV), torch.float32)
+    r = torch.randn(8, 512, device=DEV, requires_grad=True)
+    base = r * 1.0
+    v = base[2:6]                                        # contiguous slice: rows 2..5
+    assert v._is_view() and v.is_contiguous()
+    out = torch.ops.fewbit.gelu(v, inner, levels)
+    assert out.data_ptr() == v.data_ptr()
+    assert 'CopySlices' in _graph_nodes(base.grad_fn)
+    (base * 1.0).sum().backward()
+    code = torch.searchsorted(inner, r.detach()[2:6].flatten()).view(4, 512)
+    want = torch.ones(8, 512, device=DEV)
+    want[2:6] = levels[code]
+    assert torch.equal(r.grad, want)
+    assert torch.equal(base.detach()[:2], r.detach()[:2]) and torch.equal(base.detach()[6:], r.detach()[6:])
+
+
 def test_hip_graph_capture_and_replay():
     """The launches never synchronise or touch the host, so a whole forward+backward (operator level, autograd
     included) can be captured into a hipGraph once and replayed on new data: the replay must give the oracle's

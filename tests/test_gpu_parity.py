@@ -11,7 +11,7 @@ import oracle
 from fewbit_amd import cabi
 from fewbit_amd.sharding import shard_range, state_range
 from fewbit_amd.store import store
-from helpers import (DTYPES, FULL_SIZE_CASES, GOLDEN, ROOT, assert_bit_equal, forward_value_ok, from_raw, full_size_inputs,
+from helpers import (DTYPES, FULL_SIZE_CASES, GOLDEN, ROOT, assert_bit_equal, bits, forward_value_ok, from_raw, full_size_inputs,
                      load_tables, sha256_of, ulp_distance)
 
 pytestmark = pytest.mark.gpu
@@ -669,3 +669,60 @@ def test_folded_key_every_fp32_pattern():
             assert torch.equal(cabi.unpack_codes(st, chunk, 3), want), (shift, c)
             assert torch.equal(y.view(torch.int32), bits)
             del bits, x, y, st, key, want
+
+
+def test_every_launch_shape_and_tile_width_gives_the_same_bytes():
+    """fewbit_hip_tune (groups per lane per stage, resident blocks per CU, resident / chunked shape, in-place store
+    flavour) only changes HOW the tensor is swept; state, y and gx must not change by a bit.  Sizes around several tiles
+    and a ragged tail; bf16 (pattern-table and search forward, backward U = 1, 2, 4), fp32 (search forward U = 1, 2) and
+    the 1-bit family."""
+    import json
+    keys = ('waves_per_cu', 'chunk', 'lut_chunk', 'lut_blocks_per_cu', 'lut_min', 'u_fwd', 'u_bwd', 'u_lut', 'u_step1', 'nt_inplace')
+    try:
+        for dt, n in (('bf16', 64 * 8 * 4 * 37 + 13), ('f32', 64 * 8 * 4 * 19 + 5), ('bf16', 7 * 1024 * 1024 + 3)):
+            dtype = DTYPES[dt]
+            tables = load_tables()
+            borders = torch.tensor(tables['gelu03-borders']).to(dtype)[1:-1].contiguous().to(DEV)
+            levels = torch.tensor(tables['gelu03-levels']).to(dtype).to(DEV)
+            g = torch.Generator().manual_seed(n)
+            x = (torch.randn(n, generator=g) * 1.5).to(dtype).to(DEV)
+            gy = torch.randn(n, generator=g).to(dtype).to(DEV)
+            cabi.tune(**{k: -1 for k in keys})
+            y0, s0 = cabi.quantize_forward('gelu', x, borders)
+            gx0 = cabi.quantize_backward(gy, s0, levels)
+            r0, rs0 = cabi.stepwise1_forward('leaky_relu', x, 0.1)
+            rg0 = cabi.stepwise1_backward('leaky_relu', gy, rs0, 0.1)
+            seen = set()
+            for u in (1, 2, 4):
+                for wpc, chunk in ((-1, -1), (8, 0), (16, 1), (32, 3)):
+                    for lut_min in (0, 1 << 60):
+                        cabi.tune(u_fwd=u, u_bwd=u, u_lut=u, u_step1=u, waves_per_cu=wpc, chunk=chunk, lut_chunk=chunk, lut_min=lut_min)
+                        seen.add(json.dumps(cabi.describe_backward(dtype, n, 8), sort_keys=True))
+                        y, s = cabi.quantize_forward('gelu', x, borders)
+                        gx = cabi.quantize_backward(gy, s, levels)
+                        assert torch.equal(s, s0) and torch.equal(bits(y), bits(y0)) and torch.equal(bits(gx), bits(gx0)), (dt, n, u, wpc, chunk, lut_min)
+                        r, rs = cabi.stepwise1_forward('leaky_relu', x, 0.1)
+                        rg = cabi.stepwise1_backward('leaky_relu', gy, rs, 0.1)
+                        assert torch.equal(rs, rs0) and torch.equal(bits(r), bits(r0)) and torch.equal(bits(rg), bits(rg0))
+            assert len(seen) >= 6                          # the settings really did change the launch
+            for nt in (0, 1):                              # in place: plain (policy) and nontemporal output stores
+                cabi.tune(**{k: -1 for k in keys})
+                cabi.tune(nt_inplace=nt)
+                xi, gi = x.clone(), gy.clone()
+                yi, si = cabi.quantize_forward('gelu', xi, borders, out=xi)
+                gxi = cabi.quantize_backward(gi, si, levels, out=gi)
+                assert yi.data_ptr() == xi.data_ptr() and torch.equal(si, s0) and torch.equal(bits(yi), bits(y0)) and torch.equal(bits(gxi), bits(gx0))
+    finally:
+        cabi.tune(**{k: -1 for k in keys})
+
+
+def test_describe_names_the_kernel_the_dispatch_takes():
+    n2, n4 = 4096 * 4096, 8192 * 4096
+    d = cabi.describe_forward('gelu', torch.bfloat16, n2, 7)
+    assert d['kernel'].startswith('quantize_forward_lut_kernel<gelu, bf16, 3 bits') and d['threads'] == 1024 and d['blocks'] == 2 * 256
+    assert cabi.describe_forward('gelu', torch.bfloat16, 1 << 20, 7)['kernel'].startswith('quantize_forward_kernel<gelu, bf16')
+    assert cabi.describe_forward('gelu', torch.float32, n2, 7)['kernel'].startswith('quantize_forward_kernel<gelu, f32')
+    assert cabi.describe_forward('silu', torch.float16, n2, 200)['kernel'].startswith('quantize_forward_lut_wide_kernel')
+    b2, b4 = cabi.describe_backward(torch.bfloat16, n2, 8), cabi.describe_backward(torch.bfloat16, n4, 8)
+    assert b2['u'] == 2 and b2['chunk'] == 0 and b4['u'] == 1 and b4['chunk'] == 1      # the measured policy, DESIGN.md section 3
+    assert cabi.describe_stepwise1_forward('relu', torch.float32, 1 << 20)['kernel'].startswith('stepwise1_forward_kernel<relu, f32')

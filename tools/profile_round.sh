@@ -8,10 +8,11 @@
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE  bench.py --no-extras --steps 50   -> HBM traffic per launch (C2)
 #   4. rocprofv3 --kernel-trace / --pmc FETCH_SIZE / --pmc WRITE_SIZE   tools/config_runs.py
 #      -> per-dispatch durations and traffic of EVERY config, warm and cold (split by tools/summarize_profiles.py)
-#   5. bench.py --config c4 / --steps 20 / 2 gloo ranks on the one GPU, stream micro-benchmark, host cost per call,
-#      clock-transient timeline, the fp32 ULP histogram written by the GPU test-suite
+#   5. bench.py --config c4 / --steps 20 / 2 ranks on the one GPU (self-launched and under torch.distributed.run), stream
+#      micro-benchmark, host cost per call, clock-transient timeline, the fp32 ULP histogram written by the GPU test-suite
+#   6. RoBERTa-base step (both routes) and the rocprofv3 kernel stats of the few-bit kernels inside it
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
 export TMPDIR=/tmp
@@ -29,11 +30,26 @@ python3 tools/summarize_profiles.py "$R" "$RAW" "$OUT"
 # 5. the other driver-visible lines and the side measurements DESIGN.md quotes
 python3 bench.py --config c4 --no-cpu-baseline > "$OUT/${R}_bench_line_c4.json" 2>> "$RAW/bench.err"
 python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$OUT/${R}_bench_line_k20.json" 2>> "$RAW/bench.err"
-FEWBIT_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 \
-    bench.py --gpus 2 --steps 200 --warmup 10 2>> "$RAW/bench.err" | tail -1 > "$OUT/${R}_bench_line_2ranks_gloo_one_gpu.json"
+# N > 1 on the one GPU of this box (ranks SHARE it: validation of the launch paths, not a scaling point): bench.py starting
+# its own children, and the driver's torch.distributed.run form (gloo process group for the barrier and the max only)
+python3 bench.py --gpus 2 --steps 20 --warmup 5 > "$OUT/${R}_bench_line_2ranks_selflaunch_one_gpu.json" 2>> "$RAW/bench.err"
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 \
+    bench.py --gpus 2 --steps 200 --warmup 10 2>> "$RAW/bench.err" | tail -1 > "$OUT/${R}_bench_line_2ranks_torchrun_one_gpu.json"
+# 6. BASELINE config 5: RoBERTa-base step, module route and the reference's raw-operator route, and the few-bit kernels' own
+#    durations INSIDE that step (rocprofv3 kernel trace; fp32 and bf16, both routes)
+for dt in fp32 bf16; do
+    python3 tools/roberta_bench.py --dtype $dt --route both 2>> "$RAW/roberta.err" | tail -1 > "$OUT/${R}_roberta_base_$dt.json"
+    for route in fewbit op; do
+        timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/insitu_${dt}_${route}" -o rob -- \
+            python3 tools/roberta_bench.py --dtype $dt --only $route --steps 6 > /dev/null 2>> "$RAW/roberta.err"
+        find "$RAW/insitu_${dt}_${route}" -name "*kernel_trace.csv" -delete
+    done
+done
+python3 tools/summarize_profiles.py "$R" "$RAW" "$OUT" insitu > "$RAW/insitu.log" 2>&1
 if [ -x scratch/stream_bench ]; then
     scratch/stream_bench 32 > "$OUT/${R}_stream_bench_32MiB.txt" 2>&1
     scratch/stream_bench 128 > "$OUT/${R}_stream_bench_128MiB.txt" 2>&1
+    scratch/stream_bench 4 > "$OUT/${R}_stream_bench_4MiB.txt" 2>&1
 fi
 python3 scratch/hostcost.py > "$RAW/hostcost.log" 2>&1 && cp gpurun_out/hostcost.json "$OUT/${R}_hostcost.json"
 python3 scratch/timeline.py 0.0 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_clock_transient_timeline.txt"

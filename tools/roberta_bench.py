@@ -3,9 +3,14 @@
 peak memory and step time against the vanilla model.  Random-init weights of the roberta-base architecture
 (`RobertaConfig()` defaults: 768 / 12 layers / 12 heads / 3072; no network access), synthetic token ids.
 
-The reference's benchmark patches `transformers.activations.ACT2FN['gelu']` with `torch.ops.fewbit.gelu`
-(benchmark/bench-roberta.py:123-149); here the 12 `intermediate_act_fn` modules are swapped with `fewbit.map_module`.
-    python tools/roberta_bench.py [--dtype fp32|bf16] [--steps 10] [--bits 3]
+Two routes to the same kernels:
+  --route module (default)  the 12 `intermediate_act_fn` modules are swapped for `fewbit.GELU(bits=k)` with `fewbit.map_module`;
+  --route op                the REFERENCE'S OWN caller route: `intermediate_act_fn = lambda xs: torch.ops.fewbit.gelu(xs, bounds,
+                            levels)` -- the raw operator with the literal 3-bit tables of benchmark/bench-roberta.py:128-137,
+                            in place on the 3-D output of nn.Linear (a view of its 2-D addmm result), which is what the
+                            reference's monkey patch of `transformers.activations.ACT2FN['gelu']` amounts to (:139-147);
+  --route both              module and op side by side (adds `op` and `op_vs_module` to the line).
+    python tools/roberta_bench.py [--dtype fp32|bf16] [--steps 10] [--bits 3] [--route module|op|both]
 Prints one JSON line.
 """
 import argparse
@@ -42,6 +47,28 @@ def swap_gelu(model, bits):
 
     fewbit.map_module(model, fn)
     return n[0]
+
+
+# the literal tables of the reference's benchmark (benchmark/bench-roberta.py:128-137): 7 inner borders, 8 levels
+REF_BOUNDS = (-2.39798704e+00, -7.11248159e-01, -3.26290283e-01, -1.55338428e-04, 3.26182064e-01, 7.10855860e-01, 2.39811567e+00)
+REF_LEVELS = (-0.00260009, -0.08883533, 0.1251944, 0.37204148, 0.6277958, 0.87466175, 1.08880716, 1.00259936)
+
+
+def patch_gelu_with_raw_op(model, dtype, device):
+    """The reference's caller route: every intermediate activation becomes a plain function around the raw operator."""
+    bounds = torch.tensor(REF_BOUNDS, device=device).to(dtype)
+    levels = torch.tensor(REF_LEVELS, device=device).to(dtype)
+
+    def gelu3bit(xs):
+        return torch.ops.fewbit.gelu(xs, bounds, levels)
+
+    n = 0
+    for layer in model.roberta.encoder.layer:
+        if 'intermediate_act_fn' in layer.intermediate._modules:       # registered as a sub-module: unregister first
+            del layer.intermediate.intermediate_act_fn
+        layer.intermediate.intermediate_act_fn = gelu3bit
+        n += 1
+    return n
 
 
 def swap_linear(model, ratio, sketch_dtype=None):
@@ -95,7 +122,8 @@ def main():
     ap.add_argument('--bits', type=int, default=3)
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--seq', type=int, default=128)
-    ap.add_argument('--only', default=None, choices=(None, 'vanilla', 'fewbit'), help='run a single variant (profiling)')
+    ap.add_argument('--only', default=None, choices=(None, 'vanilla', 'fewbit', 'op'), help='run a single variant (profiling)')
+    ap.add_argument('--route', default='module', choices=('module', 'op', 'both'), help='see the module docstring')
     ap.add_argument('--table', action='store_true',
                     help="the four rows of the reference README's table: GELU {vanilla, 3-bit} x linear {vanilla, randomized}")
     ap.add_argument('--linear-ratio', type=float, default=0.2, help='proj_dim_ratio of the randomized linear layers')
@@ -129,11 +157,17 @@ def main():
         return
 
     res = {}
-    for name in ('vanilla', 'fewbit'):
+    names = ('vanilla', 'fewbit') + (('op', ) if args.route in ('op', 'both') or args.only == 'op' else ())
+    for name in names:
         if args.only and name != args.only:
             continue
+        if args.route == 'op' and name == 'fewbit' and not args.only:
+            continue
         model = build(dtype, dev)
-        swapped = swap_gelu(model, args.bits) if name == 'fewbit' else 0
+        if name == 'op':
+            swapped = patch_gelu_with_raw_op(model, dtype, dev)
+        else:
+            swapped = swap_gelu(model, args.bits) if name == 'fewbit' else 0
         res[name] = run(model, ids, labels, args.steps)
         res[name]['gelu_modules_swapped'] = swapped
         del model
@@ -145,11 +179,25 @@ def main():
     n_act = 12 * args.batch * args.seq * 3072
     expect = n_act * es - (args.bits * n_act) // 8
     out = {'config': f'RoBERTa-base (random init) batch {args.batch} x seq {args.seq}, {args.dtype}, fwd+bwd+SGD step',
-           'bits': args.bits, 'vanilla': res['vanilla'], 'fewbit': res['fewbit'],
-           'peak_saving_bytes': res['vanilla']['peak_bytes'] - res['fewbit']['peak_bytes'],
-           'saved_tensor_saving_bytes': res['vanilla']['saved_for_backward_bytes'] - res['fewbit']['saved_for_backward_bytes'],
-           'expected_saved_tensor_saving_bytes': expect,
-           'step_time_ratio': res['fewbit']['ms_per_step'] / res['vanilla']['ms_per_step']}
+           'bits': args.bits, 'vanilla': res['vanilla'], 'expected_saved_tensor_saving_bytes': expect}
+    for key in ('fewbit', 'op'):
+        if key not in res:
+            continue
+        out[key] = res[key]
+        out[key + '_summary' if key == 'op' else 'summary'] = {
+            'route': 'fewbit.GELU module (map_module)' if key == 'fewbit' else
+                     'raw torch.ops.fewbit.gelu with the reference benchmark\'s literal tables, in place on the Linear output',
+            'peak_saving_bytes': res['vanilla']['peak_bytes'] - res[key]['peak_bytes'],
+            'saved_tensor_saving_bytes': res['vanilla']['saved_for_backward_bytes'] - res[key]['saved_for_backward_bytes'],
+            'step_time_ratio': res[key]['ms_per_step'] / res['vanilla']['ms_per_step']}
+    if 'fewbit' in res:       # (kept at top level: what earlier rounds' profiles/ files hold)
+        out['peak_saving_bytes'] = out['summary']['peak_saving_bytes']
+        out['saved_tensor_saving_bytes'] = out['summary']['saved_tensor_saving_bytes']
+        out['step_time_ratio'] = out['summary']['step_time_ratio']
+    if 'fewbit' in res and 'op' in res:
+        out['op_vs_module'] = {'step_time_ratio': res['op']['ms_per_step'] / res['fewbit']['ms_per_step'],
+                               'saved_bytes_difference': res['op']['saved_for_backward_bytes'] - res['fewbit']['saved_for_backward_bytes'],
+                               'peak_bytes_difference': res['op']['peak_bytes'] - res['fewbit']['peak_bytes']}
     print(json.dumps(out))
 
 

@@ -123,9 +123,44 @@ def configs(rnd, raw, out):
     return doc
 
 
+def insitu(rnd, raw, out):
+    """The few-bit kernels INSIDE a training step (tools/roberta_bench.py under rocprofv3 --kernel-trace --stats): x is fresh
+    from the GEMM that produced it, gy from the GEMM's backward -- neither the cache-warm nor the cache-cold loop of bench.py.
+    Activations of RoBERTa-base at batch 128 x seq 128: 16384 x 3072 elements per layer, 3 bits."""
+    n = 16384 * 3072
+    doc = {'round': int(rnd.lstrip('r')), 'elements_per_launch': n, 'peak_GBps': HBM_PEAK,
+           'command': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/roberta_bench.py --dtype <dt> --only fewbit|op '
+                      '--steps 6 (tools/profile_round.sh); every dispatch of the run, warm-up steps included', 'runs': {}}
+    for sub in sorted(glob.glob(os.path.join(raw, 'insitu_*'))):
+        tag = os.path.basename(sub)[len('insitu_'):]
+        es = 4 if 'fp32' in tag else 2
+        nbytes = n * (2 * es + 3 / 8)
+        try:
+            stats = find(raw, os.path.basename(sub), '*kernel_stats.csv')
+        except SystemExit:
+            continue
+        shutil.copy(stats, os.path.join(out, f'{rnd}_roberta_kernel_stats_{tag}.csv'))
+        rows = {}
+        with open(stats, newline='') as f:
+            for row in csv.DictReader(f):
+                if 'fewbit_hip::' in row['Name']:
+                    avg = float(row['AverageNs'])
+                    rows[short(row['Name'])] = {'calls': int(row['Calls']), 'avg_us': round(avg / 1e3, 2), 'min_us': round(float(row['MinNs']) / 1e3, 2),
+                                                'max_us': round(float(row['MaxNs']) / 1e3, 2), 'pct_of_gpu_time': float(row['Percentage']),
+                                                'algorithmic_bytes_per_launch': int(nbytes), 'GBps': round(nbytes / avg, 1),
+                                                'frac_of_peak': round(nbytes / avg / HBM_PEAK, 4)}
+        doc['runs'][tag] = rows
+    if doc['runs']:
+        json.dump(doc, open(os.path.join(out, f'{rnd}_roberta_insitu.json'), 'w'), indent=1)
+    return doc
+
+
 def main():
     rnd, raw, out = sys.argv[1:4]
     os.makedirs(out, exist_ok=True)
+    if len(sys.argv) > 4 and sys.argv[4] == 'insitu':
+        print(json.dumps(insitu(rnd, raw, out)['runs'], indent=1))
+        return
     shutil.copy(find(raw, 'trace', '*kernel_stats.csv'), os.path.join(out, f'{rnd}_bench_kernel_stats.csv'))
     print(json.dumps(c2_traffic(rnd, raw, out), indent=1))
     doc = configs(rnd, raw, out)
