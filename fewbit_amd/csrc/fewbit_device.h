@@ -100,21 +100,6 @@ template <bool NT, int A, typename T> __device__ __forceinline__ void store_as(v
     if constexpr (NT) __builtin_nontemporal_store(v, q);
     else *q = v;
 }
-// nontemporal or plain by a WAVE-UNIFORM run-time flag (the kernels pass "the output does not alias the input"): a
-// nontemporal store to a line the same kernel has just read -- the in-place mode of the reference operator -- is 7-15 %
-// slower than a plain one on MI355X (profiles/r03_inplace_stores.txt); out of place it is the other way round.  Both
-// branches hold exactly one store instruction, so the s_waitcnt counting of the software pipeline is unaffected.
-// (The empty asm statements keep LLVM from merging the two stores back into one: the stores differ only in their
-// !nontemporal metadata, which SimplifyCFG's hoist/sink of "identical" instructions ignores -- and then drops.)
-template <int A, typename T> __device__ __forceinline__ void store_sel_as(bool nt, void *p, T v) {
-    if (nt) {
-        asm volatile("");
-        store_as<true, A>(p, v);
-    } else {
-        store_as<false, A>(p, v);
-        asm volatile("");
-    }
-}
 
 template <> struct GroupIO<FEWBIT_F32> {
     struct Raw { f32x4 a, b; };
@@ -132,19 +117,6 @@ template <> struct GroupIO<FEWBIT_F32> {
         f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
         store_as<NT, 4>(p, a);
         store_as<NT, 4>(p + 4, b);
-    }
-    static __device__ __forceinline__ void store_sel(bool nt, void *base, size_t g, const float (&v)[8]) {
-        float *p = static_cast<float *>(base) + 8 * g;
-        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-        if (nt) {
-            asm volatile("");
-            store_as<true, 4>(p, a);
-            store_as<true, 4>(p + 4, b);
-        } else {
-            store_as<false, 4>(p, a);
-            store_as<false, 4>(p + 4, b);
-            asm volatile("");
-        }
     }
 };
 
@@ -170,15 +142,6 @@ template <> struct GroupIO<FEWBIT_BF16> {
         }
         store_as<NT, 2>(static_cast<uint16_t *>(base) + 8 * g, w);
     }
-    static __device__ __forceinline__ void store_sel(bool nt, void *base, size_t g, const float (&v)[8]) {
-        u32x4 w;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x2 f = {v[2 * i], v[2 * i + 1]};
-            w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
-        }
-        store_sel_as<2>(nt, static_cast<uint16_t *>(base) + 8 * g, w);
-    }
 };
 
 template <> struct GroupIO<FEWBIT_F16> {
@@ -202,15 +165,6 @@ template <> struct GroupIO<FEWBIT_F16> {
             w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));  // v_cvt_pk_f16_f32, RNE
         }
         store_as<NT, 2>(static_cast<uint16_t *>(base) + 8 * g, w);
-    }
-    static __device__ __forceinline__ void store_sel(bool nt, void *base, size_t g, const float (&v)[8]) {
-        u32x4 w;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x2 f = {v[2 * i], v[2 * i + 1]};
-            w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));
-        }
-        store_sel_as<2>(nt, static_cast<uint16_t *>(base) + 8 * g, w);
     }
 };
 
@@ -243,19 +197,6 @@ struct SplitF32 {
         f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
         store_as<NT, 4>(p, a);
         store_as<NT, 4>(p + 256, b);
-    }
-    static __device__ __forceinline__ void store_sel(bool nt, void *base, size_t g, int lane, const float (&v)[8]) {
-        float *p = static_cast<float *>(base) + 8 * (g - lane) + 4 * lane;
-        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-        if (nt) {
-            asm volatile("");
-            store_as<true, 4>(p, a);
-            store_as<true, 4>(p + 256, b);
-        } else {
-            store_as<false, 4>(p, a);
-            store_as<false, 4>(p + 256, b);
-            asm volatile("");
-        }
     }
 };
 

@@ -117,9 +117,6 @@ __device__ unsigned long long g_trace[1 << 17];
 #define FEWBIT_STAMP(slot) do { } while (0)
 #endif
 
-// `flags` argument of the streaming kernels (wave-uniform)
-constexpr int kFlagStreamOut = 1;   // y / gx are written nontemporal: set unless the output aliases the input (in place)
-
 // Two-buffer software pipeline over the tiles of one wave: the loads of the next tile are issued
 // before the current tile is processed, and the two register buffers alternate (no copies), so the
 // only wait in front of process(tile i) is for loads issued a whole tile earlier.
@@ -217,14 +214,13 @@ template <int FN, int DT, int K, int U>
 __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) void quantize_forward_kernel(const void *x, void *y,
                                                                   uint8_t *__restrict__ state, size_t n,
                                                                   const void *__restrict__ borders, float p0,
-                                                                  float p1, int chunk, int flags) {
+                                                                  float p1, int chunk) {
     constexpr int NB = (1 << K) - 1;
     constexpr bool kFast = (DT != FEWBIT_F32);
     constexpr bool kSplit = (DT == FEWBIT_F32) && (FEWBIT_F32_SPLIT != 0);     // fp32: contiguous split tiles
     constexpr bool kStreamY = (DT != FEWBIT_F32) || kSplit;
     typedef typename GroupIO<DT>::Raw Raw;
     const Span s = make_span<U>(n, chunk);
-    const bool nt_out = (flags & kFlagStreamOut) != 0;
 
     float b[NB];
     const float mine = fetch_border<DT, NB>(borders);
@@ -279,9 +275,8 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) v
                 // instruction leaves holes that only L2 write-combining fills -- nontemporal there costs 4 us per pass.
                 // state: plain store -- it is what backward reads, and a backward that follows closely finds it
                 // cached (4096x4096 bf16 step 26.5 -> 25.6 us); when backward runs much later it makes no difference.
-                if constexpr (kSplit) SplitF32::store_sel(nt_out, y, g, s.lane, v);
-                else if constexpr (kStreamY) GroupIO<DT>::store_sel(nt_out, y, g, v);
-                else GroupIO<DT>::template store<false>(y, g, v);
+                if constexpr (kSplit) SplitF32::store<true>(y, g, s.lane, v);
+                else GroupIO<DT>::template store<kStreamY>(y, g, v);
                 store_state_quad<K, false>(state, g, s.lane, w);
             }
         });
@@ -333,7 +328,7 @@ template <int DT> __device__ __forceinline__ float value_of_pattern(uint32_t r) 
 template <int FN, int DT, int K, int U, int BLOCK = kLutBlock>
 __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize_forward_lut_kernel(const void *x, void *y, uint8_t *state,
                                                                             size_t n, const void *borders,
-                                                                            int nborders, float p0, float p1, int chunk, int flags) {
+                                                                            int nborders, float p0, float p1, int chunk) {
     constexpr int kLutBlock = BLOCK, kLutWaves = BLOCK / kWave;        // (shadow the file-level defaults)
     static_assert(DT != FEWBIT_F32, "the pattern table exists for 16-bit dtypes only");
     constexpr int NBMAX = (1 << K) - 1;
@@ -341,7 +336,6 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ __attribute__((aligned(16))) uint8_t lut[65536];
     const Span s = make_span<U, kLutWaves>(n, chunk);
-    const bool nt_out = (flags & kFlagStreamOut) != 0;
 
     // the table's global loads go out FIRST (lane j fetches border j, as a float and as a raw pattern): the build then
     // waits only for them, not for the first tile of x that pipeline2 issues right after
@@ -399,7 +393,7 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
     };
 
 #ifndef FEWBIT_ABLATE_LUT
-#define FEWBIT_ABLATE_LUT 0     // measurement builds only: 1 no activation, 2 no table lookup, 4 no table build, 8 no state store
+#define FEWBIT_ABLATE_LUT 0     // measurement builds only: 1 no activation, 2 no table lookup, 4 no table build, 8 no state store, 16 nontemporal state store
 #endif
     auto build_or_not = [&]() {
         if constexpr ((FEWBIT_ABLATE_LUT & 4) == 0) build();
@@ -431,8 +425,8 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
                     for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
                 }
                 const size_t g = (t * U + u) * kWave + s.lane;
-                GroupIO<DT>::store_sel(nt_out, y, g, v);
-                if constexpr ((FEWBIT_ABLATE_LUT & 8) == 0) store_state_quad<K, false>(state, g, s.lane, w);
+                GroupIO<DT>::template store<true>(y, g, v);
+                if constexpr ((FEWBIT_ABLATE_LUT & 8) == 0) store_state_quad<K, (FEWBIT_ABLATE_LUT & 16) != 0>(state, g, s.lane, w);
                 else if (w == 0x12345u) store_state_quad<K, false>(state, g, s.lane, w);
             }
         });
@@ -488,7 +482,7 @@ __device__ __forceinline__ void wide_forward_tail(const Span &s, const void *x, 
 template <int FN, int DT>
 __global__ __launch_bounds__(kBlock, 6) void quantize_forward_wide_kernel(const void *x, void *y, uint8_t *state, size_t n,
                                                                           const void *borders, int nborders, int nbits,
-                                                                          float p0, float p1, int chunk, int flags) {
+                                                                          float p0, float p1, int chunk) {
     constexpr bool kFast = (DT != FEWBIT_F32);
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ float sb[256];
@@ -522,8 +516,7 @@ __global__ __launch_bounds__(kBlock, 6) void quantize_forward_wide_kernel(const 
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
             const size_t g = t * kWave + s.lane;
-            if constexpr (kFast) GroupIO<DT>::store_sel((flags & kFlagStreamOut) != 0, y, g, v);
-            else GroupIO<DT>::template store<false>(y, g, v);
+            GroupIO<DT>::template store<kFast>(y, g, v);
             store_state_wide(state, g, nbits, w);
         });
     if (!s.tail_owner) return;
@@ -539,7 +532,7 @@ template <int FN, int DT>
 __global__ __launch_bounds__(kLutBlock, (lut_waves_per_simd<kLutBlock>())) void quantize_forward_lut_wide_kernel(const void *x, void *y,
                                                                                  uint8_t *state, size_t n,
                                                                                  const void *borders, int nborders,
-                                                                                 int nbits, float p0, float p1, int chunk, int flags) {
+                                                                                 int nbits, float p0, float p1, int chunk) {
     static_assert(DT != FEWBIT_F32, "the pattern table exists for 16-bit dtypes only");
     constexpr uint32_t kInf = (DT == FEWBIT_BF16) ? 0x7f80u : 0x7c00u;
     typedef typename GroupIO<DT>::Raw Raw;
@@ -610,7 +603,7 @@ __global__ __launch_bounds__(kLutBlock, (lut_waves_per_simd<kLutBlock>())) void 
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
             const size_t g = t * kWave + s.lane;
-            GroupIO<DT>::store_sel((flags & kFlagStreamOut) != 0, y, g, v);
+            GroupIO<DT>::template store<true>(y, g, v);
             store_state_wide(state, g, nbits, w);
         });
     if (!s.tail_owner) return;
@@ -622,7 +615,7 @@ __global__ __launch_bounds__(kLutBlock, (lut_waves_per_simd<kLutBlock>())) void 
 template <int DT>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_kernel(const void *gy, const uint8_t *state,
                                                                                   void *gx, size_t n, const void *levels,
-                                                                                  int nlevels, int nbits, int chunk, int flags) {
+                                                                                  int nlevels, int nbits, int chunk) {
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ float lut[256];
     const Span s = make_span<1>(n, chunk, 1);
@@ -647,8 +640,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void quantize_backward_wide_
                 v[i] = lut[(wlo >> (nbits * i)) & mask] * v[i];
                 v[4 + i] = lut[(whi >> (nbits * i)) & mask] * v[4 + i];
             }
-            if constexpr (DT != FEWBIT_F32) GroupIO<DT>::store_sel((flags & kFlagStreamOut) != 0, gx, t * kWave + s.lane, v);
-            else GroupIO<DT>::template store<false>(gx, t * kWave + s.lane, v);
+            GroupIO<DT>::template store<(DT != FEWBIT_F32)>(gx, t * kWave + s.lane, v);
         });
     if (!s.tail_owner) return;
     for (size_t g = s.tail_g0 + s.lane; g < s.ngroups; g += kWave) {
@@ -669,13 +661,12 @@ template <int DT, int K, int U>
 __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quantize_backward_kernel(const void *gy,
                                                                    const uint8_t *state, void *gx,
                                                                    size_t n, const void *__restrict__ levels,
-                                                                   int nlevels, int chunk, int flags) {
+                                                                   int nlevels, int chunk) {
     constexpr int NL = 1 << K;
     constexpr uint32_t kMask = NL - 1;
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ float lut[NL];
     const Span s = make_span<U>(n, chunk);
-    const bool nt_out = (flags & kFlagStreamOut) != 0;
 
     // the level fetch goes out before the first tiles: vmcnt counts in order, so waiting for it in init() does not
     // wait for the tiles as well
@@ -725,7 +716,7 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
                         v[i] = lut[(cA >> (K * i)) & kMask] * v[i];
                         v[4 + i] = lut[(cB >> (K * i)) & kMask] * v[4 + i];
                     }
-                    SplitF32::store_sel(nt_out, gx, (t * U + u) * kWave + s.lane, s.lane, v);
+                    SplitF32::store<true>(gx, (t * U + u) * kWave + s.lane, s.lane, v);
                     continue;
                 }
 #pragma unroll
@@ -734,8 +725,7 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
                 // be read out of L2 / Infinity Cache and is written back during the NEXT kernel (cache-cold backward at
                 // 4096x4096 bf16 15.3 -> 13.9 us, 2^26 elements forward+backward 100.6 -> 94.1 us; RoBERTa-base step
                 // unchanged).  fp32 in the split layout (above) stores whole lines and is nontemporal too.
-                if constexpr (DT != FEWBIT_F32 && (FEWBIT_ABLATE_BWD & 4) == 0) GroupIO<DT>::store_sel(nt_out, gx, (t * U + u) * kWave + s.lane, v);
-                else GroupIO<DT>::template store<false>(gx, (t * U + u) * kWave + s.lane, v);
+                GroupIO<DT>::template store<(DT != FEWBIT_F32) && (FEWBIT_ABLATE_BWD & 4) == 0>(gx, (t * U + u) * kWave + s.lane, v);
             }
         });
 
@@ -754,10 +744,9 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
 template <int FN, int DT, int U>
 __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void stepwise1_forward_kernel(const void *x, void *y,
                                                                    uint8_t *__restrict__ state, size_t n, float p0,
-                                                                   float p1, int chunk, int flags) {
+                                                                   float p1, int chunk) {
     typedef typename GroupIO<DT>::Raw Raw;
     const Span s = make_span<U>(n, chunk);
-    const bool nt_out = (flags & kFlagStreamOut) != 0;
     constexpr bool kSplit = (DT == FEWBIT_F32) && (FEWBIT_F32_SPLIT != 0);     // see SplitF32
     struct Buf { Raw r[U]; };
     pipeline2<Buf>(
@@ -789,11 +778,9 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void step
                 const size_t g = (t * U + u) * kWave + s.lane;
                 if constexpr (kSplit) {      // bits 0..3 / 4..7 of w belong to halves of two different groups
                     w = split_halves_to_word<1>(w & 15u, w >> 4, s.lane);
-                    SplitF32::store_sel(nt_out, y, g, s.lane, v);
-                } else if constexpr (DT != FEWBIT_F32) {
-                    GroupIO<DT>::store_sel(nt_out, y, g, v);
+                    SplitF32::store<true>(y, g, s.lane, v);
                 } else {
-                    GroupIO<DT>::template store<false>(y, g, v);
+                    GroupIO<DT>::template store<(DT != FEWBIT_F32)>(y, g, v);
                 }
                 store_state_quad<1, false>(state, g, s.lane, w);
             }
@@ -816,10 +803,9 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void step
 template <int DT, int U>
 __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void stepwise1_backward_kernel(const void *gy,
                                                                     const uint8_t *state, void *gx,
-                                                                    size_t n, float m0, float m1, int chunk, int flags) {
+                                                                    size_t n, float m0, float m1, int chunk) {
     typedef typename GroupIO<DT>::Raw Raw;
     const Span s = make_span<U>(n, chunk);
-    const bool nt_out = (flags & kFlagStreamOut) != 0;
     constexpr bool kSplit = (DT == FEWBIT_F32) && (FEWBIT_F32_SPLIT != 0);
     struct Buf { Raw r[U]; uint32_t w[U]; };
     pipeline2<Buf>(
@@ -850,9 +836,8 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void step
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = (((w >> i) & 1u) ? m1 : m0) * v[i];
-                if constexpr (kSplit) SplitF32::store_sel(nt_out, gx, (t * U + u) * kWave + s.lane, s.lane, v);
-                else if constexpr (DT != FEWBIT_F32) GroupIO<DT>::store_sel(nt_out, gx, (t * U + u) * kWave + s.lane, v);
-                else GroupIO<DT>::template store<false>(gx, (t * U + u) * kWave + s.lane, v);
+                if constexpr (kSplit) SplitF32::store<true>(gx, (t * U + u) * kWave + s.lane, s.lane, v);
+                else GroupIO<DT>::template store<(DT != FEWBIT_F32)>(gx, (t * U + u) * kWave + s.lane, v);
             }
         });
     if (!s.tail_owner) return;
@@ -967,7 +952,6 @@ enum TuneKey {
     T_LUT_MIN,             // smallest tensor (elements) that takes the pattern-table forward; 0 = always
     T_LUT_BLOCK,           // threads per pattern-table block (512 or 1024), where the build has both
     T_U_FWD, T_U_BWD, T_U_LUT, T_U_STEP1,     // groups per lane per pipeline stage (1, 2 or 4), where the build has them
-    T_NT_INPLACE,          // 1: nontemporal output stores even when the output aliases the input (A/B of the policy: plain)
     T_COUNT
 };
 struct TuneSpec { const char *key, *env; };
@@ -975,7 +959,6 @@ constexpr TuneSpec kTuneSpec[T_COUNT] = {
     {"waves_per_cu", "FEWBIT_HIP_WAVES_PER_CU"}, {"chunk", "FEWBIT_HIP_CHUNK"}, {"lut_chunk", "FEWBIT_HIP_LUT_CHUNK"},
     {"lut_blocks_per_cu", "FEWBIT_HIP_LUT_BLOCKS_PER_CU"}, {"lut_min", "FEWBIT_HIP_LUT_MIN"}, {"lut_block", "FEWBIT_HIP_LUT_BLOCK"},
     {"u_fwd", "FEWBIT_HIP_U_FWD"}, {"u_bwd", "FEWBIT_HIP_U_BWD"}, {"u_lut", "FEWBIT_HIP_U_LUT"}, {"u_step1", "FEWBIT_HIP_U_STEP1"},
-    {"nt_inplace", "FEWBIT_HIP_NT_INPLACE"},
 };
 std::atomic<long long> g_tune[T_COUNT];
 std::once_flag g_tune_once;
@@ -1095,7 +1078,7 @@ Shape launch_shape(size_t ntiles, int waves_per_block, size_t resident_blocks, l
 
 // launch (or, dry, only describe) a 256-thread streaming kernel instantiation; the kernels' last parameter is the chunk
 template <auto Kern, typename... Args>
-void launch_tiled(Plan *plan, bool dry, const Device &dev, size_t n, int U, int flags, hipStream_t s, Args... args) {
+void launch_tiled(Plan *plan, bool dry, const Device &dev, size_t n, int U, hipStream_t s, Args... args) {
     int per_cu = occupancy_blocks_per_cu<Kern>(dev, kBlock);
     if (per_cu > 8) per_cu = 8;
     const long long cap = tune(T_WAVES_PER_CU);
@@ -1110,12 +1093,12 @@ void launch_tiled(Plan *plan, bool dry, const Device &dev, size_t n, int U, int 
         plan->u = U;
         plan->blocks_per_cu = per_cu;
     }
-    if (!dry) hipLaunchKernelGGL(Kern, dim3(sh.blocks), dim3(kBlock), 0, s, args..., sh.chunk, flags);
+    if (!dry) hipLaunchKernelGGL(Kern, dim3(sh.blocks), dim3(kBlock), 0, s, args..., sh.chunk);
 }
 
 // pattern-table forward: BLOCK-thread blocks, at most two resident per CU (LDS), each wave loops over its tiles
 template <auto Kern, int BLOCK, typename... Args>
-void launch_lut(Plan *plan, bool dry, const Device &dev, size_t n, int U, int flags, hipStream_t s, Args... args) {
+void launch_lut(Plan *plan, bool dry, const Device &dev, size_t n, int U, hipStream_t s, Args... args) {
     int per_cu = occupancy_blocks_per_cu<Kern>(dev, BLOCK);
     if (per_cu > 2) per_cu = 2;
     const long long cap = tune(T_LUT_BLOCKS_PER_CU);
@@ -1130,7 +1113,7 @@ void launch_lut(Plan *plan, bool dry, const Device &dev, size_t n, int U, int fl
         plan->u = U;
         plan->blocks_per_cu = per_cu;
     }
-    if (!dry) hipLaunchKernelGGL(Kern, dim3(sh.blocks), dim3(BLOCK), 0, s, args..., sh.chunk, flags);
+    if (!dry) hipLaunchKernelGGL(Kern, dim3(sh.blocks), dim3(BLOCK), 0, s, args..., sh.chunk);
 }
 
 // Smallest tensor that takes the pattern-table forward: building the table costs the same whatever the table, the register
@@ -1194,13 +1177,6 @@ long long tuned(TuneKey key, long long policy) {
     return t > 0 ? t : policy;
 }
 
-// kernel `flags`: outputs go past the caches (nontemporal) unless they alias the input -- the reference operator's own
-// in-place mode --, where the line being written has just been read and a plain store is 7-15 % faster
-int out_flags(const void *in, const void *out) {
-    if (in != out) return kFlagStreamOut;
-    return tune(T_NT_INPLACE) == 1 ? kFlagStreamOut : 0;
-}
-
 unsigned group_grid(size_t n) { return static_cast<unsigned>(((n + 7) / 8 + kBlock - 1) / kBlock); }
 
 template <int FN, int DT>
@@ -1208,7 +1184,6 @@ int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state,
                    int k, float p0, float p1, hipStream_t s) {
     Device dev;
     if (const int rc = get_device(dev)) return rc;
-    const int flags = out_flags(x, y);
     const bool pow2 = nborders == (1 << k) - 1;
     if (plan) plan->k = k;
     auto name = [&](const char *kern, int U, int block) {
@@ -1220,7 +1195,7 @@ int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state,
         // building the table in every block
         if (n >= lut_min_elements(k)) {
             if (k > 4) {
-                launch_lut<quantize_forward_lut_wide_kernel<FN, DT>, kLutBlock>(plan, dry, dev, n, 1, flags, s, x, y, state, n, borders, nborders, k, p0, p1);
+                launch_lut<quantize_forward_lut_wide_kernel<FN, DT>, kLutBlock>(plan, dry, dev, n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
                 name("quantize_forward_lut_wide_kernel", 1, kLutBlock);
                 return dry ? FEWBIT_OK : check_launch("quantize_forward(lut)");
             }
@@ -1229,10 +1204,10 @@ int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state,
                 auto go = [&](auto btag) {
                     constexpr int B = decltype(btag)::value;
                     switch (k) {
-                    case 1: launch_lut<quantize_forward_lut_kernel<FN, DT, 1, U, B>, B>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, nborders, p0, p1); break;
-                    case 2: launch_lut<quantize_forward_lut_kernel<FN, DT, 2, U, B>, B>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, nborders, p0, p1); break;
-                    case 3: launch_lut<quantize_forward_lut_kernel<FN, DT, 3, U, B>, B>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, nborders, p0, p1); break;
-                    default: launch_lut<quantize_forward_lut_kernel<FN, DT, 4, U, B>, B>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    case 1: launch_lut<quantize_forward_lut_kernel<FN, DT, 1, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    case 2: launch_lut<quantize_forward_lut_kernel<FN, DT, 2, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    case 3: launch_lut<quantize_forward_lut_kernel<FN, DT, 3, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+                    default: launch_lut<quantize_forward_lut_kernel<FN, DT, 4, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
                     }
                     name("quantize_forward_lut_kernel", U, B);
                 };
@@ -1251,15 +1226,15 @@ int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state,
         with_u(Us{}, tuned(T_U_FWD, policy_u_fwd<DT>(n)), [&](auto tag) {
             constexpr int U = decltype(tag)::value;
             switch (k) {
-            case 1: launch_tiled<quantize_forward_kernel<FN, DT, 1, U>>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, p0, p1); break;
-            case 2: launch_tiled<quantize_forward_kernel<FN, DT, 2, U>>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, p0, p1); break;
-            case 3: launch_tiled<quantize_forward_kernel<FN, DT, 3, U>>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, p0, p1); break;
-            default: launch_tiled<quantize_forward_kernel<FN, DT, 4, U>>(plan, dry, dev, n, U, flags, s, x, y, state, n, borders, p0, p1); break;
+            case 1: launch_tiled<quantize_forward_kernel<FN, DT, 1, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
+            case 2: launch_tiled<quantize_forward_kernel<FN, DT, 2, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
+            case 3: launch_tiled<quantize_forward_kernel<FN, DT, 3, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
+            default: launch_tiled<quantize_forward_kernel<FN, DT, 4, U>>(plan, dry, dev, n, U, s, x, y, state, n, borders, p0, p1); break;
             }
             name("quantize_forward_kernel", U, kBlock);
         });
     } else {                       // 5..8-bit tables and tables that do not fill their bit width: borders in LDS
-        launch_tiled<quantize_forward_wide_kernel<FN, DT>>(plan, dry, dev, n, 1, flags, s, x, y, state, n, borders, nborders, k, p0, p1);
+        launch_tiled<quantize_forward_wide_kernel<FN, DT>>(plan, dry, dev, n, 1, s, x, y, state, n, borders, nborders, k, p0, p1);
         name("quantize_forward_wide_kernel", 1, kBlock);
     }
     return dry ? FEWBIT_OK : check_launch("quantize_forward");
@@ -1281,10 +1256,9 @@ int launch_backward(Plan *plan, bool dry, const void *gy, const uint8_t *state, 
                     int k, hipStream_t s) {
     Device dev;
     if (const int rc = get_device(dev)) return rc;
-    const int flags = out_flags(gy, gx);
     if (plan) plan->k = k;
     if (k > 4) {
-        launch_tiled<quantize_backward_wide_kernel<DT>>(plan, dry, dev, n, 1, flags, s, gy, state, gx, n, levels, nlevels, k);
+        launch_tiled<quantize_backward_wide_kernel<DT>>(plan, dry, dev, n, 1, s, gy, state, gx, n, levels, nlevels, k);
         if (plan) snprintf(plan->kernel, sizeof plan->kernel, "quantize_backward_wide_kernel<%s, %d bits>", dtype_name(DT), k);
         return dry ? FEWBIT_OK : check_launch("quantize_backward");
     }
@@ -1292,10 +1266,10 @@ int launch_backward(Plan *plan, bool dry, const void *gy, const uint8_t *state, 
     with_u(Us{}, tuned(T_U_BWD, policy_u_bwd<DT>(n)), [&](auto tag) {
         constexpr int U = decltype(tag)::value;
         switch (k) {
-        case 1: launch_tiled<quantize_backward_kernel<DT, 1, U>>(plan, dry, dev, n, U, flags, s, gy, state, gx, n, levels, nlevels); break;
-        case 2: launch_tiled<quantize_backward_kernel<DT, 2, U>>(plan, dry, dev, n, U, flags, s, gy, state, gx, n, levels, nlevels); break;
-        case 3: launch_tiled<quantize_backward_kernel<DT, 3, U>>(plan, dry, dev, n, U, flags, s, gy, state, gx, n, levels, nlevels); break;
-        default: launch_tiled<quantize_backward_kernel<DT, 4, U>>(plan, dry, dev, n, U, flags, s, gy, state, gx, n, levels, nlevels); break;
+        case 1: launch_tiled<quantize_backward_kernel<DT, 1, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
+        case 2: launch_tiled<quantize_backward_kernel<DT, 2, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
+        case 3: launch_tiled<quantize_backward_kernel<DT, 3, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
+        default: launch_tiled<quantize_backward_kernel<DT, 4, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, levels, nlevels); break;
         }
         if (plan) snprintf(plan->kernel, sizeof plan->kernel, "quantize_backward_kernel<%s, %d bits, U=%d>", dtype_name(DT), k, U);
     });
@@ -1306,12 +1280,11 @@ template <int FN, int DT>
 int launch_step1_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state, size_t n, float p0, float p1, hipStream_t s) {
     Device dev;
     if (const int rc = get_device(dev)) return rc;
-    const int flags = out_flags(x, y);
     if (plan) plan->k = 1;
     typedef typename std::conditional<DT == FEWBIT_F32, StreamUs32, StreamUs16>::type Us;
     with_u(Us{}, tuned(T_U_STEP1, policy_u_step1_fwd<DT>(n)), [&](auto tag) {
         constexpr int U = decltype(tag)::value;
-        launch_tiled<stepwise1_forward_kernel<FN, DT, U>>(plan, dry, dev, n, U, flags, s, x, y, state, n, p0, p1);
+        launch_tiled<stepwise1_forward_kernel<FN, DT, U>>(plan, dry, dev, n, U, s, x, y, state, n, p0, p1);
         if (plan) snprintf(plan->kernel, sizeof plan->kernel, "stepwise1_forward_kernel<%s, %s, U=%d>", kStepNames[FN], dtype_name(DT), U);
     });
     return dry ? FEWBIT_OK : check_launch("stepwise1_forward");
@@ -1333,12 +1306,11 @@ int launch_step1_backward(Plan *plan, bool dry, const void *gy, const uint8_t *s
                           hipStream_t s) {
     Device dev;
     if (const int rc = get_device(dev)) return rc;
-    const int flags = out_flags(gy, gx);
     if (plan) plan->k = 1;
     typedef typename std::conditional<DT == FEWBIT_F32, StreamUs32, StreamUs16>::type Us;
     with_u(Us{}, tuned(T_U_STEP1, policy_u_step1_bwd<DT>(n)), [&](auto tag) {
         constexpr int U = decltype(tag)::value;
-        launch_tiled<stepwise1_backward_kernel<DT, U>>(plan, dry, dev, n, U, flags, s, gy, state, gx, n, m0, m1);
+        launch_tiled<stepwise1_backward_kernel<DT, U>>(plan, dry, dev, n, U, s, gy, state, gx, n, m0, m1);
         if (plan) snprintf(plan->kernel, sizeof plan->kernel, "stepwise1_backward_kernel<%s, U=%d>", dtype_name(DT), U);
     });
     return dry ? FEWBIT_OK : check_launch("stepwise1_backward");

@@ -148,7 +148,7 @@ int fewbit_hip_describe_stepwise1_backward(int fn, int dtype, size_t n, char *bu
 /*
  * Launch-shape tuning at run time (measurement scripts; not needed for correctness -- every setting computes the same
  * bytes).  Keys: "waves_per_cu", "chunk", "lut_chunk", "lut_blocks_per_cu", "lut_min", "lut_block", "u_fwd", "u_bwd",
- * "u_lut", "u_step1", "nt_inplace"; value -1 restores the built-in policy.  The same keys are read once from the environment
+ * "u_lut", "u_step1"; value -1 restores the built-in policy.  The same keys are read once from the environment
  * (FEWBIT_HIP_<KEY in upper case>) at the first launch.
  */
 int fewbit_hip_tune(const char *key, long long value);

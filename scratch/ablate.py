@@ -12,7 +12,7 @@ from fewbit_amd.store import store
 
 which = sys.argv[1]
 libs = [a.split('=', 1) for a in sys.argv[2:]]
-KEYS = ('waves_per_cu', 'chunk', 'lut_chunk', 'lut_blocks_per_cu', 'lut_min', 'lut_block', 'u_fwd', 'u_bwd', 'u_lut', 'u_step1', 'nt_inplace')
+KEYS = ('waves_per_cu', 'chunk', 'lut_chunk', 'lut_blocks_per_cu', 'lut_min', 'lut_block', 'u_fwd', 'u_bwd', 'u_lut', 'u_step1')
 n = int(os.environ.get('SIZE', 4096 * 4096)); k = int(os.environ.get('K', 3)); fn = os.environ.get('FN', 'gelu')
 dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[os.environ.get('DT', 'bf16')]
 tune = dict(kv.split('=') for kv in os.environ.get('TUNE', '').split(',') if kv)
@@ -37,7 +37,7 @@ for name, path in libs:
     SET[name] = (lib, dict(tune, **own))
     lib.fewbit_hip_quantize_forward.argtypes = [i32, i32, vp, vp, vp, sz, vp, i32, dbl, dbl, vp]
     lib.fewbit_hip_quantize_backward.argtypes = [i32, vp, vp, vp, sz, vp, i32, vp]
-    lib.fewbit_hip_tune.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
+    if hasattr(lib, 'fewbit_hip_tune'): lib.fewbit_hip_tune.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
     calls = []
     for (x, y, gy, gx, st) in sets:
         af = (cabi.CONTINUOUS.index(fn), cabi.DTYPES[dtype], x.data_ptr(), (x if inplace else y).data_ptr(), st.data_ptr(), n, bo.data_ptr(), bo.numel(), 0.0, 0.0, stream)
@@ -54,6 +54,7 @@ torch.cuda.synchronize()
 
 def apply(name):
     lib, settings = SET[name]
+    if not hasattr(lib, 'fewbit_hip_tune'): return        # an older build (no run-time tuning)
     for kk in KEYS: lib.fewbit_hip_tune(kk.encode(), -1)
     for kk, vv in settings.items(): assert lib.fewbit_hip_tune(kk.encode(), int(vv)) == 0, kk
 

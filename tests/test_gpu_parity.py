@@ -672,12 +672,11 @@ def test_folded_key_every_fp32_pattern():
 
 
 def test_every_launch_shape_and_tile_width_gives_the_same_bytes():
-    """fewbit_hip_tune (groups per lane per stage, resident blocks per CU, resident / chunked shape, in-place store
-    flavour) only changes HOW the tensor is swept; state, y and gx must not change by a bit.  Sizes around several tiles
+    """fewbit_hip_tune (groups per lane per stage, resident blocks per CU, resident / chunked shape) only changes HOW the tensor is swept; state, y and gx must not change by a bit.  Sizes around several tiles
     and a ragged tail; bf16 (pattern-table and search forward, backward U = 1, 2, 4), fp32 (search forward U = 1, 2) and
     the 1-bit family."""
     import json
-    keys = ('waves_per_cu', 'chunk', 'lut_chunk', 'lut_blocks_per_cu', 'lut_min', 'u_fwd', 'u_bwd', 'u_lut', 'u_step1', 'nt_inplace')
+    keys = ('waves_per_cu', 'chunk', 'lut_chunk', 'lut_blocks_per_cu', 'lut_min', 'u_fwd', 'u_bwd', 'u_lut', 'u_step1')
     try:
         for dt, n in (('bf16', 64 * 8 * 4 * 37 + 13), ('f32', 64 * 8 * 4 * 19 + 5), ('bf16', 7 * 1024 * 1024 + 3)):
             dtype = DTYPES[dt]
@@ -705,13 +704,11 @@ def test_every_launch_shape_and_tile_width_gives_the_same_bytes():
                         rg = cabi.stepwise1_backward('leaky_relu', gy, rs, 0.1)
                         assert torch.equal(rs, rs0) and torch.equal(bits(r), bits(r0)) and torch.equal(bits(rg), bits(rg0))
             assert len(seen) >= 6                          # the settings really did change the launch
-            for nt in (0, 1):                              # in place: plain (policy) and nontemporal output stores
-                cabi.tune(**{k: -1 for k in keys})
-                cabi.tune(nt_inplace=nt)
-                xi, gi = x.clone(), gy.clone()
-                yi, si = cabi.quantize_forward('gelu', xi, borders, out=xi)
-                gxi = cabi.quantize_backward(gi, si, levels, out=gi)
-                assert yi.data_ptr() == xi.data_ptr() and torch.equal(si, s0) and torch.equal(bits(yi), bits(y0)) and torch.equal(bits(gxi), bits(gx0))
+            cabi.tune(**{k: -1 for k in keys})             # in place (the reference operator's own mode): the same bytes
+            xi, gi = x.clone(), gy.clone()
+            yi, si = cabi.quantize_forward('gelu', xi, borders, out=xi)
+            gxi = cabi.quantize_backward(gi, si, levels, out=gi)
+            assert yi.data_ptr() == xi.data_ptr() and torch.equal(si, s0) and torch.equal(bits(yi), bits(y0)) and torch.equal(bits(gxi), bits(gx0))
     finally:
         cabi.tune(**{k: -1 for k in keys})
 

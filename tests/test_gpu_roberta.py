@@ -1,5 +1,6 @@
 """BASELINE.json configs[4] on the GPU: RoBERTa-base (random init, `RobertaConfig()` defaults 768/12/12/3072), batch 128 x
-seq 128, forward+backward with all 12 intermediate GELUs replaced by fewbit.GELU(bits=3), against the vanilla model.
+seq 128, forward+backward with all 12 intermediate GELUs replaced by fewbit.GELU(bits=3) -- and, third variant, by the raw
+`torch.ops.fewbit.gelu` the way the reference's own benchmark patches it in --, against the vanilla model.
 
 The caller this mimics is the reference's benchmark/bench-roberta.py:123-149 (it patches ACT2FN['gelu'] with
 torch.ops.fewbit.gelu and reports wall time and the peak-memory delta); SURVEY 8(d) C5 gives the expected saving:
@@ -49,10 +50,15 @@ def test_roberta_base_all_gelu_fewbit(dtype):
     es = torch.empty(0, dtype=dtype).element_size()
 
     res = {}
-    for name in ('vanilla', 'fewbit'):
+    for name in ('vanilla', 'fewbit', 'op'):
         model = rb.build(dtype, dev)                                  # same seed -> same weights
-        swapped = rb.swap_gelu(model, BITS) if name == 'fewbit' else 0
-        assert swapped == (12 if name == 'fewbit' else 0)
+        if name == 'op':
+            # the REFERENCE'S caller route (benchmark/bench-roberta.py:123-149): the raw operator with its literal tables, in
+            # place on nn.Linear's 3-D output (a view of the addmm result)
+            swapped = rb.patch_gelu_with_raw_op(model, dtype, dev)
+        else:
+            swapped = rb.swap_gelu(model, BITS) if name == 'fewbit' else 0
+        assert swapped == (0 if name == 'vanilla' else 12)
         # first step: same weights, same dropout stream -> the loss may differ only by the GELU arithmetic
         torch.manual_seed(123)
         torch.cuda.reset_peak_memory_stats(dev)
@@ -80,3 +86,11 @@ def test_roberta_base_all_gelu_fewbit(dtype):
     print(f'\nroberta-base {dtype}: vanilla {res["vanilla"]["ms"]:.2f} ms, fewbit {res["fewbit"]["ms"]:.2f} ms (ratio {ratio:.3f}); '
           f'peak {res["vanilla"]["peak"] / 2**30:.2f} -> {res["fewbit"]["peak"] / 2**30:.2f} GiB; saved-tensor delta {delta} B')
     assert ratio <= 1.03, res
+    # the raw-operator route: nothing but {state, levels} saved (no CopySlices copies), same loss (same forward), and no slower
+    # than the module route beyond noise
+    assert res['op']['saved'] == res['fewbit']['saved'], res
+    assert abs(res['op']['peak'] - res['fewbit']['peak']) <= (1 << 20), res
+    assert abs(res['op']['loss'] - res['fewbit']['loss']) <= tol, res
+    print(f'raw-op route: {res["op"]["ms"]:.2f} ms (x{res["op"]["ms"] / res["fewbit"]["ms"]:.3f} of the module route, '
+          f'x{res["op"]["ms"] / res["vanilla"]["ms"]:.3f} of vanilla)')
+    assert res['op']['ms'] / res['vanilla']['ms'] <= 1.05 and res['op']['ms'] / res['fewbit']['ms'] <= 1.05, res
