@@ -849,6 +849,7 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void step
     }
 }
 
+#if !defined(FEWBIT_TU) || FEWBIT_TU == 0      // (not templates: one unit of a split build defines them)
 // ------------------------------------------------------------------------------------------------
 // Stand-alone codec (test seam for the layout): int32 codes <-> packed bytes, width 1..8.
 // Replaces DeflateBlockKernel / InflateBlockKernel (fewbit/cuda/codec.cu:166-182, :205-220).
@@ -877,15 +878,58 @@ __global__ __launch_bounds__(kBlock) void unpack_codes_kernel(const uint8_t *__r
     for (int i = 0; i < 8; ++i)
         if (e0 + i < n) codes[e0 + i] = static_cast<int32_t>((w >> (nbits * i)) & mask);
 }
+#endif
 
 // ================================================================================================
 // host side: argument checks, dispatch, launch
 // ================================================================================================
-namespace {
+// Split build (Makefile): the forward functors -- nine tenths of the compile time -- are compiled in parallel as units
+// -DFEWBIT_TU=1..FEWBIT_TU_COUNT (three functors each, only dispatch_forward_dtype<FN> instantiated), everything else is unit
+// -DFEWBIT_TU=0; without FEWBIT_TU one unit holds everything (`make variant`).  What the units share has external (hidden)
+// linkage and is defined in the core unit; all the rest below is per unit.
+#if defined(FEWBIT_TU) && FEWBIT_TU != 0
+#define FEWBIT_CORE_TU 0
+#else
+#define FEWBIT_CORE_TU 1
+#endif
+#define FEWBIT_TU_COUNT 5
+#define FEWBIT_HIDDEN __attribute__((visibility("hidden")))
 
+// Run-time tuning.  Every key is -1 ("built-in policy") unless its environment variable is set when the library makes
+// its first launch, or fewbit_hip_tune() sets it later (measurement scripts sweep shapes inside one process that way).
+enum TuneKey {
+    T_WAVES_PER_CU,        // cap on the resident waves per CU a streaming kernel's grid is sized for
+    T_CHUNK,               // search / backward / 1-bit kernels: 0 = resident shape, T = chunked with T tiles per wave
+    T_LUT_CHUNK,           // the same for the pattern-table forward
+    T_LUT_BLOCKS_PER_CU,   // cap on resident pattern-table blocks per CU (at most 2 fit: 64 KiB of LDS each)
+    T_LUT_MIN,             // smallest tensor (elements) that takes the pattern-table forward; 0 = always
+    T_LUT_BLOCK,           // threads per pattern-table block (512 or 1024), where the build has both
+    T_U_FWD, T_U_BWD, T_U_LUT, T_U_STEP1,     // groups per lane per pipeline stage (1, 2 or 4), where the build has them
+    T_COUNT
+};
+struct TuneSpec { const char *key, *env; };
+constexpr TuneSpec kTuneSpec[T_COUNT] = {
+    {"waves_per_cu", "FEWBIT_HIP_WAVES_PER_CU"}, {"chunk", "FEWBIT_HIP_CHUNK"}, {"lut_chunk", "FEWBIT_HIP_LUT_CHUNK"},
+    {"lut_blocks_per_cu", "FEWBIT_HIP_LUT_BLOCKS_PER_CU"}, {"lut_min", "FEWBIT_HIP_LUT_MIN"}, {"lut_block", "FEWBIT_HIP_LUT_BLOCK"},
+    {"u_fwd", "FEWBIT_HIP_U_FWD"}, {"u_bwd", "FEWBIT_HIP_U_BWD"}, {"u_lut", "FEWBIT_HIP_U_LUT"}, {"u_step1", "FEWBIT_HIP_U_STEP1"},
+};
+
+// What a call launched (or would launch: fewbit_hip_describe_*): kernel instantiation and launch shape.
+struct Plan {
+    char kernel[128];
+    unsigned blocks;
+    int threads, chunk, u, k, blocks_per_cu;
+};
+
+extern FEWBIT_HIDDEN thread_local char g_last_error[256];
+extern FEWBIT_HIDDEN std::atomic<long long> g_tune[T_COUNT];
+FEWBIT_HIDDEN int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+FEWBIT_HIDDEN void tune_init();
+
+#if FEWBIT_CORE_TU
 thread_local char g_last_error[256] = "";
+std::atomic<long long> g_tune[T_COUNT];
 
-int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -893,6 +937,19 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+
+void tune_init() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int i = 0; i < T_COUNT; ++i) {
+            const char *e = getenv(kTuneSpec[i].env);
+            g_tune[i].store(e && *e ? atoll(e) : -1ll, std::memory_order_relaxed);
+        }
+    });
+}
+#endif
+
+namespace {
 
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
@@ -941,36 +998,6 @@ size_t dtype_size(int dtype) { return dtype == FEWBIT_F32 ? 4 : 2; }
         if (rc_ != FEWBIT_OK) return rc_;                            \
     } while (0)
 
-// ------------------------------------------------------------------------------------------------
-// Run-time tuning.  Every key is -1 ("built-in policy") unless its environment variable is set when the library makes
-// its first launch, or fewbit_hip_tune() sets it later (measurement scripts sweep shapes inside one process that way).
-enum TuneKey {
-    T_WAVES_PER_CU,        // cap on the resident waves per CU a streaming kernel's grid is sized for
-    T_CHUNK,               // search / backward / 1-bit kernels: 0 = resident shape, T = chunked with T tiles per wave
-    T_LUT_CHUNK,           // the same for the pattern-table forward
-    T_LUT_BLOCKS_PER_CU,   // cap on resident pattern-table blocks per CU (at most 2 fit: 64 KiB of LDS each)
-    T_LUT_MIN,             // smallest tensor (elements) that takes the pattern-table forward; 0 = always
-    T_LUT_BLOCK,           // threads per pattern-table block (512 or 1024), where the build has both
-    T_U_FWD, T_U_BWD, T_U_LUT, T_U_STEP1,     // groups per lane per pipeline stage (1, 2 or 4), where the build has them
-    T_COUNT
-};
-struct TuneSpec { const char *key, *env; };
-constexpr TuneSpec kTuneSpec[T_COUNT] = {
-    {"waves_per_cu", "FEWBIT_HIP_WAVES_PER_CU"}, {"chunk", "FEWBIT_HIP_CHUNK"}, {"lut_chunk", "FEWBIT_HIP_LUT_CHUNK"},
-    {"lut_blocks_per_cu", "FEWBIT_HIP_LUT_BLOCKS_PER_CU"}, {"lut_min", "FEWBIT_HIP_LUT_MIN"}, {"lut_block", "FEWBIT_HIP_LUT_BLOCK"},
-    {"u_fwd", "FEWBIT_HIP_U_FWD"}, {"u_bwd", "FEWBIT_HIP_U_BWD"}, {"u_lut", "FEWBIT_HIP_U_LUT"}, {"u_step1", "FEWBIT_HIP_U_STEP1"},
-};
-std::atomic<long long> g_tune[T_COUNT];
-std::once_flag g_tune_once;
-
-void tune_init() {
-    std::call_once(g_tune_once, [] {
-        for (int i = 0; i < T_COUNT; ++i) {
-            const char *e = getenv(kTuneSpec[i].env);
-            g_tune[i].store(e && *e ? atoll(e) : -1ll, std::memory_order_relaxed);
-        }
-    });
-}
 long long tune(TuneKey k) {
     tune_init();
     return g_tune[k].load(std::memory_order_relaxed);
@@ -1016,13 +1043,6 @@ template <auto Kern> int occupancy_blocks_per_cu(const Device &d, int threads) {
     }
     return nb;
 }
-
-// What a call launched (or would launch: fewbit_hip_describe_*): kernel instantiation and launch shape.
-struct Plan {
-    char kernel[128];
-    unsigned blocks;
-    int threads, chunk, u, k, blocks_per_cu;
-};
 
 const char *const kFnNames[FEWBIT_CONTINUOUS_COUNT] = {"celu", "elu", "gelu", "hardswish", "logsigmoid", "mish", "selu", "sigmoid",
                                                        "silu", "softplus", "softsign", "tanh", "tanhshrink", "identity",
@@ -1126,20 +1146,21 @@ size_t lut_min_elements(int k) {
     return k == 4 ? (static_cast<size_t>(9) << 19) : (static_cast<size_t>(6) << 20);
 }
 
-// Groups per lane per pipeline stage.  Which values a build holds: the cheap kernels (backward, 1-bit) always 1, 2 and 4;
-// the forward kernels (15 functors x 3 dtypes x 4 widths each) only the policy's own unless built with -DFEWBIT_SWEEP
-// (scratch measurement build: fewer functors, every U, both table block sizes).
+// Groups per lane per pipeline stage.  Which values a build holds: the policy's own (backward, 1-bit and fp32 forward: 1 and
+// 2; 16-bit forward: 1) unless built with -DFEWBIT_SWEEP (scratch measurement build: fewer functors, 1 / 2 / 4 for every
+// kernel, both table block sizes).
 template <int... Us> struct UList {};
 #ifdef FEWBIT_SWEEP
 typedef UList<1, 2, 4> FwdUs16;
 typedef UList<1, 2> FwdUs32;
 typedef UList<1, 2, 4> LutUs;
+typedef UList<1, 2, 4> StreamUs16;
 #else
 typedef UList<1> FwdUs16;
 typedef UList<1, 2> FwdUs32;
 typedef UList<1> LutUs;
+typedef UList<1, 2> StreamUs16;        // (U = 4 never won a size class: profiles/r03_backward_shape_sweep.txt)
 #endif
-typedef UList<1, 2, 4> StreamUs16;
 typedef UList<1, 2> StreamUs32;
 
 // call f(integral_constant<U>) for the U of the list that `want` names (the list's first entry if it names none)
@@ -1240,9 +1261,12 @@ int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state,
     return dry ? FEWBIT_OK : check_launch("quantize_forward");
 }
 
+}  // namespace
+
+// one functor, every dtype: the unit of the split build (external, hidden linkage; see FEWBIT_TU above)
 template <int FN>
-int dispatch_forward_dtype(Plan *plan, bool dry, int dtype, const void *x, void *y, uint8_t *state, size_t n, const void *borders,
-                           int nborders, int k, float p0, float p1, hipStream_t s) {
+FEWBIT_HIDDEN int dispatch_forward_dtype(Plan *plan, bool dry, int dtype, const void *x, void *y, uint8_t *state, size_t n,
+                                         const void *borders, int nborders, int k, float p0, float p1, hipStream_t s) {
     switch (dtype) {
     case FEWBIT_F32: return launch_forward<FN, FEWBIT_F32>(plan, dry, x, y, state, n, borders, nborders, k, p0, p1, s);
     case FEWBIT_F16: return launch_forward<FN, FEWBIT_F16>(plan, dry, x, y, state, n, borders, nborders, k, p0, p1, s);
@@ -1250,6 +1274,42 @@ int dispatch_forward_dtype(Plan *plan, bool dry, int dtype, const void *x, void 
     default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
     }
 }
+
+#ifdef FEWBIT_TU
+// functor id F is compiled by unit 1 + F / 3; every other unit only declares it
+#define FB_DISPATCH_ARGS (Plan *, bool, int, const void *, void *, uint8_t *, size_t, const void *, int, int, float, float, hipStream_t)
+#define FB_DECLARE(F) extern template int dispatch_forward_dtype<F> FB_DISPATCH_ARGS;
+#define FB_DEFINE(F) template int dispatch_forward_dtype<F> FB_DISPATCH_ARGS;
+#if FEWBIT_TU == 1
+FB_DEFINE(0) FB_DEFINE(1) FB_DEFINE(2)
+#else
+FB_DECLARE(0) FB_DECLARE(1) FB_DECLARE(2)
+#endif
+#if FEWBIT_TU == 2
+FB_DEFINE(3) FB_DEFINE(4) FB_DEFINE(5)
+#else
+FB_DECLARE(3) FB_DECLARE(4) FB_DECLARE(5)
+#endif
+#if FEWBIT_TU == 3
+FB_DEFINE(6) FB_DEFINE(7) FB_DEFINE(8)
+#else
+FB_DECLARE(6) FB_DECLARE(7) FB_DECLARE(8)
+#endif
+#if FEWBIT_TU == 4
+FB_DEFINE(9) FB_DEFINE(10) FB_DEFINE(11)
+#else
+FB_DECLARE(9) FB_DECLARE(10) FB_DECLARE(11)
+#endif
+#if FEWBIT_TU == 5
+FB_DEFINE(12) FB_DEFINE(13) FB_DEFINE(14)
+#else
+FB_DECLARE(12) FB_DECLARE(13) FB_DECLARE(14)
+#endif
+static_assert(FEWBIT_CONTINUOUS_COUNT == 3 * FEWBIT_TU_COUNT, "every continuous functor needs a unit");
+#endif
+
+#if FEWBIT_CORE_TU
+namespace {
 
 template <int DT>
 int launch_backward(Plan *plan, bool dry, const void *gy, const uint8_t *state, void *gx, size_t n, const void *levels, int nlevels,
@@ -1426,8 +1486,10 @@ int write_plan(const Plan &p, char *buf, size_t len) {
 }
 
 }  // namespace
+#endif  // FEWBIT_CORE_TU
 }  // namespace fewbit_hip
 
+#if FEWBIT_CORE_TU
 // ================================================================================================
 // C-ABI
 // ================================================================================================
@@ -1532,3 +1594,4 @@ int fewbit_hip_unpack_codes(const uint8_t *state, int32_t *codes, size_t n, int 
 }
 
 }  // extern "C"
+#endif  // FEWBIT_CORE_TU
