@@ -1191,8 +1191,17 @@ constexpr size_t kLargeForward32 = static_cast<size_t>(32) << 20;
 template <int DT> long long policy_u_fwd(size_t n) { return DT == FEWBIT_F32 && n >= kLargeForward32 ? 2 : 1; }
 template <int DT> long long policy_u_lut(size_t) { return 1; }
 template <int DT> long long policy_u_bwd(size_t n) { return DT == FEWBIT_F32 || n >= kLargeStream16 ? 1 : 2; }
-template <int DT> long long policy_u_step1_fwd(size_t) { return 1; }
-template <int DT> long long policy_u_step1_bwd(size_t n) { return DT == FEWBIT_F32 || n >= kLargeStream16 ? 1 : 2; }
+//   1-bit family (profiles/r03_shape_sweep_step1.txt, r03_shape_sweep_step1_sizes.txt; relu): these kernels are copies with a
+//     compare, and two groups per lane is the better copy -- 16-bit forward from 6 Mi elements on (4096x4096 bf16: 11.02 ->
+//     9.42 us warm, 13.65 -> 13.0 cold; 8192x4096: 20.79 -> 20.21 / 24.47 -> 23.64), 16-bit backward at every size
+//     (25 Mi: 17.39 -> 16.29 / 20.29 -> 19.34); fp32 only between 4 Mi and 12 Mi elements (8 Mi: 9.74 -> 9.02 / 13.30 -> 12.81;
+//     from 16 Mi on one group is better: 19.9 against 20.4 us).  Below ~4 Mi elements every shape takes the same 3.9 us.
+template <int DT> bool step1_mid32(size_t n) { return n >= (static_cast<size_t>(4) << 20) && n < (static_cast<size_t>(12) << 20); }
+template <int DT> long long policy_u_step1_fwd(size_t n) {
+    if (DT == FEWBIT_F32) return step1_mid32<DT>(n) ? 2 : 1;
+    return n >= (static_cast<size_t>(6) << 20) ? 2 : 1;
+}
+template <int DT> long long policy_u_step1_bwd(size_t n) { return DT == FEWBIT_F32 ? (step1_mid32<DT>(n) ? 2 : 1) : 2; }
 long long tuned(TuneKey key, long long policy) {
     const long long t = tune(key);
     return t > 0 ? t : policy;

@@ -19,7 +19,14 @@ names = sys.argv[2].split(',') if len(sys.argv) > 2 else ['c2', 'c4', 'c3k2', 'c
 CFG = {'c2': ('gelu', 3, torch.bfloat16, 4096 * 4096), 'c4': ('gelu', 3, torch.bfloat16, 8192 * 4096),
        'c3k2': ('silu', 2, torch.float16, 8192 * 8192), 'c3k4': ('silu', 4, torch.float16, 8192 * 8192),
        'f32': ('gelu', 3, torch.float32, 4096 * 4096), 'c1': ('relu', 1, torch.float32, 1024 * 1024),
-       'rob': ('gelu', 3, torch.float32, 16384 * 3072), 'robbf': ('gelu', 3, torch.bfloat16, 16384 * 3072)}
+       'rob': ('gelu', 3, torch.float32, 16384 * 3072), 'robbf': ('gelu', 3, torch.bfloat16, 16384 * 3072),
+       'relu16': ('relu', 1, torch.bfloat16, 8192 * 4096), 'relu16c2': ('relu', 1, torch.bfloat16, 4096 * 4096),
+       'relu32': ('relu', 1, torch.float32, 16384 * 3072), 'relu16_2m': ('relu', 1, torch.bfloat16, 2 << 20),
+       'relu16_4m': ('relu', 1, torch.bfloat16, 4 << 20), 'relu16_8m': ('relu', 1, torch.bfloat16, 8 << 20),
+       'relu16_12m': ('relu', 1, torch.bfloat16, 12 << 20), 'relu16_25m': ('relu', 1, torch.bfloat16, 25 << 20),
+       'relu32_16m': ('relu', 1, torch.float32, 16 << 20), 'relu32_8m': ('relu', 1, torch.float32, 8 << 20),
+       'f32_8m': ('gelu', 3, torch.float32, 8 << 20), 'f32_4m': ('gelu', 3, torch.float32, 4 << 20), 'bf16_8m': ('gelu', 3, torch.bfloat16, 8 << 20),
+       'bf16_12m': ('gelu', 3, torch.bfloat16, 12 << 20), 'bf16_4m': ('gelu', 3, torch.bfloat16, 4 << 20)}
 ALL = ('waves_per_cu', 'chunk', 'lut_chunk', 'lut_blocks_per_cu', 'lut_min', 'lut_block', 'u_fwd', 'u_bwd', 'u_lut', 'u_step1')
 
 
@@ -96,7 +103,7 @@ def run(cfgname, kind):
         desc = lambda: cabi.describe_forward(name, dtype, n, 2**k - 1)
     elif kind == 'step1f':
         which = 'fwd'
-        grid = [dict(u_step1=u, waves_per_cu=w, chunk=c) for u in (1, 2, 4) for w in (8, 16, 32) for c in (0, 1)]
+        grid = [dict(u_step1=u, waves_per_cu=w, chunk=c) for u in (1, 2, 4) for w in (8, 16, 32) for c in (0, 1, 3)]
         desc = lambda: cabi.describe_stepwise1_forward(name, dtype, n)
     else:  # step1b
         which = 'bwd'

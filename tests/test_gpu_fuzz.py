@@ -34,6 +34,23 @@ def offset_copy(t, off_elems, extra=16):
     return view
 
 
+TUNE_KEYS = ('waves_per_cu', 'chunk', 'lut_chunk', 'u_fwd', 'u_bwd', 'u_lut', 'u_step1')
+
+
+def random_launch_shape(rng):
+    """groups per lane per stage, resident blocks per CU and resident / chunked shape picked per case (fewbit_hip_tune):
+    every kernel instantiation the size policy can choose is reached at the small sizes of this file too"""
+    u = int(rng.choice([-1, 1, 2]))
+    cabi.tune(u_fwd=u, u_bwd=int(rng.choice([-1, 1, 2])), u_lut=u, u_step1=int(rng.choice([-1, 1, 2])),
+              waves_per_cu=int(rng.choice([-1, 8, 16, 32])), chunk=int(rng.choice([-1, 0, 1, 3])), lut_chunk=int(rng.choice([-1, 0, 2])))
+
+
+@pytest.fixture(autouse=True)
+def _restore_launch_policy():
+    yield
+    cabi.tune(**{k: -1 for k in TUNE_KEYS})
+
+
 # FEWBIT_FUZZ_SEEDS=N widens the sweep (a one-off soak run; the default keeps the suite short)
 N_SEEDS = int(__import__('os').environ.get('FEWBIT_FUZZ_SEEDS', '12'))
 
@@ -65,6 +82,7 @@ def test_fuzz_quantize_paths(seed):
         inplace = bool(rng.integers(2))
         out = xd if inplace else offset_copy(torch.zeros_like(x), int(rng.integers(0, 8)))
         tag = f'seed={seed} {fn} {dt} nlev={nlev} n={n} offs=({xo},{so},{go}) inplace={inplace}'
+        random_launch_shape(rng)
         y, _ = cabi.quantize_forward(fn, xd, inner.to(DEV), *p, out=out, state=st)
         assert_bit_equal(st.cpu(), s_o, tag + ' state')
         assert sbuf[:so].sum().item() == 0 and sbuf[so + nbytes:].sum().item() == 0, tag + ' wrote outside the state'
@@ -100,6 +118,7 @@ def test_fuzz_one_bit_family(seed):
         sbuf = torch.zeros(s_o.numel() + so + 16, dtype=torch.uint8, device=DEV)
         st = sbuf[so:so + s_o.numel()]
         tag = f'seed={seed} {name} {dt} n={n} offs=({xo},{so})'
+        random_launch_shape(rng)
         y, _ = cabi.stepwise1_forward(name, xd, *p, state=st)
         assert_bit_equal(st.cpu(), s_o, tag + ' state')
         assert sbuf[:so].sum().item() == 0 and sbuf[so + s_o.numel():].sum().item() == 0, tag

@@ -723,3 +723,46 @@ def test_describe_names_the_kernel_the_dispatch_takes():
     b2, b4 = cabi.describe_backward(torch.bfloat16, n2, 8), cabi.describe_backward(torch.bfloat16, n4, 8)
     assert b2['u'] == 2 and b2['chunk'] == 0 and b4['u'] == 1 and b4['chunk'] == 1      # the measured policy, DESIGN.md section 3
     assert cabi.describe_stepwise1_forward('relu', torch.float32, 1 << 20)['kernel'].startswith('stepwise1_forward_kernel<relu, f32')
+
+
+def test_large_fp32_tensor_takes_the_wide_forward_tile_and_stays_exact():
+    """RoBERTa-base's MLP activation in the reference's own dtype (16384x3072 fp32, 50 Mi elements + a ragged tail): the size
+    class where the policy switches the fp32 forward to two groups per lane per stage and every backward to the
+    one-tile-per-wave grid.  Codes == torch.bucketize, gradients == levels[codes] * gy, an oracle window, in place ==
+    out of place, and the same bytes as the narrow tile (u_fwd = 1)."""
+    n = 16384 * 3072 + 8 * 37 + 3
+    dtype = torch.float32
+    g = torch.Generator(device=DEV).manual_seed(5)
+    xd = torch.randn(n, generator=g, device=DEV) * 1.5
+    gyd = torch.randn(n, generator=g, device=DEV)
+    borders, levels = store.get('gelu', 3, 'cpu', dtype)
+    inner = borders[1:-1].contiguous()
+    bd, ld = inner.to(DEV), levels.to(DEV)
+    plan = cabi.describe_forward('gelu', dtype, n, 7)
+    assert plan['u'] == 2 and plan['kernel'].startswith('quantize_forward_kernel<gelu, f32'), plan
+    assert cabi.describe_backward(dtype, n, 8)['chunk'] == 1
+    y, state = cabi.quantize_forward('gelu', xd, bd)
+    gx = cabi.quantize_backward(gyd, state, ld)
+    codes = cabi.unpack_codes(state, n, 3)
+    assert torch.equal(codes, torch.bucketize(xd, bd, out_int32=True))
+    assert torch.equal(gx, ld[codes.long()] * gyd)
+    lo = (n // 2 // 512) * 512
+    win = slice(lo, lo + 512 * 200)
+    xw, gw = xd[win].cpu(), gyd[win].cpu()
+    y_o, s_o, _ = oracle.quantize('gelu', xw, inner)
+    sb, se = state_range(win.start, win.stop, 3)
+    assert_bit_equal(state[sb:se].cpu(), s_o, 'window state')
+    assert_bit_equal(gx[win].cpu(), oracle.quantize_backward(gw, s_o, levels), 'window gx')
+    assert forward_value_ok(xw, y[win].cpu(), y_o).all()
+    tail = slice(n - 600, n)                                   # the ragged end against the oracle
+    y_t, s_t, _ = oracle.quantize('gelu', xd[n - 8 * 75 - 3:].cpu(), inner)
+    assert_bit_equal(state[3 * ((n - 8 * 75 - 3) // 8):].cpu(), s_t, 'tail state')
+    xi = xd.clone()
+    _, s_in = cabi.quantize_forward('gelu', xi, bd, out=xi)
+    assert torch.equal(s_in, state) and torch.equal(xi, y)
+    try:
+        cabi.tune(u_fwd=1)
+        y1, s1 = cabi.quantize_forward('gelu', xd, bd)
+    finally:
+        cabi.tune(u_fwd=-1)
+    assert torch.equal(s1, state) and torch.equal(y1, y)
