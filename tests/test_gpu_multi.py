@@ -18,7 +18,6 @@ import json
 import pytest
 import torch
 
-import oracle  # noqa: F401  (checker package; keeps the import order of the other GPU test files)
 from fewbit_amd import cabi
 from helpers import C4_BITS, GOLDEN, c4_shard, c4_tensor_inputs, load_tables, sha256_of
 
