@@ -568,49 +568,60 @@ def build_line(args, world, res, per_rank=None, launcher='single process'):
     return line
 
 
+def _guarded(what, fn):
+    """The extras never take the contract's line down with them: a failure is recorded in place of the result."""
+    try:
+        return fn()
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write(f'[bench] extra `{what}` failed: {type(e).__name__}: {e}\n')
+        torch.cuda.empty_cache()
+        return {'error': f'{type(e).__name__}: {e}'[:300]}
+
+
+def _other_config(name, c, args, device):
+    kf, kb = describe(c)
+    entry = {'workload': c['label'], 'bytes_per_step': int(step_bytes(c)[0]),
+             'kernels': {'fwd': kf['kernel'], 'bwd': kb['kernel'],
+                         'fwd_shape': {k: kf[k] for k in ('blocks', 'threads', 'chunk')},
+                         'bwd_shape': {k: kb[k] for k in ('blocks', 'threads', 'chunk')}},
+             'warm': measure_config(c, device, cold=False)}
+    if step_bytes(c)[0] < (64 << 20):                    # launch-bound size: add the host-free figure
+        def graph():
+            us = graph_step_us(c, device)
+            return {'us_step': round(us, 2), 'GiB_s': round(step_bytes(c)[0] / (us * 1e-6) / 2**30, 1),
+                    'frac': round(step_bytes(c)[0] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                    'note': '50 steps captured in one hipGraph, replayed: kernels + their two dependent-launch boundaries, no host '
+                            'launch cost (the eager figures above are bounded by the host: two launches per step at >= 2.7 us each)'}
+        entry['warm_hipgraph'] = _guarded(f'{name}.warm_hipgraph', graph)
+    if step_bytes(c)[0] < 8 * INFINITY_CACHE_BYTES:      # beyond that one buffer set is cache-cold by itself
+        entry['cold'] = measure_config(c, device, cold=True)
+    if 'reference_published' in c:
+        entry['reference_published'] = c['reference_published']
+        entry['vs_reference_published'] = round(entry['warm']['GiB_s'] / c['reference_published']['GiB_s'], 2)
+    if not args.no_cpu_baseline and name in CPU_SAMPLES:
+        entry['cpu_baseline'] = _guarded(f'{name}.cpu_baseline', lambda: cpu_baseline(name, c, CPU_SAMPLES[name][0]))
+    return entry
+
+
 def add_extras(line, args, device):
     cfg = CONFIGS[args.config]
     _, fb = step_bytes(cfg)
     if not args.no_extras:
-        cold = measure_config(cfg, device, cold=True)
-        line['cold'] = dict(cold, note='same workload, rotating through independent buffer sets so nothing is re-used '
-                                       'from L2 / Infinity Cache; frac = fwd+bwd algorithmic bytes / us_step / 8 TB/s')
-        line['roofline']['frac_cold'] = round(fb / (cold['us_fwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-        line['roofline']['avg_launch_us_cold'] = cold['us_fwd']
-        line['op_level'] = measure_op_level(cfg, device)
-        others = {}
-        for name, c in CONFIGS.items():
-            if name == args.config:
-                continue
-            kf, kb = describe(c)
-            others[name] = {'workload': c['label'], 'bytes_per_step': int(step_bytes(c)[0]),
-                            'kernels': {'fwd': kf['kernel'], 'bwd': kb['kernel'],
-                                        'fwd_shape': {k: kf[k] for k in ('blocks', 'threads', 'chunk')},
-                                        'bwd_shape': {k: kb[k] for k in ('blocks', 'threads', 'chunk')}},
-                            'warm': measure_config(c, device, cold=False)}
-            if step_bytes(c)[0] < (64 << 20):                    # launch-bound size: add the host-free figure
-                try:
-                    us = graph_step_us(c, device)
-                    others[name]['warm_hipgraph'] = {'us_step': round(us, 2), 'GiB_s': round(step_bytes(c)[0] / (us * 1e-6) / 2**30, 1),
-                                                     'frac': round(step_bytes(c)[0] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                     'note': '50 steps captured in one hipGraph, replayed: kernels + their two dependent-launch '
-                                                             'boundaries, no host launch cost (the eager figures above are bounded by the '
-                                                             'host: two launches per step at >= 2.7 us each)'}
-                except Exception as e:  # noqa: BLE001
-                    others[name]['warm_hipgraph'] = {'error': f'{type(e).__name__}: {e}'[:200]}
-            if step_bytes(c)[0] < 8 * INFINITY_CACHE_BYTES:      # beyond that one buffer set is cache-cold by itself
-                others[name]['cold'] = measure_config(c, device, cold=True)
-            if 'reference_published' in c:
-                others[name]['reference_published'] = c['reference_published']
-                others[name]['vs_reference_published'] = round(others[name]['warm']['GiB_s'] / c['reference_published']['GiB_s'], 2)
-            if not args.no_cpu_baseline and name in CPU_SAMPLES:
-                others[name]['cpu_baseline'] = cpu_baseline(name, c, CPU_SAMPLES[name][0])
-        line['configs'] = others
+        cold = _guarded('cold', lambda: measure_config(cfg, device, cold=True))
+        line['cold'] = cold
+        if 'error' not in cold:
+            cold['note'] = ('same workload, rotating through independent buffer sets so nothing is re-used from L2 / Infinity Cache; '
+                            'frac = fwd+bwd algorithmic bytes / us_step / 8 TB/s')
+            line['roofline']['frac_cold'] = round(fb / (cold['us_fwd'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            line['roofline']['avg_launch_us_cold'] = cold['us_fwd']
+        line['op_level'] = _guarded('op_level', lambda: measure_op_level(cfg, device))
+        line['configs'] = {name: _guarded(f'configs.{name}', lambda name=name, c=c: _other_config(name, c, args, device))
+                           for name, c in CONFIGS.items() if name != args.config}
     if not args.no_cpu_baseline:
         reps_all, reps_one = CPU_SAMPLES[args.config]
-        line['cpu_baseline'] = cpu_baseline(args.config, cfg, reps_all)
+        line['cpu_baseline'] = _guarded('cpu_baseline', lambda: cpu_baseline(args.config, cfg, reps_all))
         if reps_one:
-            line['cpu_baseline_1thread'] = cpu_baseline(args.config, cfg, reps_one, threads=1)
+            line['cpu_baseline_1thread'] = _guarded('cpu_baseline_1thread', lambda: cpu_baseline(args.config, cfg, reps_one, threads=1))
 
 
 def parent_launch(args):
