@@ -131,6 +131,16 @@ __device__ unsigned long long g_trace[1 << 17];
 #ifndef FEWBIT_EARLY_ALL
 #define FEWBIT_EARLY_ALL 0    // tuning hook: early head for every kernel, not only the pattern-table forward
 #endif
+#ifndef FEWBIT_SETPRIO
+#define FEWBIT_SETPRIO 0      // tuning hook: raise the wave's issue priority while it computes and stores a tile (s_setprio)
+#endif
+#if FEWBIT_SETPRIO
+#define FEWBIT_PRIO_HI() __builtin_amdgcn_s_setprio(FEWBIT_SETPRIO)
+#define FEWBIT_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define FEWBIT_PRIO_HI() do { } while (0)
+#define FEWBIT_PRIO_LO() do { } while (0)
+#endif
 template <typename Buf, bool EARLY = (FEWBIT_EARLY_ALL != 0), typename Init, typename Load, typename Process>
 __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&load, Process &&process) {
     Buf A, B;
@@ -160,12 +170,16 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
     FEWBIT_STAMP(1);
     int slot = 2;
     for (;;) {
+        FEWBIT_PRIO_HI();
         process(t, A);
+        FEWBIT_PRIO_LO();
         FEWBIT_STAMP(slot); ++slot;
         if (t1 >= s.t_end) break;
         const size_t t2 = t1 + s.stride;
         load(t2 < s.t_end ? t2 : hot, t2 < s.t_end ? s.lane : 0, A);
+        FEWBIT_PRIO_HI();
         process(t1, B);
+        FEWBIT_PRIO_LO();
         FEWBIT_STAMP(slot); ++slot;
         if (t2 >= s.t_end) break;
         t = t2;
@@ -179,12 +193,16 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
     for (;;) {
         const size_t t1 = t + s.stride;
         load(t1 < s.t_end ? t1 : hot, t1 < s.t_end ? s.lane : 0, B);
+        FEWBIT_PRIO_HI();
         process(t, A);
+        FEWBIT_PRIO_LO();
         FEWBIT_STAMP(slot); ++slot;
         if (t1 >= s.t_end) break;
         const size_t t2 = t1 + s.stride;
         load(t2 < s.t_end ? t2 : hot, t2 < s.t_end ? s.lane : 0, A);
+        FEWBIT_PRIO_HI();
         process(t1, B);
+        FEWBIT_PRIO_LO();
         FEWBIT_STAMP(slot); ++slot;
         if (t2 >= s.t_end) break;
         t = t2;
