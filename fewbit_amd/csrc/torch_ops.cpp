@@ -23,6 +23,7 @@
 //   CPU           the same without an autograd node (plain activation), quantize / quantize_backward
 #include <ATen/OpMathType.h>
 #include <ATen/Parallel.h>
+#include <torch/csrc/autograd/variable.h>
 #include <torch/library.h>
 #include <torch/torch.h>
 
@@ -380,6 +381,10 @@ void note_inplace_write(const Tensor &self) {
 // semantics, nothing saved but {state, levels}, no copies.  Returns the undefined tensor when `self` is not such a view.
 Tensor whole_view_base(const Tensor &self) {
     if (!self.is_view()) return Tensor();
+    // only ordinary views: for the kinds autograd refuses to modify in place (outputs of multi-output view ops, views made
+    // under no_grad or inside a custom Function) the general route below keeps raising autograd's own error
+    const auto *meta = torch::autograd::impl::get_view_autograd_meta(self);
+    if (!meta || meta->get_creation_meta() != torch::autograd::CreationMeta::DEFAULT) return Tensor();
     const Tensor base(self._base());      // (TensorBase::_base returns a const TensorBase &)
     if (!base.defined() || !base.requires_grad() || base.is_leaf() || !base.is_contiguous() || !self.is_contiguous() ||
         base.numel() != self.numel() || base.storage_offset() != self.storage_offset() || base.scalar_type() != self.scalar_type() ||

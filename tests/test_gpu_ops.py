@@ -270,6 +270,19 @@ def test_in_place_on_a_view_keeps_in_place_semantics_for_later_users():
     assert torch.allclose(g_view, levels[code] * (w + 5.0))
 
 
+def test_views_autograd_refuses_to_modify_keep_raising():
+    """A whole-tensor view that comes out of a multi-output view op (unbind of a size-1 dimension) covers its base too, but
+    autograd forbids modifying such views in place; the operator must not route around that check."""
+    inner, levels = fewbit.functional.store.get_inner('gelu', 3, torch.device(DEV), torch.float32)
+    r = torch.randn(1, 4096, device=DEV, requires_grad=True)
+    v = (r * 1.0).unbind(0)[0]
+    assert v._is_view() and v.numel() == r.numel()
+    with pytest.raises(RuntimeError, match='view'):
+        torch.ops.fewbit.gelu(v, inner, levels)
+    with pytest.raises(RuntimeError, match='view'):
+        torch.ops.fewbit.relu((r * 1.0).unbind(0)[0])
+
+
 def test_partial_views_take_the_general_route_and_stay_correct():
     """A view that does not cover its whole base (a slice) cannot use the base shortcut: autograd's own in-place-on-view
     machinery (CopySlices) runs, and the result must still be right."""
