@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- forward+backward throughput of the few-bit activation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4] [--no-extras] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4|c4_tensor] [--scaling weak|strong]
+                    [--digests] [--no-extras] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W [--config c4]
 
@@ -11,8 +12,14 @@ backward of fewbit.gelu(bits=3), both through the C-ABI (include/fewbit_hip.h) o
   --config c4            8192x4096 bf16 per GPU = the shard one GPU owns of BASELINE.json configs[3]
                          (4 x (16384x4096) bf16 over 8 GPUs, cut by fewbit_amd.sharding.shard_range)
 
-N > 1: every rank runs the same per-GPU workload on its own shard (weak scaling); the path has NO exchange step, so no
-collective is involved anywhere.  Two ways to start it, same worker code:
+  --config c4_tensor     16384x4096 bf16 = ONE whole tensor of configs[3] (meant for --scaling strong)
+
+N > 1, --scaling weak (default, the driver's contract): every rank runs the same per-GPU workload on its own shard.
+N > 1, --scaling strong: ONE tensor of the config's size (north_star's literal "a 4096x4096 bf16 tensor at 1/2/4/8 GPUs")
+is cut by fewbit_amd.sharding.shard_range over the N ranks; rank r holds exactly elements [begin_r, end_r) of the seeded
+global tensor and runs the path on that slice; `value` = bytes of the WHOLE tensor / the slowest rank's time.  At N = 8
+a rank has 2 Mi elements (4 MiB in, ~4 us kernels): that line measures the launch boundary, and says so.
+The path has NO exchange step, so no collective is involved anywhere.  Two ways to start it, same worker code:
   * `python bench.py --gpus N` by itself: this process starts N fresh children (one per device, the reference's own
     model: benchmark/README.md:18, benchmark/benchmark.py:149-162), BEFORE it touches the GPU; the barriers around the
     timed region are files in a private temporary directory; the parent prints the one JSON line.  A failed rank makes
@@ -20,7 +27,11 @@ collective is involved anywhere.  Two ways to start it, same worker code:
   * under torch.distributed.run: torch.distributed carries the barrier and the max over ranks only -- over gloo (CPU)
     by default, because there is nothing for RCCL to move (FEWBIT_BENCH_BACKEND=nccl uses RCCL for the same two calls).
 Ranks take device `local_rank % device_count`, so more ranks than GPUs share devices (a validation hook for 1-GPU
-boxes; the line then says "shared_gpu": true).
+boxes; the line then says "shared_gpu": true and prices the roofline against the devices actually used).  When there
+are at least as many devices as ranks the ranks' devices must be pairwise distinct, or the run fails.
+A rank that raises writes its traceback to `<sync dir>/error.<rank>`; the parent prints it and exits non-zero.
+`--digests` adds per-rank SHA-256 digests of (y, state, gx) to the line (computed after the timed region): the
+strong-scaling test compares them with slices of the unsharded result (tests/test_gpu_bench.py).
 
 Timed region (the driver's contract): exactly W warm-up steps, barrier + synchronize, host clock, EXACTLY K steps,
 synchronize, host clock, barrier.  `value` / `ms_per_step` = wall time of those K steps, max over ranks.  A second,
@@ -65,6 +76,8 @@ CONFIGS = {
                label='fewbit.gelu bits=3 on 4096x4096 bf16'),
     'c4': dict(fn='gelu', bits=3, rows=8192, cols=4096, dtype='bf16', kind='continuous',
                label='fewbit.gelu bits=3 on 8192x4096 bf16 = one GPU\'s shard of 4x(16384x4096) over 8 GPUs'),
+    'c4_tensor': dict(fn='gelu', bits=3, rows=16384, cols=4096, dtype='bf16', kind='continuous',
+                      label='fewbit.gelu bits=3 on 16384x4096 bf16 = one whole tensor of 4x(16384x4096)'),
     'c1': dict(fn='relu', bits=1, rows=1024, cols=1024, dtype='f32', kind='stepwise1',
                label='fewbit.relu 1-bit on 1024x1024 fp32'),
     'c3_k2': dict(fn='silu', bits=2, rows=8192, cols=8192, dtype='f16', kind='continuous',
@@ -83,7 +96,7 @@ CONFIGS = {
                                               'source': 'notebooks/few-bit-backward/memory-usage-operation-only.py:41,70,80-85'}),
 }
 # bounded CPU-baseline samples per config: (repetitions at all threads, repetitions at one thread); ~25 s of CPU in all
-CPU_SAMPLES = {'c2': (12, 6), 'c4': (5, 0), 'c1': (40, 0), 'c3_k2': (3, 0), 'c3_k4': (3, 0), 'c2_fp32': (6, 0)}
+CPU_SAMPLES = {'c2': (12, 6), 'c4': (5, 0), 'c4_tensor': (3, 0), 'c1': (40, 0), 'c3_k2': (3, 0), 'c3_k4': (3, 0), 'c2_fp32': (6, 0)}
 
 
 def load_tables(cfg, device):
@@ -95,42 +108,48 @@ def load_tables(cfg, device):
     return borders, levels
 
 
-def step_bytes(cfg):
+def step_bytes(cfg, n=None):
+    """(fwd+bwd, fwd only) algorithmic bytes of one step over `n` elements (default: the whole config tensor)"""
     es = torch.empty(0, dtype=DTYPES[cfg['dtype']]).element_size()
-    n = cfg['rows'] * cfg['cols']
+    n = cfg['rows'] * cfg['cols'] if n is None else n
     return n * (4 * es + cfg['bits'] / 4), n * (2 * es + cfg['bits'] / 8)
 
 
-def describe(cfg):
+def describe(cfg, n=None):
     """kernel instantiation + launch shape the library uses for this config on the current device (nothing is launched)"""
     from fewbit_amd import cabi
-    dt, n = DTYPES[cfg['dtype']], cfg['rows'] * cfg['cols']
+    dt, n = DTYPES[cfg['dtype']], (cfg['rows'] * cfg['cols'] if n is None else n)
     if cfg['kind'] == 'continuous':
         return (cabi.describe_forward(cfg['fn'], dt, n, 2 ** cfg['bits'] - 1), cabi.describe_backward(dt, n, 2 ** cfg['bits']))
     return cabi.describe_stepwise1_forward(cfg['fn'], dt, n), cabi.describe_stepwise1_backward(cfg['fn'], dt, n)
 
 
 class Workload:
-    """`nsets` independent buffer sets (x, y, gy, gx, state) of one config with pre-resolved launches per set."""
+    """`nsets` independent buffer sets (x, y, gy, gx, state) of one config with pre-resolved launches per set.
+    `span` = (begin, end): this workload is the slice [begin, end) of the config's flattened tensor (strong scaling);
+    with host seeding the slice holds exactly those elements of the seeded global tensor."""
 
-    def __init__(self, cfg, device, nsets=1, seed=0, host_seeded=True):
+    def __init__(self, cfg, device, nsets=1, seed=0, host_seeded=True, span=None):
         from fewbit_amd import cabi
         dt = DTYPES[cfg['dtype']]
-        n = cfg['rows'] * cfg['cols']
-        self.cfg, self.n, self.nsets = cfg, n, nsets
+        total = cfg['rows'] * cfg['cols']
+        begin, end = span if span is not None else (0, total)
+        n = end - begin
+        shape = (cfg['rows'], cfg['cols']) if span is None else (n,)
+        self.cfg, self.n, self.nsets, self.span = cfg, n, nsets, (begin, end)
         self.fwd, self.bwd, self.keep = [], [], []
         if cfg['kind'] == 'continuous':
             borders, levels = load_tables(cfg, device)
         for i in range(nsets):
             if host_seeded:     # synthetic shard (SURVEY 8d): seeded on the host, then resident in HBM
                 g = torch.Generator().manual_seed(2 * seed + 1000 * i)
-                x = torch.randn(cfg['rows'], cfg['cols'], generator=g).to(dt).to(device)
+                x = torch.randn(total, generator=g).to(dt)[begin:end].reshape(shape).contiguous().to(device)
                 g = torch.Generator().manual_seed(2 * seed + 1 + 1000 * i)
-                gy = torch.randn(cfg['rows'], cfg['cols'], generator=g).to(dt).to(device)
+                gy = torch.randn(total, generator=g).to(dt)[begin:end].reshape(shape).contiguous().to(device)
             else:               # the extra measurements: same distribution, drawn on the device
                 g = torch.Generator(device=device).manual_seed(2 * seed + 1000 * i)
-                x = torch.randn(cfg['rows'], cfg['cols'], generator=g, device=device).to(dt)
-                gy = torch.randn(cfg['rows'], cfg['cols'], generator=g, device=device).to(dt)
+                x = torch.randn(shape, generator=g, device=device).to(dt)
+                gy = torch.randn(shape, generator=g, device=device).to(dt)
             y, gx = torch.empty_like(x), torch.empty_like(x)
             state = torch.empty(cabi.state_nbytes(n, cfg['bits']), dtype=torch.uint8, device=device)
             if cfg['kind'] == 'continuous':
@@ -148,6 +167,14 @@ class Workload:
         for f, b in zip(self.fwd, self.bwd):
             out += [f, b]
         return out
+
+    def digests(self):
+        """SHA-256 of y, state, gx of set 0 as they stand (after at least one step)"""
+        import hashlib
+        torch.cuda.synchronize()
+        _, y, _, gx, state = self.keep[0]
+        return {name: hashlib.sha256(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+                for name, t in (('y', y), ('state', state), ('gx', gx))}
 
 
 def event_time_us(launches, rounds, preroll=1):
@@ -371,6 +398,7 @@ class FileSync:
         while not all(p.exists() for p in names):
             if (self.dir / 'abort').exists() or time.perf_counter() - t0 > self.timeout:
                 raise RuntimeError(f'rank {self.rank}: barrier `{tag}` failed (abort flag or timeout)')
+            time.sleep(0.0005)      # outside the timed region; N ranks x N files must not burn N cores while the slowest sets up
 
     def max(self, values):          # the parent takes the max over the ranks' result files
         return values
@@ -417,10 +445,15 @@ def run_rank(args, rank, local_rank, world, make_sync):
 
     cfg = CONFIGS[args.config]
     n = cfg['rows'] * cfg['cols']
-    # which elements of the (weak-scaled) global tensor this rank owns: documentation of the cut, the data is synthetic
-    begin, end = shard_range(n * world, world, rank)
-    assert end - begin == n
-    w = Workload(cfg, device, nsets=1, seed=rank)
+    if args.scaling == 'strong':
+        # ONE tensor of n elements (seed 0), rank r owns -- and only ever uploads -- elements [begin, end) of it
+        begin, end = shard_range(n, world, rank)
+        w = Workload(cfg, device, nsets=1, seed=0, span=(begin, end))
+    else:
+        # which elements of the (weak-scaled) global tensor this rank owns: documentation of the cut, the data is synthetic
+        begin, end = shard_range(n * world, world, rank)
+        assert end - begin == n
+        w = Workload(cfg, device, nsets=1, seed=rank)
     fwd, bwd = w.fwd[0], w.bwd[0]
 
     t_warm = time.perf_counter()
@@ -465,7 +498,10 @@ def run_rank(args, rank, local_rank, world, make_sync):
     event = e0.elapsed_time(e1) * 1e-3
     wall_max, event_max = sync.max([wall, event])
     res = {'rank': rank, 'device': device.index, 'n_devices': ndev, 'wall_s': wall_max, 'event_s': event_max,
-           'own_wall_s': wall, 'own_event_s': event, 'settle_steps': settle_steps, 'set_bytes': w.set_bytes}
+           'own_wall_s': wall, 'own_event_s': event, 'settle_steps': settle_steps, 'set_bytes': w.set_bytes,
+           'elements': w.n, 'span': [begin, end]}
+    if args.digests:
+        res['sha256'] = w.digests()
     if rank == 0:
         # Per-kernel figures for `roofline`, measured AFTER the contract's region and settled: a GPU that was idle boosts for
         # ~1.5 ms, then runs 8-12 % slower for ~10 ms, then settles (scratch/timeline.py), and a short timed region (the
@@ -480,18 +516,35 @@ def run_rank(args, rank, local_rank, world, make_sync):
         reps = max(400, min(args.steps, 2000))
         res['steady_step_us'] = event_time_us([fwd, bwd], reps, preroll=4)
         res['fwd_us'], res['bwd_us'] = event_time_us([fwd], reps), event_time_us([bwd], reps)
-        res['kernels'] = describe(cfg)
+        res['kernels'] = describe(cfg, w.n)
     return res, sync, device, w
+
+
+METRICS = {
+    'c2': 'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4096x4096 bf16',
+    'c4': 'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4x(16384x4096) bf16 sharded over 8 GPUs (per-GPU shard 8192x4096)',
+    'c4_tensor': 'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, one 16384x4096 bf16 tensor of 4x(16384x4096)',
+}
+
+
+def check_placement(world, n_devices, devices):
+    """With at least as many devices as ranks every rank must have landed on its own device."""
+    if devices is None or world > n_devices:
+        return
+    if len(set(devices)) != len(devices):
+        raise RuntimeError(f'{world} ranks on a box with {n_devices} devices, but they did not land on pairwise distinct devices: {devices}')
 
 
 def build_line(args, world, res, per_rank=None, launcher='single process'):
     cfg = CONFIGS[args.config]
     n = cfg['rows'] * cfg['cols']
-    sb, fb = step_bytes(cfg)
+    strong = args.scaling == 'strong'
+    n_rank0 = res.get('elements', n)                     # rank 0 owns the largest slice (shard_range gives extras to low ranks)
+    sb, _ = step_bytes(cfg)                              # whole config tensor
+    _, fb = step_bytes(cfg, n_rank0)                     # what ONE forward launch of rank 0 moves
     wall, event = res['wall_s'], res['event_s']
-    total = sb * args.steps * world
+    total = sb * args.steps * (1 if strong else world)
     value = total / wall / 2**30
-    step_us = wall / args.steps * 1e6
     event_step_us = event / args.steps * 1e6
     fwd_us, bwd_us = res['fwd_us'], res['bwd_us']
     # forward's duration inside a step: the GPU time of a step (HIP events on the launch stream around a long, settled
@@ -504,7 +557,7 @@ def build_line(args, world, res, per_rank=None, launcher='single process'):
     fwd_in_timed_us = event_step_us * fwd_us / (fwd_us + bwd_us)
     traffic, traffic_source = None, None
     tf = ROOT / 'profiles' / 'traffic_forward.json'
-    if args.config == 'c2' and tf.exists():
+    if args.config == 'c2' and world == 1 and tf.exists():
         try:
             doc = json.loads(tf.read_text())
             traffic = doc.get('hbm_bytes_per_launch')
@@ -514,15 +567,25 @@ def build_line(args, world, res, per_rank=None, launcher='single process'):
             traffic = None
     kf, kb = res['kernels']
     shared = world > res['n_devices']
+    devices_used = min(world, res['n_devices'])          # ranks sharing a GPU share its 8 TB/s too
+    if per_rank:
+        check_placement(world, res['n_devices'], [r['device'] for r in per_rank])
+    if strong:
+        what = (f"ONE {cfg['rows']}x{cfg['cols']} {cfg['dtype']} tensor ({cfg['fn']} bits={cfg['bits']}) cut into {world} slice(s) by "
+                "sharding.shard_range, one slice per GPU")
+        parallelism = f'{world} slice(s) of one {n}-element tensor (largest: {n_rank0} elements), cut by sharding.shard_range, no collectives'
+    else:
+        what = f"{cfg['label']} per GPU"
+        parallelism = f'{world} independent shard(s) of {n} elements, cut by sharding.shard_range, no collectives'
     line = {
-        'metric': 'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4096x4096 bf16' if args.config == 'c2' else
-                  'fwd+bwd GiB/s (and % HBM roofline) for 3-bit GELU, 4x(16384x4096) bf16 sharded over 8 GPUs (per-GPU shard 8192x4096)',
+        'metric': METRICS[args.config],
         'value': round(value, 2), 'unit': 'GiB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(wall / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(wall / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': f"{cfg['label']} per GPU, fused quantize+pack fwd / unpack+mul bwd via the C-ABI, inputs resident in HBM",
-                   'name': args.config, 'elements_per_gpu': n, 'bytes_per_step_per_gpu': int(sb),
-                   'parallelism': f'{world} independent shard(s) of {n} elements, cut by sharding.shard_range, no collectives',
+        'config': {'workload': f"{what}, fused quantize+pack fwd / unpack+mul bwd via the C-ABI, inputs resident in HBM",
+                   'name': args.config, 'elements_per_gpu': n_rank0, 'elements_total': n if strong else n * world,
+                   'bytes_per_step_per_gpu': int(step_bytes(cfg, n_rank0)[0]), 'bytes_per_step_total': int(sb * (1 if strong else world)),
+                   'parallelism': parallelism,
                    'launcher': launcher,
                    'working_set_MiB_per_gpu': round(res['set_bytes'] / 2**20, 1),
                    'cache_state': 'warm: one buffer set re-used every step; it fits the 256 MiB Infinity Cache (see `cold`)'
@@ -536,8 +599,8 @@ def build_line(args, world, res, per_rank=None, launcher='single process'):
                                  'wake-up after the final synchronize (~18 us together, profiles/r03_wall_overhead.txt)',
                    'warmup_settle': (f'{res["settle_steps"]} extra untimed steps until the GPU had been busy {args.settle_ms:g} ms'
                                      if args.settle_ms > 0 else 'off: exactly W warm-up steps')},
-        'pct_of_hbm_roofline': round(100.0 * (total / wall / 1e9) / (HBM_PEAK_GBS * world), 2),
-        'pct_of_hbm_roofline_event_timed': round(100.0 * (total / event / 1e9) / (HBM_PEAK_GBS * world), 2),
+        'pct_of_hbm_roofline': round(100.0 * (total / wall / 1e9) / (HBM_PEAK_GBS * devices_used), 2),
+        'pct_of_hbm_roofline_event_timed': round(100.0 * (total / event / 1e9) / (HBM_PEAK_GBS * devices_used), 2),
         'fwd_us': round(fwd_us, 2), 'bwd_us': round(bwd_us, 2), 'fwd_in_step_us': round(fwd_in_step_us, 2),
         'roofline': {'bound': 'hbm', 'kernel': kf['kernel'], 'launch_shape': {k: kf[k] for k in ('blocks', 'threads', 'blocks_per_cu', 'chunk', 'u')},
                      'other_kernel': kb['kernel'],
@@ -554,13 +617,24 @@ def build_line(args, world, res, per_rank=None, launcher='single process'):
                      'cache_state': 'warm (x and gy are served from the Infinity Cache; writes go to HBM); frac_cold is the figure '
                                     'with nothing cached'},
     }
+    if strong and world > 1:
+        line['roofline']['note'] = (f'rank 0\'s slice ({n_rank0} elements, {int(fb)} B per forward launch): at this size a launch is bounded by the '
+                                    'dispatch boundary (an empty kernel is 2.5-2.7 us), not by HBM')
     if shared:
         line['shared_gpu'] = True
-        line['config']['parallelism'] += f' -- {world} ranks on {res["n_devices"]} visible device(s): ranks SHARE a GPU (validation run)'
+        line['config']['parallelism'] += (f' -- {world} ranks on {res["n_devices"]} visible device(s): ranks SHARE a GPU (validation run; '
+                                          f'pct_of_hbm_roofline is against {devices_used} x 8 TB/s)')
     if per_rank:
         line['per_gpu_us_per_step'] = [round(r['own_wall_s'] / args.steps * 1e6, 2) for r in per_rank]
         line['per_gpu_event_us_per_step'] = [round(r['own_event_s'] / args.steps * 1e6, 2) for r in per_rank]
         line['per_gpu_device'] = [r['device'] for r in per_rank]
+        if all('elements' in r for r in per_rank):
+            line['per_gpu_elements'] = [r['elements'] for r in per_rank]
+        if all('sha256' in r for r in per_rank):
+            line['per_gpu_sha256'] = [r['sha256'] for r in per_rank]
+            line['per_gpu_span'] = [r['span'] for r in per_rank]
+    elif 'sha256' in res:
+        line['per_gpu_sha256'], line['per_gpu_span'] = [res['sha256']], [res['span']]
     line['evidence'] = {'rocprofv3_kernel_stats': 'profiles/r03_bench_kernel_stats.csv (this command with --no-extras)',
                         'pmc_traffic': 'profiles/r03_pmc_traffic.json', 'per_config_rocprofv3_and_pmc': 'profiles/r03_configs.json',
                         'shape_sweeps': 'profiles/r03_shape_sweep_*.txt', 'copy_floor_at_this_size': 'profiles/r03_stream_bench_32MiB.txt',
@@ -616,7 +690,7 @@ def add_extras(line, args, device):
             line['roofline']['avg_launch_us_cold'] = cold['us_fwd']
         line['op_level'] = _guarded('op_level', lambda: measure_op_level(cfg, device))
         line['configs'] = {name: _guarded(f'configs.{name}', lambda name=name, c=c: _other_config(name, c, args, device))
-                           for name, c in CONFIGS.items() if name != args.config}
+                           for name, c in CONFIGS.items() if name not in (args.config, 'c4_tensor')}
     if not args.no_cpu_baseline:
         reps_all, reps_one = CPU_SAMPLES[args.config]
         line['cpu_baseline'] = _guarded('cpu_baseline', lambda: cpu_baseline(args.config, cfg, reps_all))
@@ -634,7 +708,9 @@ def parent_launch(args):
         # FEWBIT_BENCH_WORKER: a stand-in worker script speaking the same protocol (tests/test_bench_launcher.py, no GPU)
         worker = os.environ.get('FEWBIT_BENCH_WORKER') or str(Path(__file__).resolve())
         base = [sys.executable, worker, '--gpus', str(world), '--steps', str(args.steps), '--warmup', str(args.warmup),
-                '--config', args.config, '--settle-ms', str(args.settle_ms), '--sync-dir', str(sync_dir)]
+                '--config', args.config, '--scaling', args.scaling, '--settle-ms', str(args.settle_ms), '--sync-dir', str(sync_dir)]
+        if args.digests:
+            base.append('--digests')
         env = dict(os.environ)
         for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
             env.pop(k, None)
@@ -663,13 +739,18 @@ def parent_launch(args):
                     c.wait(timeout=10)
                 except subprocess.TimeoutExpired:
                     c.kill()
+            for ef in sorted(sync_dir.glob('error.*')):     # the REASON, not just the rank: each child's own traceback
+                sys.stderr.write(f'---- bench.py rank {ef.suffix[1:]} raised ----\n{ef.read_text()}\n')
             sys.exit(f'bench.py: rank {failed[0]} failed ({failed[1]}); no result')
         per_rank = [json.loads((sync_dir / f'result.{r}.json').read_text()) for r in range(world)]
         res = dict(per_rank[0])
         res['wall_s'] = max(r['own_wall_s'] for r in per_rank)
         res['event_s'] = max(r['own_event_s'] for r in per_rank)
-        line = build_line(args, world, res, per_rank,
-                          launcher=f'bench.py started {world} child processes itself (one per device, file barriers, no process group)')
+        try:
+            line = build_line(args, world, res, per_rank,
+                              launcher=f'bench.py started {world} child processes itself (one per device, file barriers, no process group)')
+        except RuntimeError as e:                           # ranks did not land on distinct devices
+            sys.exit(f'bench.py: {e}; no result')
         print(json.dumps(line), flush=True)
     finally:
         shutil.rmtree(sync_dir, ignore_errors=True)
@@ -680,7 +761,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--config', choices=('c2', 'c4'), default='c2', help='headline workload per GPU (see module docstring)')
+    ap.add_argument('--config', choices=('c2', 'c4', 'c4_tensor'), default='c2', help='headline workload per GPU (see module docstring)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak (default, the driver\'s contract): every GPU gets its own tensor of the config\'s size; strong: ONE such tensor '
+                         'is cut over the N GPUs by sharding.shard_range')
+    ap.add_argument('--digests', action='store_true', help='add per-rank SHA-256 of (y, state, gx) to the line (after the timed region)')
     ap.add_argument('--settle-ms', type=float, default=0.0,
                     help='optional: keep issuing untimed warm-up steps until the GPU has been busy this long (default 0 = exactly W '
                          'steps): MI355X drops its clocks 1.5-10 ms after load begins and recovers by ~15 ms (scratch/timeline.py)')
@@ -693,10 +778,17 @@ def main():
 
     if args.worker_rank is not None:                     # a child of parent_launch
         rank, world = args.worker_rank, args.gpus
-        res, sync, device, w = run_rank(args, rank, rank, world, lambda device: FileSync(args.sync_dir, rank, world))
-        tmp = Path(args.sync_dir) / f'result.{rank}.json.tmp'
-        tmp.write_text(json.dumps(res))
-        tmp.rename(Path(args.sync_dir) / f'result.{rank}.json')
+        try:
+            if os.environ.get('FEWBIT_BENCH_INJECT_FAILURE') == str(rank):      # test hook: a rank that raises (tests/test_gpu_bench.py)
+                raise RuntimeError(f'injected failure on rank {rank}')
+            res, sync, device, w = run_rank(args, rank, rank, world, lambda device: FileSync(args.sync_dir, rank, world))
+            tmp = Path(args.sync_dir) / f'result.{rank}.json.tmp'
+            tmp.write_text(json.dumps(res))
+            tmp.rename(Path(args.sync_dir) / f'result.{rank}.json')
+        except BaseException:                            # the parent prints this file: a child's stdout goes nowhere
+            import traceback
+            (Path(args.sync_dir) / f'error.{rank}').write_text(traceback.format_exc())
+            raise
         return
 
     if 'WORLD_SIZE' in os.environ:                       # under torch.distributed.run
@@ -704,15 +796,18 @@ def main():
         args.gpus = world
         if world > 1:
             res, sync, device, w = run_rank(args, rank, local_rank, world, lambda device: TorchSync(rank, world, device))
-            own = torch.tensor([res['own_wall_s'], res['own_event_s'], float(res['device'])], dtype=torch.float64)
-            gathered = [torch.zeros_like(own) for _ in range(world)] if sync.backend != 'nccl' else None
             per_rank = None
-            if gathered is not None:
-                sync.dist.all_gather(gathered, own)
-                per_rank = [{'own_wall_s': float(g[0]), 'own_event_s': float(g[1]), 'device': int(g[2])} for g in gathered]
+            if sync.backend != 'nccl':                  # reporting only (after the timed region): each rank's own figures
+                own = {k: res[k] for k in ('own_wall_s', 'own_event_s', 'device', 'elements', 'span', 'sha256') if k in res}
+                per_rank = [None] * world
+                sync.dist.all_gather_object(per_rank, own)
             if rank == 0:
-                line = build_line(args, world, res, per_rank,
-                                  launcher=f'torch.distributed.run, {world} ranks; {sync.backend} process group for the barrier and the max only')
+                try:
+                    line = build_line(args, world, res, per_rank,
+                                      launcher=f'torch.distributed.run, {world} ranks; {sync.backend} process group for the barrier and the max only')
+                except RuntimeError as e:                   # ranks did not land on distinct devices
+                    sync.close()
+                    sys.exit(f'bench.py: {e}; no result')
                 print(json.dumps(line), flush=True)
             sync.close()
             return

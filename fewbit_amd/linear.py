@@ -24,6 +24,7 @@ constructor / call signatures; the implementation is this repository's own:
 This is PyTorch-level code (GEMM- and FFT-bound); it is outside the quantized-activation hot path that the HIP
 kernels of this package implement.
 """
+import contextlib
 from typing import Optional, Tuple
 
 import torch
@@ -75,8 +76,28 @@ def _replay_rng(token) -> torch.Generator:
     return gen
 
 
+_INJECTED: Optional[torch.Tensor] = None
+
+
+@contextlib.contextmanager
+def inject_sketch(S: torch.Tensor):
+    """Checker hook: inside the block every dense sketch (forward AND backward of ``linear_grp`` with ``'gaussian'`` /
+    ``'rademacher'``) is the given ``p x rows`` matrix instead of a fresh draw.  The fixture tests inject the matrix the
+    reference drew (tests/golden/linear_draw_ref.npz) and compare the weight gradient with the reference's own."""
+    global _INJECTED
+    prev, _INJECTED = _INJECTED, S
+    try:
+        yield
+    finally:
+        _INJECTED = prev
+
+
 def _dense_sketch(kind: str, p: int, rows: int, like: torch.Tensor, gen: torch.Generator,
                   draw_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    if _INJECTED is not None:
+        if tuple(_INJECTED.shape) != (p, rows):
+            raise ValueError(f'injected sketch is {tuple(_INJECTED.shape)}, this call needs {(p, rows)}')
+        return _INJECTED.to(like.device, like.dtype)
     if kind == 'gaussian':
         # drawn in ONE dtype (`draw_dtype`, recorded by the forward) and then cast to the operand: randn's stream depends
         # on the dtype, so a backward whose grad_output has another dtype than the forward's input (autocast) would

@@ -22,20 +22,31 @@ STUB = textwrap.dedent('''
     ap = argparse.ArgumentParser()
     for a in ('--gpus', '--steps', '--warmup', '--worker-rank'):
         ap.add_argument(a, type=int)
-    ap.add_argument('--config'); ap.add_argument('--settle-ms'); ap.add_argument('--sync-dir')
+    ap.add_argument('--config'); ap.add_argument('--settle-ms'); ap.add_argument('--sync-dir'); ap.add_argument('--scaling')
+    ap.add_argument('--digests', action='store_true')
     args = ap.parse_args()
     mode = os.environ.get('STUB_MODE', 'ok')
     rank, world = args.worker_rank, args.gpus
     if mode == 'die_early' and rank == 1:
         sys.exit(3)
+    if mode == 'raise' and rank == 2:
+        try:
+            raise ValueError('the reason rank 2 died')
+        except ValueError:
+            import traceback
+            (Path(args.sync_dir) / f'error.{{rank}}').write_text(traceback.format_exc())
+            raise
     sync = bench.FileSync(args.sync_dir, rank, world, timeout=30.0)
     sync.barrier('start')
     wall = 1e-3 * (1.0 + 0.1 * rank)             # rank r "takes" (1 + 0.1 r) ms for the K steps
     sync.barrier('stop')
     if mode == 'die_late' and rank == world - 1:
         sys.exit(4)
-    res = dict(rank=rank, device=rank, n_devices=world, wall_s=wall, event_s=0.9 * wall, own_wall_s=wall, own_event_s=0.9 * wall,
-               settle_steps=0, set_bytes=140509184)
+    from fewbit_amd.sharding import shard_range
+    n = 4096 * 4096
+    begin, end = shard_range(n, world, rank) if args.scaling == 'strong' else (0, n)
+    res = dict(rank=rank, device=0 if mode == 'same_device' else rank, n_devices=world, wall_s=wall, event_s=0.9 * wall,
+               own_wall_s=wall, own_event_s=0.9 * wall, settle_steps=0, set_bytes=140509184, elements=end - begin, span=[begin, end])
     if rank == 0:
         res.update(fwd_us=12.0, bwd_us=11.0, steady_step_us=23.5,
                    kernels=[dict(kernel='stub_fwd', blocks=1, threads=1, blocks_per_cu=1, chunk=0, u=1, bits=3),
@@ -46,14 +57,14 @@ STUB = textwrap.dedent('''
 ''')
 
 
-def _run(tmp_path, mode, gpus=4, steps=20):
+def _run(tmp_path, mode, gpus=4, steps=20, extra=()):
     stub = tmp_path / 'stub_worker.py'
     stub.write_text(STUB.format(root=str(ROOT)))
     env = dict(os.environ, FEWBIT_BENCH_WORKER=str(stub), STUB_MODE=mode)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
         env.pop(k, None)
     return subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', str(gpus), '--steps', str(steps), '--warmup', '5',
-                           '--launch-timeout', '60'], env=env, capture_output=True, text=True, timeout=120)
+                           '--launch-timeout', '60', *extra], env=env, capture_output=True, text=True, timeout=120)
 
 
 def test_parent_starts_one_child_per_gpu_and_prints_one_line(tmp_path):
@@ -80,6 +91,44 @@ def test_a_failed_rank_makes_the_parent_fail(tmp_path, mode):
     assert r.stdout.strip() == ''                     # no result line from a broken run
     assert 'failed' in r.stderr
     assert time.time() - t0 < 60                      # the survivors are released by the abort flag, not by their timeout
+
+
+def test_eight_children_weak(tmp_path):
+    r = _run(tmp_path, 'ok', gpus=8, steps=20)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip())
+    assert line['n_gpus'] == 8 and line['per_gpu_device'] == list(range(8)) and 'shared_gpu' not in line
+    assert line['value'] == pytest.approx(8 * 20 * 146800640 / (1e-3 * 1.7) / 2**30, rel=1e-3)
+    assert line['pct_of_hbm_roofline'] == pytest.approx(100 * 8 * 20 * 146800640 / (1e-3 * 1.7) / 1e9 / (8 * 8000.0), rel=1e-3)
+
+
+@pytest.mark.parametrize('gpus', (2, 4, 8))
+def test_strong_scaling_line_is_one_tensor_over_n_ranks(tmp_path, gpus):
+    """--scaling strong: the bytes of ONE 4096x4096 tensor / the slowest rank; every rank reports its slice."""
+    r = _run(tmp_path, 'ok', gpus=gpus, steps=20, extra=('--scaling', 'strong'))
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip())
+    n = 4096 * 4096
+    assert line['scaling'] == 'strong' and line['n_gpus'] == gpus
+    assert sum(line['per_gpu_elements']) == n and line['config']['elements_total'] == n
+    assert line['config']['elements_per_gpu'] == n // gpus == max(line['per_gpu_elements'])
+    assert line['config']['bytes_per_step_total'] == 146800640
+    slowest = 1e-3 * (1.0 + 0.1 * (gpus - 1))
+    assert line['value'] == pytest.approx(20 * 146800640 / slowest / 2**30, rel=1e-3)       # NOT multiplied by the rank count
+    assert line['roofline']['algorithmic_bytes_per_launch'] == (n // gpus) * (2 * 2 + 3 / 8)
+
+
+def test_the_parent_prints_a_childs_traceback(tmp_path):
+    r = _run(tmp_path, 'raise', gpus=4)
+    assert r.returncode != 0 and r.stdout.strip() == ''
+    assert 'bench.py rank 2 raised' in r.stderr and 'ValueError: the reason rank 2 died' in r.stderr
+    assert 'rank 2 failed' in r.stderr
+
+
+def test_ranks_on_the_same_device_of_a_big_enough_box_fail(tmp_path):
+    r = _run(tmp_path, 'same_device', gpus=4)          # 4 devices reported, all ranks claim device 0
+    assert r.returncode != 0 and r.stdout.strip() == ''
+    assert 'pairwise distinct' in r.stderr
 
 
 def test_file_barrier_orders_phases(tmp_path):

@@ -1,6 +1,7 @@
 """The driver-facing contract of bench.py on hardware: one JSON line with the fields the driver reads, for N = 1 and for the
-self-launched N = 2 (two ranks sharing this box's GPU).  The timed region is tiny (--steps 5); what is checked is the shape
-of the line and the internal consistency of its numbers, not performance."""
+self-launched N = 2 / 8 (ranks sharing this box's GPU when it has fewer devices).  The timed region is tiny (--steps 5); what
+is checked is the shape of the line and the internal consistency of its numbers, not performance.  --scaling strong: the
+ranks' result bytes (SHA-256 per rank) must be the slices of the unsharded result."""
 import json
 import os
 import subprocess
@@ -16,25 +17,31 @@ CONTRACT = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step
             'dtype', 'data', 'config')
 
 
-def _bench(*args):
-    env = dict(os.environ)
+def _bench_raw(*args, **extra_env):
+    env = dict(os.environ, **extra_env)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), *args], env=env, capture_output=True, text=True, timeout=600)
+    return subprocess.run([sys.executable, str(ROOT / 'bench.py'), *args], env=env, capture_output=True, text=True, timeout=900)
+
+
+def _bench(*args):
+    r = _bench_raw(*args)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     return json.loads(lines[0])
 
 
-def _check_contract(line, n_gpus, steps, warmup):
+def _check_contract(line, n_gpus, steps, warmup, scaling='weak'):
     for key in CONTRACT:
         assert key in line, key
     assert line['n_gpus'] == n_gpus and line['steps'] == steps and line['warmup'] == warmup
-    assert line['unit'] == 'GiB/s' and line['higher_is_better'] is True and line['scaling'] == 'weak' and line['vs_baseline'] is None
+    assert line['unit'] == 'GiB/s' and line['higher_is_better'] is True and line['scaling'] == scaling and line['vs_baseline'] is None
     assert line['dtype'] == 'bf16' and line['data'] == 'synthetic' and 'workload' in line['config'] and 'model' not in line['config']
     # value is the whole job: bytes of ALL ranks / the reported time per step
-    total = line['config']['bytes_per_step_per_gpu'] * n_gpus
+    total = line['config']['bytes_per_step_total']
+    if scaling == 'weak':
+        assert total == line['config']['bytes_per_step_per_gpu'] * n_gpus
     assert line['value'] == pytest.approx(total / (line['ms_per_step'] * 1e-3) / 2**30, rel=2e-3)
     assert 0.0 < line['pct_of_hbm_roofline'] < 100.0
     roof = line['roofline']
@@ -59,3 +66,53 @@ def test_self_launched_ranks_line():
     if torch.cuda.device_count() < 2:
         assert line.get('shared_gpu') is True
     assert 'started 2 child processes itself' in line['config']['launcher']
+
+
+def test_eight_self_launched_ranks_line():
+    """the launch path the 8-GPU lease will take (python bench.py --gpus 8): 8 children, file barriers, one line"""
+    line = _bench('--gpus', '8', '--steps', '5', '--warmup', '2')
+    _check_contract(line, 8, 5, 2)
+    assert len(line['per_gpu_us_per_step']) == 8 and len(line['per_gpu_device']) == 8
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev >= 8:
+        assert sorted(line['per_gpu_device']) == list(range(8)) and 'shared_gpu' not in line
+    else:
+        assert line.get('shared_gpu') is True and set(line['per_gpu_device']) <= set(range(ndev))
+
+
+def test_a_failing_rank_shows_its_traceback():
+    r = _bench_raw('--gpus', '2', '--steps', '5', '--warmup', '2', '--launch-timeout', '300', FEWBIT_BENCH_INJECT_FAILURE='1')
+    assert r.returncode != 0 and r.stdout.strip() == ''
+    assert 'bench.py rank 1 raised' in r.stderr and 'RuntimeError: injected failure on rank 1' in r.stderr
+
+
+@pytest.mark.parametrize('gpus', (1, 2))
+def test_strong_scaling_bytes_are_slices_of_the_unsharded_result(gpus):
+    """--scaling strong --digests: rank r's (y, state, gx) are bit for bit the slices [begin_r, end_r) of what ONE launch over
+    the whole seeded 4096x4096 tensor gives (computed here, in this process, through the same C-ABI)."""
+    import hashlib
+    import torch
+    from fewbit_amd import cabi
+    from fewbit_amd.sharding import shard_range, state_range
+    import bench
+    line = _bench('--gpus', str(gpus), '--steps', '5', '--warmup', '2', '--scaling', 'strong', '--digests', '--no-extras', '--no-cpu-baseline')
+    _check_contract(line, gpus, 5, 2, scaling='strong')
+    cfg = bench.CONFIGS['c2']
+    n = cfg['rows'] * cfg['cols']
+    assert line['config']['elements_total'] == n and sum(s[1] - s[0] for s in line['per_gpu_span']) == n
+    x = torch.randn(n, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16).cuda()
+    gy = torch.randn(n, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+    borders, levels = bench.load_tables(cfg, 'cuda')
+    y, state = cabi.quantize_forward('gelu', x, borders)
+    gx = cabi.quantize_backward(gy, state, levels)
+
+    def sha(t):
+        return hashlib.sha256(t.cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+
+    for r in range(gpus):
+        b, e = shard_range(n, gpus, r)
+        assert line['per_gpu_span'][r] == [b, e]
+        sb, se = state_range(b, e, cfg['bits'])
+        got = line['per_gpu_sha256'][r]
+        assert got['y'] == sha(y[b:e]) and got['gx'] == sha(gx[b:e]) and got['state'] == sha(state[sb:se]), f'rank {r}'

@@ -1,0 +1,72 @@
+"""SURVEY 8(f)#4 on the GPU against fixtures made by RUNNING THE REFERENCE (tests/golden/gen_linear_golden.py):
+everything deterministic of the randomized linear layers -- forward, input gradient, bias gradient, DCT / IDCT, and the
+weight gradient once the reference's own sketch matrix is injected -- computed on cuda:0 and compared with the reference's
+numbers.  Tolerance: fp32 GEMMs / FFTs in another summation order, relative to the largest entry (stated per check)."""
+import numpy as np
+import pytest
+import torch
+
+import fewbit
+from helpers import GOLDEN
+from test_linear import check_injected_draws
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def lref():
+    with np.load(GOLDEN / 'linear_ref.npz') as z:
+        return {k: torch.from_numpy(z[k].copy()) for k in z.files}
+
+
+def rel_err(got, want):
+    return float((got.detach().cpu() - want).abs().max() / want.abs().max())
+
+
+def test_weight_gradient_with_the_reference_sketch_on_the_gpu():
+    """gaussian and rademacher, three shapes (one 3-D): y, gx, gb, gw vs the reference run, fp32, rtol 2e-4 of the largest entry"""
+    assert check_injected_draws(DEV, rtol=2e-4) == 24
+
+
+def test_deterministic_outputs_of_every_estimator_on_the_gpu(lref):
+    """linear_grp (4 sketches) and linear_crs: forward, input gradient and bias gradient do not depend on the draw"""
+    x, w, b, gy = (lref[k].to(DEV) for k in ('lin_x', 'lin_w', 'lin_b', 'lin_gy'))
+    p, nopairs = int(lref['lin_proj_dim']), int(lref['crs_nopairs'])
+    calls = [(f'grp_{kind}', lambda xi, wi, bi, kind=kind: fewbit.functional.linear_grp(xi, wi, bi, proj_dim=p, matmul=kind))
+             for kind in ('gaussian', 'rademacher', 'dct')]
+    calls.append(('crs', lambda xi, wi, bi: fewbit.functional.linear_crs(xi, wi, bi, nopairs)))
+    for name, call in calls:
+        xi, wi, bi = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        y = call(xi, wi, bi)
+        y.backward(gy)
+        assert y.device.type == 'cuda' and wi.grad.shape == w.shape
+        for got, key in ((y, 'y'), (xi.grad, 'gx'), (bi.grad, 'gb')):
+            assert rel_err(got, lref[f'{name}_{key}']) <= 1e-5, (name, key)
+
+
+def test_dct_and_idct_on_the_gpu(lref):
+    """float64 inputs; the reference's twiddles are complex64 (fewbit/fft.py:28-29), so it is single-precision accurate: 1e-6"""
+    for i in range(5):
+        x, dim = lref[f'dct{i}_x'].to(DEV), int(lref[f'dct{i}_dim'])
+        for norm in ('backward', 'ortho'):
+            assert rel_err(fewbit.fft.dct(x, dim=dim, norm=norm), lref[f'dct{i}_{norm}']) <= 1e-6
+        assert rel_err(fewbit.fft.idct(x, dim=dim, norm='ortho'), lref[f'idct{i}_ortho']) <= 1e-6
+
+
+def test_estimator_statistics_on_the_gpu(lref):
+    """the Gaussian and Rademacher estimators drawn ON THE DEVICE: mean = exact gradient, mean squared deviation = the
+    reference's (4000 reference draws in the fixture; 600 here: +-10 %)"""
+    x, w, b, gy = (lref[k].to(DEV) for k in ('lin_x', 'lin_w', 'lin_b', 'lin_gy'))
+    exact = lref['lin_exact_gw'].to(DEV)
+    p, draws = int(lref['lin_proj_dim']), 600
+    torch.manual_seed(5)
+    for kind in ('gaussian', 'rademacher'):
+        acc, msd = torch.zeros_like(exact), 0.0
+        for _ in range(draws):
+            wi = w.clone().requires_grad_()
+            fewbit.functional.linear_grp(x, wi, b, proj_dim=p, matmul=kind).backward(gy)
+            acc += wi.grad
+            msd += float(((wi.grad - exact)**2).sum())
+        assert float(torch.linalg.norm(acc / draws - exact) / torch.linalg.norm(exact)) <= 0.12, kind
+        assert abs(msd / draws / float(lref[f'grp_{kind}_msd']) - 1.0) <= 0.12, (kind, msd / draws, float(lref[f'grp_{kind}_msd']))

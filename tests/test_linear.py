@@ -227,3 +227,36 @@ def test_randomized_linear_against_the_reference_run(lref):
     for got, key in zip(first, ('y', 'gx', 'gb')):
         assert torch.allclose(got, torch.from_numpy(lref[f'crs_{key}']), rtol=1e-5, atol=1e-5), key
     assert abs(msd / float(lref['crs_msd']) - 1.0) <= 0.10
+
+
+# ---- single draws with the reference's own sketch matrix injected (tests/golden/gen_linear_golden.py draw) ----------------
+def check_injected_draws(device, rtol=2e-4):
+    """Shared by the CPU test below and the -m gpu test (tests/test_gpu_linear.py): with the matrix the reference drew,
+    forward, input gradient, bias gradient AND the weight gradient equal the reference's up to fp32 GEMM rounding
+    (rtol on the largest entry: the products are sums of <= 256 fp32 terms in another order)."""
+    import numpy as np
+    from helpers import GOLDEN
+    from fewbit_amd.linear import inject_sketch
+    with np.load(GOLDEN / 'linear_draw_ref.npz') as z:
+        ref = {k: torch.from_numpy(z[k].copy()) for k in z.files}
+    checked = 0
+    for name in ('small', 'mid', 'ragged'):
+        p = int(ref[f'{name}_p'])
+        for kind in ('gaussian', 'rademacher'):
+            S = ref[f'{name}_{kind}_S']
+            if kind == 'rademacher':
+                S = 2 * S - 1                               # the reference keeps {0,1} - 0.5 and folds the 4 into the scale
+            x, w, b = (ref[f'{name}_{k}'].to(device).requires_grad_() for k in ('x', 'w', 'b'))
+            with inject_sketch(S.to(device)):
+                y = linear_grp(x, w, b, proj_dim=p, matmul=kind)
+                y.backward(ref[f'{name}_gy'].to(device))
+            for got, key in ((y.detach(), 'y'), (x.grad, 'gx'), (b.grad, 'gb'), (w.grad, 'gw')):
+                want = ref[f'{name}_{kind}_{key}']
+                err = float((got.cpu() - want).abs().max() / want.abs().max())
+                assert got.device.type == torch.device(device).type and err <= rtol, (name, kind, key, err)
+                checked += 1
+    return checked
+
+
+def test_single_draws_with_the_reference_sketch_injected():
+    assert check_injected_draws('cpu', rtol=1e-5) == 24
