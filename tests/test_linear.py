@@ -246,7 +246,7 @@ def check_injected_draws(device, rtol=2e-4):
             S = ref[f'{name}_{kind}_S']
             if kind == 'rademacher':
                 S = 2 * S - 1                               # the reference keeps {0,1} - 0.5 and folds the 4 into the scale
-            x, w, b = (ref[f'{name}_{k}'].to(device).requires_grad_() for k in ('x', 'w', 'b'))
+            x, w, b = (ref[f'{name}_{k}'].clone().to(device).requires_grad_() for k in ('x', 'w', 'b'))
             with inject_sketch(S.to(device)):
                 y = linear_grp(x, w, b, proj_dim=p, matmul=kind)
                 y.backward(ref[f'{name}_gy'].to(device))
