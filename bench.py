@@ -447,7 +447,9 @@ def run_rank(args, rank, local_rank, world, make_sync):
     n = cfg['rows'] * cfg['cols']
     if args.scaling == 'strong':
         # ONE tensor of n elements (seed 0), rank r owns -- and only ever uploads -- elements [begin, end) of it
-        begin, end = shard_range(n, world, rank)
+        # (--emulate-world M on one GPU: rank 0's slice of an M-way cut, alone on the device -- what each of M separate
+        # GPUs would run, since nothing is shared between ranks)
+        begin, end = shard_range(n, args.emulate_world or world, rank)
         w = Workload(cfg, device, nsets=1, seed=0, span=(begin, end))
     else:
         # which elements of the (weak-scaled) global tensor this rank owns: documentation of the cut, the data is synthetic
@@ -617,7 +619,18 @@ def build_line(args, world, res, per_rank=None, launcher='single process'):
                      'cache_state': 'warm (x and gy are served from the Infinity Cache; writes go to HBM); frac_cold is the figure '
                                     'with nothing cached'},
     }
-    if strong and world > 1:
+    if strong and args.emulate_world:
+        m = args.emulate_world
+        line['emulated_world'] = m
+        line['projected'] = {'n_gpus': m, 'value_GiB_s': round(sb * args.steps / wall / 2**30, 2),
+                             'pct_of_hbm_roofline': round(100.0 * (sb * args.steps / wall / 1e9) / (HBM_PEAK_GBS * m), 2),
+                             'note': f'this GPU ran rank 0\'s slice ({n_rank0} of {n} elements) of a {m}-way cut ALONE; the path has no exchange step, so {m} '
+                                     f'separate GPUs each take this time for their slice: projected whole-tensor rate = {int(sb)} B / this time. '
+                                     'A projection from one device, not a measurement on several.'}
+        line['value'] = round(step_bytes(cfg, n_rank0)[0] * args.steps / wall / 2**30, 2)     # what THIS device did
+        line['pct_of_hbm_roofline'] = round(100.0 * (step_bytes(cfg, n_rank0)[0] * args.steps / wall / 1e9) / HBM_PEAK_GBS, 2)
+        line['config']['bytes_per_step_total'] = int(step_bytes(cfg, n_rank0)[0])
+    if strong and (world > 1 or args.emulate_world):
         line['roofline']['note'] = (f'rank 0\'s slice ({n_rank0} elements, {int(fb)} B per forward launch): at this size a launch is bounded by the '
                                     'dispatch boundary (an empty kernel is 2.5-2.7 us), not by HBM')
     if shared:
@@ -765,6 +778,9 @@ def main():
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='weak (default, the driver\'s contract): every GPU gets its own tensor of the config\'s size; strong: ONE such tensor '
                          'is cut over the N GPUs by sharding.shard_range')
+    ap.add_argument('--emulate-world', type=int, default=0,
+                    help='with --gpus 1 --scaling strong: run rank 0\'s slice of an M-way cut alone on this GPU and add the projected '
+                         'M-GPU figure to the line (a projection, labelled so)')
     ap.add_argument('--digests', action='store_true', help='add per-rank SHA-256 of (y, state, gx) to the line (after the timed region)')
     ap.add_argument('--settle-ms', type=float, default=0.0,
                     help='optional: keep issuing untimed warm-up steps until the GPU has been busy this long (default 0 = exactly W '
@@ -776,6 +792,8 @@ def main():
     ap.add_argument('--launch-timeout', type=float, default=900.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.emulate_world and (args.gpus != 1 or args.scaling != 'strong' or 'WORLD_SIZE' in os.environ):
+        ap.error('--emulate-world needs --gpus 1 --scaling strong and no launcher')
     if args.worker_rank is not None:                     # a child of parent_launch
         rank, world = args.worker_rank, args.gpus
         try:

@@ -43,7 +43,9 @@ def _check_contract(line, n_gpus, steps, warmup, scaling='weak'):
     if scaling == 'weak':
         assert total == line['config']['bytes_per_step_per_gpu'] * n_gpus
     assert line['value'] == pytest.approx(total / (line['ms_per_step'] * 1e-3) / 2**30, rel=2e-3)
-    assert 0.0 < line['pct_of_hbm_roofline'] < 100.0
+    # (ranks sharing ONE device also share its 256 MiB Infinity Cache: two warm 134 MiB working sets read x and gy from the
+    # cache, so the algorithmic rate can exceed the HBM peak there -- seen: 107 %; never on a device of its own)
+    assert 0.0 < line['pct_of_hbm_roofline'] < (100.0 if not line.get('shared_gpu') else 250.0)
     roof = line['roofline']
     for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel'):
         assert key in roof, key
@@ -85,6 +87,13 @@ def test_a_failing_rank_shows_its_traceback():
     r = _bench_raw('--gpus', '2', '--steps', '5', '--warmup', '2', '--launch-timeout', '300', FEWBIT_BENCH_INJECT_FAILURE='1')
     assert r.returncode != 0 and r.stdout.strip() == ''
     assert 'bench.py rank 1 raised' in r.stderr and 'RuntimeError: injected failure on rank 1' in r.stderr
+
+
+def test_emulated_world_line_projects_from_one_slice():
+    line = _bench('--gpus', '1', '--scaling', 'strong', '--emulate-world', '8', '--steps', '20', '--warmup', '5', '--no-extras', '--no-cpu-baseline')
+    assert line['n_gpus'] == 1 and line['emulated_world'] == 8 and line['config']['elements_per_gpu'] == 4096 * 4096 // 8
+    assert line['projected']['n_gpus'] == 8 and line['projected']['value_GiB_s'] == pytest.approx(8 * line['value'], rel=1e-3)
+    assert 0 < line['projected']['pct_of_hbm_roofline'] < 100
 
 
 @pytest.mark.parametrize('gpus', (1, 2))
