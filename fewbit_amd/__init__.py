@@ -14,7 +14,8 @@ from warnings import warn
 
 import torch
 
-_NATIVE_PATH = Path(__file__).resolve().with_name('libfewbit.so')
+# FEWBIT_OPS_LIB: another build of the SAME operator library (e.g. the public-API-only test build), not a fallback
+_NATIVE_PATH = Path(getenv('FEWBIT_OPS_LIB') or Path(__file__).resolve().with_name('libfewbit.so'))
 _native_error = 'not attempted'
 _native_loaded = False
 
@@ -39,6 +40,34 @@ def load_native(path=None) -> bool:
     except Exception as e:  # noqa: BLE001  -- OSError, RuntimeError, AttributeError all mean "not available"
         _native_error = f'{type(e).__name__}: {e}'
     return _native_loaded
+
+
+def autograd_route(name: str, on=None) -> bool:
+    """Query (``on=None``) or set one of the operator library's autograd routes: ``'direct_node'`` (hand-written backward
+    node instead of a ``torch::autograd::Function``), ``'base_dirty'`` (in place on a whole-tensor view modifies the base)
+    and ``'fresh_view'`` (that call returns a new view of the base).  Returns the previous setting.  All routes give the
+    same values, gradients and saved bytes (fewbit_amd/csrc/torch_ops.cpp, header comment); the switches exist so that the
+    public-API fallback stays tested.  Environment: ``FEWBIT_NO_DIRECT_NODE`` / ``FEWBIT_NO_BASE_DIRTY`` /
+    ``FEWBIT_NO_FRESH_VIEW`` = 1."""
+    import ctypes
+    if not _native_loaded:
+        raise RuntimeError(f'operator library not loaded: {_native_error}')
+    lib = ctypes.CDLL(str(_NATIVE_PATH))
+    lib.fewbit_torch_route.argtypes, lib.fewbit_torch_route.restype = [ctypes.c_char_p, ctypes.c_int], ctypes.c_int
+    prev = lib.fewbit_torch_route(name.encode(), -1 if on is None else int(bool(on)))
+    if prev == -1:
+        raise KeyError(name)
+    if prev == -2:
+        raise RuntimeError(f'route {name!r} needs a library built with FEWBIT_AUTOGRAD_INTERNALS=1')
+    return bool(prev)
+
+
+def autograd_internals() -> bool:
+    """Was the operator library built with the internal-API autograd routes (only for the torch release it was verified on)?"""
+    import ctypes
+    lib = ctypes.CDLL(str(_NATIVE_PATH))
+    lib.fewbit_torch_autograd_internals.restype = ctypes.c_int
+    return bool(lib.fewbit_torch_autograd_internals())
 
 
 if getenv('FEWBIT_NATIVE') not in ('0', 'no', 'false'):

@@ -17,17 +17,47 @@
 //   CUDA          the same launches without an autograd node (torch.inference_mode(), where the Autograd keys are
 //                 excluded); quantize / quantize_backward
 //   AutogradCPU   host tensors: this file's own ATen-level implementation with the same PACKED state (section "host
-//                 tensors" below); OUT OF PLACE and layout-agnostic like the reference's host operator.  The reference registers `gelu` only, as an autograd Function under the CPU key
-//                 (fewbit/cpu/gelu.cc:47-76), plus quantize / quantize_backward (fewbit/fewbit.cc:6-7); here every
-//                 operator has one.  Product code; it never touches oracle/.
+//                 tensors" below), layout-agnostic like the reference's host operator.  The reference registers `gelu`
+//                 only, as an autograd Function under the CPU key (fewbit/cpu/gelu.cc:47-76), plus quantize /
+//                 quantize_backward (fewbit/fewbit.cc:6-7); here every operator has one.  In-place rule on the host:
+//                 `gelu` returns a FRESH tensor and leaves its input intact -- that is what the reference's host operator
+//                 does whatever its schema says (fewbit/cpu/gelu.cc:7-31), pinned by tests/test_host_ops.py; every OTHER
+//                 operator (no reference host implementation to match) honours its `Tensor(a!)` schema: the result is
+//                 written into `self`, which is returned, exactly as on the GPU.  Product code; it never touches oracle/.
 //   CPU           the same without an autograd node (plain activation), quantize / quantize_backward
+//
+// Autograd plumbing, two routes with identical results (tests: both give the same bytes and gradients):
+//   direct    one hand-written torch::autograd::Node per call (PackedBackwardNode below) wired the way ATen's generated
+//             code wires its own (check_inplace / collect_next_edges / rebase_history / set_history): ~3 us less host
+//             time per forward+backward than a torch::autograd::Function.  These helpers -- and the view meta data that
+//             `whole_view_base` reads -- are internal headers of libtorch, so the route is compiled only for the torch
+//             release it was written and tested against (FEWBIT_AUTOGRAD_INTERNALS, see below).
+//   portable  torch::autograd::Function (public API only): every other torch release, -DFEWBIT_AUTOGRAD_INTERNALS=0, or at
+//             run time FEWBIT_NO_DIRECT_NODE=1 / FEWBIT_NO_BASE_DIRTY=1 (or fewbit_torch_route(), bottom of this file).
 #include <ATen/OpMathType.h>
 #include <ATen/Parallel.h>
 #include <torch/csrc/autograd/variable.h>
 #include <torch/library.h>
 #include <torch/torch.h>
 
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+// The internal-API routes are tied to the release they were verified against: another torch falls back to the public
+// API at compile time instead of building against headers that may have changed meaning.
+#ifndef FEWBIT_AUTOGRAD_INTERNALS
+#if defined(TORCH_VERSION_MAJOR) && TORCH_VERSION_MAJOR == 2 && TORCH_VERSION_MINOR == 10
+#define FEWBIT_AUTOGRAD_INTERNALS 1
+#else
+#define FEWBIT_AUTOGRAD_INTERNALS 0
+#endif
+#endif
+#if FEWBIT_AUTOGRAD_INTERNALS
+#include <torch/csrc/autograd/VariableTypeUtils.h>     // check_inplace, rebase_history, increment_version
+#include <torch/csrc/autograd/functions/utils.h>       // set_history, collect_next_edges
+#endif
 
 // ROCm builds of PyTorch expose HIP devices as device type `cuda`; these are the matching guard / stream types
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
@@ -113,16 +143,54 @@ Tensor launch_dequantize(const Tensor &grad, const Tensor &state, const Tensor &
     return gx;
 }
 
-// ---- autograd Functions --------------------------------------------------------------------------
+// 1-bit family: y = fn(self) into `out` (may be `self`); returns the packed bits
+Tensor launch_step1(int fn, const Tensor &self, Tensor &out, double p0, double p1) {
+    check_input(self, "self");
+    Tensor state = new_state(self, self.numel(), 1);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(self.device());
+    check_status(fewbit_hip_stepwise1_forward(fn, dtype_code(self), self.data_ptr(), out.data_ptr(), state.data_ptr<uint8_t>(),
+                                              static_cast<size_t>(self.numel()), p0, p1, current_stream(self)),
+                 "stepwise1_forward");
+    return state;
+}
+
+Tensor launch_step1_backward(int fn, const Tensor &grad, const Tensor &state, double p0) {
+    Tensor gy = grad.contiguous();
+    check_input(gy, "grad_output");
+    Tensor gx = torch::empty_like(gy);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(gy.device());
+    check_status(fewbit_hip_stepwise1_backward(fn, dtype_code(gy), gy.data_ptr(), state.data_ptr<uint8_t>(), gx.data_ptr(),
+                                               static_cast<size_t>(gy.numel()), p0, current_stream(gy)),
+                 "stepwise1_backward");
+    return gx;
+}
+
+// ---- run-time route switches (see the header comment) ---------------------------------------------------------------
+namespace route {
+enum Which { DirectNode, BaseDirty, FreshView, Count };
+constexpr const char *kNames[Count] = {"direct_node", "base_dirty", "fresh_view"};
+constexpr const char *kOffEnv[Count] = {"FEWBIT_NO_DIRECT_NODE", "FEWBIT_NO_BASE_DIRTY", "FEWBIT_NO_FRESH_VIEW"};
+constexpr bool kNeedsInternals[Count] = {true, true, false};
+std::atomic<int> g_state[Count] = {{-1}, {-1}, {-1}};      // -1: not read yet (environment decides on first use)
+
+bool on(Which w) {
+    if (kNeedsInternals[w] && !FEWBIT_AUTOGRAD_INTERNALS) return false;
+    int v = g_state[w].load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = std::getenv(kOffEnv[w]);
+        v = (e && *e && std::strcmp(e, "0") != 0) ? 0 : 1;
+        g_state[w].store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+}  // namespace route
+
+// ---- autograd, portable route: torch::autograd::Function (public API only) ---------------------------------------------
 
 // all 13 continuous activations (+ custom `stepwise` tables): state and levels are what is saved
 struct ContinuousFunction : public torch::autograd::Function<ContinuousFunction> {
     static Tensor forward(AutogradContext *ctx, Tensor self, const Tensor &bounds, const Tensor &levels, int64_t fn,
                           double p0, double p1, bool inplace) {
-        TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
-                    "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(),
-                    " and ", levels.numel());
-        check_table(self, levels, "levels");
         Tensor out = inplace ? self : torch::empty_like(self);
         Tensor state = launch_quantize(static_cast<int>(fn), self, out, bounds, p0, p1);
         if (inplace) ctx->mark_dirty({self});
@@ -142,12 +210,7 @@ struct Stepwise1Function : public torch::autograd::Function<Stepwise1Function> {
     static Tensor forward(AutogradContext *ctx, Tensor self, int64_t fn, double p0, double p1, bool inplace) {
         check_input(self, "self");
         Tensor out = inplace ? self : torch::empty_like(self);
-        Tensor state = new_state(self, self.numel(), 1);
-        c10::hip::HIPGuardMasqueradingAsCUDA guard(self.device());
-        check_status(fewbit_hip_stepwise1_forward(static_cast<int>(fn), dtype_code(self), self.data_ptr(), out.data_ptr(),
-                                                  state.data_ptr<uint8_t>(), static_cast<size_t>(self.numel()), p0, p1,
-                                                  current_stream(self)),
-                     "stepwise1_forward");
+        Tensor state = launch_step1(static_cast<int>(fn), self, out, p0, p1);
         if (inplace) ctx->mark_dirty({self});
         ctx->save_for_backward({state});
         ctx->saved_data["fn"] = fn;
@@ -159,15 +222,7 @@ struct Stepwise1Function : public torch::autograd::Function<Stepwise1Function> {
         const auto saved = ctx->get_saved_variables();
         const auto fn = ctx->saved_data["fn"].toInt();
         const auto p0 = ctx->saved_data["p0"].toDouble();
-        Tensor gy = grad_output[0].contiguous();
-        check_input(gy, "grad_output");
-        Tensor gx = torch::empty_like(gy);
-        c10::hip::HIPGuardMasqueradingAsCUDA guard(gy.device());
-        check_status(fewbit_hip_stepwise1_backward(static_cast<int>(fn), dtype_code(gy), gy.data_ptr(),
-                                                   saved[0].data_ptr<uint8_t>(), gx.data_ptr(),
-                                                   static_cast<size_t>(gy.numel()), p0, current_stream(gy)),
-                     "stepwise1_backward");
-        return {gx, Tensor(), Tensor(), Tensor(), Tensor()};
+        return {launch_step1_backward(static_cast<int>(fn), grad_output[0], saved[0], p0), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
@@ -268,9 +323,9 @@ void check_host_table(const Tensor &self, const Tensor &table, const char *name)
                 ", input ", self.scalar_type());
 }
 
-// y = fn(self) as a FRESH tensor (the reference's host operator leaves its input intact, fewbit/cpu/gelu.cc:7-31,
-// although the schema says Tensor(a!)); any layout is accepted: codes and state follow the logical row-major order
-// (hard part 7: what the reference's CPU path does for a strided input).  Returns the packed state.
+// y = fn(self), written into `out` when `out` is defined (in place: `out` is `self`) and as a fresh tensor otherwise;
+// any layout is accepted: codes and state follow the logical row-major order (hard part 7: what the reference's
+// CPU path does for a strided input, fewbit/cpu/gelu.cc:7-31).  Returns the packed state.
 Tensor host_quantize(int fn, const Tensor &self, Tensor &out, const Tensor &bounds, double p0, double p1) {
     TORCH_CHECK(self.is_floating_point(), "fewbit: unsupported dtype ", self.scalar_type());
     check_host_table(self, bounds, "bounds");
@@ -284,30 +339,18 @@ Tensor host_quantize(int fn, const Tensor &self, Tensor &out, const Tensor &boun
                              ? torch::searchsorted(b.to(torch::kFloat), flat.to(torch::kFloat).sub(p0).abs(), /*out_int32=*/true)
                              : torch::searchsorted(b, flat, /*out_int32=*/true);
     Tensor state = host_pack(codes, nbits);
-    out = host_activation(fn, x, p0, p1);
+    Tensor y = host_activation(fn, x, p0, p1);
+    if (out.defined())
+        out.copy_(y);
+    else
+        out = y;
     return state;
 }
 
-struct HostContinuousFunction : public torch::autograd::Function<HostContinuousFunction> {
-    static Tensor forward(AutogradContext *ctx, const Tensor &self, const Tensor &bounds, const Tensor &levels, int64_t fn,
-                          double p0, double p1) {
-        TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
-                    "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(),
-                    " and ", levels.numel());
-        check_host_table(self, levels, "levels");
-        Tensor out;
-        Tensor state = host_quantize(static_cast<int>(fn), self, out, bounds, p0, p1);
-        ctx->save_for_backward({state, levels});
-        return out;
-    }
-
-    static variable_list backward(AutogradContext *ctx, variable_list grad_output) {
-        const auto saved = ctx->get_saved_variables();
-        const Tensor lv = saved[1].contiguous();
-        return {host_unpack_mul(grad_output[0], saved[0], lv, bitwidth_of(lv.numel())), Tensor(), Tensor(), Tensor(),
-                Tensor(), Tensor()};
-    }
-};
+Tensor host_dequantize(const Tensor &grad, const Tensor &state, const Tensor &levels) {
+    const Tensor lv = levels.contiguous();
+    return host_unpack_mul(grad, state, lv, bitwidth_of(lv.numel()));
+}
 
 // 1-bit family on the host: values by ATen, the derivative-branch bit by the same rules as the kernels
 // (Step1<> in fewbit_device.h; fewbit/cuda/codec.cu:298-487)
@@ -341,26 +384,58 @@ Tensor host_step1_bits(int fn, const Tensor &x, double p0, double p1) {
     return bit.to(torch::kInt32);
 }
 
+// as host_quantize: `out` defined = write the values there (in place), else a fresh tensor
+Tensor host_step1(int fn, const Tensor &self, Tensor &out, double p0, double p1) {
+    TORCH_CHECK(self.is_floating_point(), "fewbit: unsupported dtype ", self.scalar_type());
+    const Tensor x = self.contiguous();
+    Tensor state = host_pack(host_step1_bits(fn, x, p0, p1), 1);
+    Tensor y = host_step1_activation(fn, x, p0, p1);
+    if (out.defined())
+        out.copy_(y);
+    else
+        out = y;
+    return state;
+}
+
+Tensor host_step1_backward(int fn, const Tensor &grad, const Tensor &state, double p0) {
+    float pair[2] = {0.0f, 1.0f};       // as fewbit_hip_stepwise1_backward: (m0, m1) in fp32
+    if (fn == FEWBIT_HARDSIGMOID) pair[1] = 1.0f / 6.0f;
+    if (fn == FEWBIT_LEAKY_RELU) { pair[0] = 1.0f; pair[1] = static_cast<float>(p0); }
+    return host_unpack_mul(grad, state, Tensor(), 1, pair);
+}
+
+struct HostContinuousFunction : public torch::autograd::Function<HostContinuousFunction> {
+    static Tensor forward(AutogradContext *ctx, Tensor self, const Tensor &bounds, const Tensor &levels, int64_t fn,
+                          double p0, double p1, bool inplace) {
+        Tensor out = inplace ? self : Tensor();
+        Tensor state = host_quantize(static_cast<int>(fn), self, out, bounds, p0, p1);
+        if (inplace) ctx->mark_dirty({self});
+        ctx->save_for_backward({state, levels});
+        return out;
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grad_output) {
+        const auto saved = ctx->get_saved_variables();
+        return {host_dequantize(grad_output[0], saved[0], saved[1]), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
 struct HostStepwise1Function : public torch::autograd::Function<HostStepwise1Function> {
-    static Tensor forward(AutogradContext *ctx, const Tensor &self, int64_t fn, double p0, double p1) {
-        TORCH_CHECK(self.is_floating_point(), "fewbit: unsupported dtype ", self.scalar_type());
-        const Tensor x = self.contiguous();
-        Tensor state = host_pack(host_step1_bits(static_cast<int>(fn), x, p0, p1), 1);
-        Tensor y = host_step1_activation(static_cast<int>(fn), x, p0, p1);
+    static Tensor forward(AutogradContext *ctx, Tensor self, int64_t fn, double p0, double p1, bool inplace) {
+        Tensor out = inplace ? self : Tensor();
+        Tensor state = host_step1(static_cast<int>(fn), self, out, p0, p1);
+        if (inplace) ctx->mark_dirty({self});
         ctx->save_for_backward({state});
         ctx->saved_data["fn"] = fn;
         ctx->saved_data["p0"] = p0;
-        return y;
+        return out;
     }
 
     static variable_list backward(AutogradContext *ctx, variable_list grad_output) {
         const auto saved = ctx->get_saved_variables();
         const auto fn = ctx->saved_data["fn"].toInt();
         const auto p0 = ctx->saved_data["p0"].toDouble();
-        float pair[2] = {0.0f, 1.0f};       // as fewbit_hip_stepwise1_backward: (m0, m1) in fp32
-        if (fn == FEWBIT_HARDSIGMOID) pair[1] = 1.0f / 6.0f;
-        if (fn == FEWBIT_LEAKY_RELU) { pair[0] = 1.0f; pair[1] = static_cast<float>(p0); }
-        return {host_unpack_mul(grad_output[0], saved[0], Tensor(), 1, pair), Tensor(), Tensor(), Tensor()};
+        return {host_step1_backward(static_cast<int>(fn), grad_output[0], saved[0], p0), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
@@ -373,16 +448,88 @@ void note_inplace_write(const Tensor &self) {
     if (!self.is_inference()) self.unsafeGetTensorImpl()->bump_version();
 }
 
+void check_table_sizes(const Tensor &bounds, const Tensor &levels) {
+    TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
+                "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(), " and ",
+                levels.numel());
+}
+
+#if FEWBIT_AUTOGRAD_INTERNALS
+// ---- autograd, direct route: one backward node, wired like ATen's generated code wires its own ---------------------
+// (torch/csrc/autograd/generated/VariableType_*.cpp pattern: check_inplace -> grad_fn->set_next_edges(collect_next_edges)
+// -> kernel below autograd -> increment_version + rebase_history (in place) / set_history (fresh result) -> SavedVariable.)
+struct PackedBackwardNode : public torch::autograd::Node {
+    torch::autograd::SavedVariable state, levels;     // `levels` stays empty for the 1-bit family
+    int step_fn = -1;                                  // >= 0: a 1-bit operator
+    double p0 = 0.0;
+    bool host = false;
+
+    variable_list apply(variable_list &&grads) override {
+        variable_list out(1);
+        const Tensor st = state.unpack();              // raises autograd's own "backward through the graph a second time"
+        const Tensor &g = grads[0];
+        if (!g.defined() || !task_should_compute_output(0)) return out;
+        if (step_fn >= 0) {
+            out[0] = host ? host_step1_backward(step_fn, g, st, p0) : launch_step1_backward(step_fn, g, st, p0);
+        } else {
+            const Tensor lv = levels.unpack();
+            out[0] = host ? host_dequantize(g, st, lv) : launch_dequantize(g, st, lv);
+        }
+        return out;
+    }
+
+    void release_variables() override {
+        std::lock_guard<std::mutex> lock(mutex_);
+        state.reset_data();
+        levels.reset_data();
+    }
+
+    std::string name() const override { return "FewbitPackedBackward"; }
+};
+
+// `launch(out)` runs below autograd: it writes the values into `out` (defined = in place, `out` is `self`) or makes `out`,
+// and returns the packed state
+template <typename Launch>
+Tensor forward_direct(const Tensor &self, bool inplace, bool host, int step_fn, double p0, const Tensor &levels, Launch &&launch) {
+    if (inplace) torch::autograd::check_inplace(self, /*requires_grad=*/true);
+    std::shared_ptr<PackedBackwardNode> node(new PackedBackwardNode(), torch::autograd::deleteNode);
+    node->host = host;
+    node->step_fn = step_fn;
+    node->p0 = p0;
+    node->set_next_edges(torch::autograd::collect_next_edges(self));
+    Tensor out = inplace ? self : Tensor();
+    Tensor state;
+    {
+        at::AutoDispatchBelowADInplaceOrView below;
+        state = launch(out);
+    }
+    if (inplace) {
+        torch::autograd::increment_version(self);
+        torch::autograd::rebase_history(self, node);
+    } else {
+        torch::autograd::set_history(out, node);
+    }
+    node->state = torch::autograd::SavedVariable(state, /*is_output=*/false);
+    if (levels.defined()) node->levels = torch::autograd::SavedVariable(levels, /*is_output=*/false);
+    return out;
+}
+#endif
+
 // In place on a VIEW that covers its whole base -- what the reference's callers do: the 3-D output of nn.Linear is a view
-// of its 2-D addmm result, and benchmark/bench-roberta.py:138-147 hands it straight to torch.ops.fewbit.gelu.  Marking
-// the view itself dirty makes autograd rebase it (CopySlices: a zero-fill plus three full-size copies around our
-// backward).  Marking the BASE dirty instead is the same write to the same memory, and autograd re-derives the view's
-// grad_fn from the base's new one by itself (the standard "base modified after the view was taken" path) -- same graph
-// semantics, nothing saved but {state, levels}, no copies.  Returns the undefined tensor when `self` is not such a view.
+// of its 2-D addmm result, and benchmark/bench-roberta.py:138-147 hands it straight to torch.ops.fewbit.gelu.  Modifying
+// the view itself makes autograd rebase it (CopySlices: a zero-fill plus three full-size copies around our backward).
+// Modifying the BASE instead is the same write to the same memory: nothing is saved but {state, levels}, and
+//   * the RETURNED tensor is a fresh `base.view(sizes)` (route `fresh_view`): its backward is a reshape, no copy at all;
+//   * the tensor that was passed in stays correct for later users -- autograd re-derives its grad_fn from the base's new
+//     one by itself (the standard "base modified after the view was taken" path: an AsStridedBackward0 node, whose
+//     backward costs one zero-fill and one copy of the base -- only paid by graphs that keep using the OLD python object).
+// Returns the undefined tensor when `self` is not such a view, or when the route is off / not compiled (then autograd's
+// general in-place-on-view machinery runs: correct, slower).
 Tensor whole_view_base(const Tensor &self) {
-    if (!self.is_view()) return Tensor();
+#if FEWBIT_AUTOGRAD_INTERNALS
+    if (!self.is_view() || !route::on(route::BaseDirty)) return Tensor();
     // only ordinary views: for the kinds autograd refuses to modify in place (outputs of multi-output view ops, views made
-    // under no_grad or inside a custom Function) the general route below keeps raising autograd's own error
+    // under no_grad or inside a custom Function) the general route keeps raising autograd's own error
     const auto *meta = torch::autograd::impl::get_view_autograd_meta(self);
     if (!meta || meta->get_creation_meta() != torch::autograd::CreationMeta::DEFAULT) return Tensor();
     const Tensor base(self._base());      // (TensorBase::_base returns a const TensorBase &)
@@ -391,39 +538,88 @@ Tensor whole_view_base(const Tensor &self) {
         base.device() != self.device())
         return Tensor();
     return base;
+#else
+    (void)self;
+    return Tensor();
+#endif
 }
 
-// ---- the three flavours every operator is registered in --------------------------------------------
+// what the caller gets back after the base was modified in its place
+Tensor after_base_write(const Tensor &self, const Tensor &base) {
+    return route::on(route::FreshView) ? base.view(self.sizes()) : self;
+}
+
+// ---- the four flavours every operator is registered in ---------------------------------------------
 enum class Where { AutogradGpu, RawGpu, AutogradHost, RawHost };
+
+// with an autograd node, device or host tensors, either route
+Tensor continuous_with_node(bool host, int fn, const Tensor &self, const Tensor &bounds, const Tensor &levels, double p0,
+                            double p1, bool inplace) {
+#if FEWBIT_AUTOGRAD_INTERNALS
+    if (route::on(route::DirectNode)) {
+        return forward_direct(self, inplace, host, -1, 0.0, levels, [&](Tensor &out) {
+            if (host) return host_quantize(fn, self, out, bounds, p0, p1);
+            if (!out.defined()) out = torch::empty_like(self);
+            return launch_quantize(fn, self, out, bounds, p0, p1);
+        });
+    }
+#endif
+    return host ? HostContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, inplace)
+                : ContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, inplace);
+}
+
+Tensor stepwise1_with_node(bool host, int fn, const Tensor &self, double p0, double p1, bool inplace) {
+#if FEWBIT_AUTOGRAD_INTERNALS
+    if (route::on(route::DirectNode)) {
+        return forward_direct(self, inplace, host, fn, p0, Tensor(), [&](Tensor &out) {
+            if (host) return host_step1(fn, self, out, p0, p1);
+            check_input(self, "self");
+            if (!out.defined()) out = torch::empty_like(self);
+            return launch_step1(fn, self, out, p0, p1);
+        });
+    }
+#endif
+    return host ? HostStepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, inplace)
+                : Stepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, inplace);
+}
 
 template <Where W>
 Tensor continuous(int fn, const Tensor &self, const Tensor &bounds, const Tensor &levels, double p0 = 0.0, double p1 = 0.0,
                   bool inplace = true) {
+    check_table_sizes(bounds, levels);
     if constexpr (W == Where::AutogradGpu) {
-        // nothing will ever ask for this call's gradient: skip the autograd node (and its ~4 us of host time)
+        // nothing will ever ask for this call's gradient: skip the autograd node (and its host time)
         if (!needs_node(self)) return continuous<Where::RawGpu>(fn, self, bounds, levels, p0, p1, inplace);
+        check_table(self, levels, "levels");
         if (inplace) {
             if (const Tensor base = whole_view_base(self); base.defined()) {
-                ContinuousFunction::apply(base, bounds, levels, static_cast<int64_t>(fn), p0, p1, true);
-                return self;
+                continuous_with_node(false, fn, base, bounds, levels, p0, p1, true);
+                return after_base_write(self, base);
             }
         }
-        return ContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1, inplace);
+        return continuous_with_node(false, fn, self, bounds, levels, p0, p1, inplace);
     } else if constexpr (W == Where::AutogradHost) {
-        // host tensors: always a fresh result, like the reference's host operator (see host_quantize)
-        return HostContinuousFunction::apply(self, bounds, levels, static_cast<int64_t>(fn), p0, p1);
+        if (!needs_node(self)) return continuous<Where::RawHost>(fn, self, bounds, levels, p0, p1, inplace);
+        check_host_table(self, levels, "levels");
+        // `gelu` is the one operator the reference implements for host tensors, and there it returns a fresh tensor
+        // (fewbit/cpu/gelu.cc:7-31); everything else honours the Tensor(a!) schema like the GPU side
+        const bool write_back = inplace && fn != FEWBIT_GELU;
+        if (write_back) {
+            if (const Tensor base = whole_view_base(self); base.defined()) {
+                continuous_with_node(true, fn, base, bounds, levels, p0, p1, true);
+                return after_base_write(self, base);
+            }
+        }
+        return continuous_with_node(true, fn, self, bounds, levels, p0, p1, write_back);
     } else if constexpr (W == Where::RawHost) {     // no autograd node: nothing to save, plain activation
-        TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
-                    "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(), " and ",
-                    levels.numel());
         check_host_table(self, bounds, "bounds");      // the same argument errors with and without autograd
         check_host_table(self, levels, "levels");
-        return host_activation(fn, self, p0, p1);
+        Tensor y = host_activation(fn, self, p0, p1);
+        if (!inplace || fn == FEWBIT_GELU) return y;
+        self.copy_(y);                                 // (copy_ bumps the version counter itself)
+        return self;
     } else {
         // no autograd node (inference_mode): same kernel, the packed state goes to a scratch buffer and is dropped
-        TORCH_CHECK(bounds.numel() + 1 == levels.numel(),
-                    "fewbit: size of `bounds` should be lesser than size of `levels` by one, got ", bounds.numel(), " and ",
-                    levels.numel());
         Tensor out = inplace ? self : torch::empty_like(self);
         launch_quantize(fn, self, out, bounds, p0, p1);
         if (inplace) note_inplace_write(self);
@@ -436,23 +632,29 @@ template <Where W> Tensor stepwise1(int fn, const Tensor &self, double p0 = 0.0,
         if (!needs_node(self)) return stepwise1<Where::RawGpu>(fn, self, p0, p1, inplace);
         if (inplace) {
             if (const Tensor base = whole_view_base(self); base.defined()) {       // see whole_view_base
-                Stepwise1Function::apply(base, static_cast<int64_t>(fn), p0, p1, true);
-                return self;
+                stepwise1_with_node(false, fn, base, p0, p1, true);
+                return after_base_write(self, base);
             }
         }
-        return Stepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1, inplace);
+        return stepwise1_with_node(false, fn, self, p0, p1, inplace);
     } else if constexpr (W == Where::AutogradHost) {
-        return HostStepwise1Function::apply(self, static_cast<int64_t>(fn), p0, p1);
+        if (!needs_node(self)) return stepwise1<Where::RawHost>(fn, self, p0, p1, inplace);
+        if (inplace) {
+            if (const Tensor base = whole_view_base(self); base.defined()) {
+                stepwise1_with_node(true, fn, base, p0, p1, true);
+                return after_base_write(self, base);
+            }
+        }
+        return stepwise1_with_node(true, fn, self, p0, p1, inplace);
     } else if constexpr (W == Where::RawHost) {
-        return host_step1_activation(fn, self, p0, p1);
+        Tensor y = host_step1_activation(fn, self, p0, p1);
+        if (!inplace) return y;
+        self.copy_(y);
+        return self;
     } else {
         check_input(self, "self");
         Tensor out = inplace ? self : torch::empty_like(self);
-        Tensor state = new_state(self, self.numel(), 1);
-        c10::hip::HIPGuardMasqueradingAsCUDA guard(self.device());
-        check_status(fewbit_hip_stepwise1_forward(fn, dtype_code(self), self.data_ptr(), out.data_ptr(), state.data_ptr<uint8_t>(),
-                                                  static_cast<size_t>(self.numel()), p0, p1, current_stream(self)),
-                     "stepwise1_forward");
+        launch_step1(fn, self, out, p0, p1);
         if (inplace) note_inplace_write(self);
         return out;
     }
@@ -660,3 +862,22 @@ TORCH_LIBRARY_IMPL(fewbit, CPU, m) {
     m.impl("quantize", fewbit_amd::quantize_host);
     m.impl("quantize_backward", fewbit_amd::quantize_backward_host);
 }
+
+// Run-time switch of the autograd routes (header comment): name in {"direct_node", "base_dirty", "fresh_view"};
+// value 0 / 1 sets, -1 only queries.  Returns the previous effective setting (0 / 1), -1 for an unknown name, -2 when the
+// route cannot be enabled because the library was built without the internal-API code (FEWBIT_AUTOGRAD_INTERNALS = 0).
+extern "C" __attribute__((visibility("default"))) int fewbit_torch_route(const char *name, int value) {
+    namespace r = fewbit_amd::route;
+    for (int w = 0; w < r::Count; ++w) {
+        if (std::strcmp(name, r::kNames[w]) != 0) continue;
+        const int prev = r::on(static_cast<r::Which>(w)) ? 1 : 0;
+        if (value >= 0) {
+            if (value > 0 && r::kNeedsInternals[w] && !FEWBIT_AUTOGRAD_INTERNALS) return -2;
+            r::g_state[w].store(value > 0 ? 1 : 0, std::memory_order_relaxed);
+        }
+        return prev;
+    }
+    return -1;
+}
+
+extern "C" __attribute__((visibility("default"))) int fewbit_torch_autograd_internals(void) { return FEWBIT_AUTOGRAD_INTERNALS; }

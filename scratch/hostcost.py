@@ -34,6 +34,33 @@ def vb():
     y = van(xr * 1.0); y.backward(g)
 show('vanilla mul+GELU fwd+bwd', host(vb, 500))
 show('fewbit  mul+GELU fwd+bwd', host(fb, 500))
+# the raw operator against torch.nn.functional.gelu, per autograd route of the operator library (torch_ops.cpp header):
+# forward with a node, and forward+backward, on a tensor small enough that only host time counts
+import fewbit_amd
+import torch.nn.functional as TF
+op = torch.ops.fewbit.gelu.default
+def raw_fwd():
+    return op(xg.clone(), bi, l)
+def raw_fb():
+    op(xr * 1.0, bi, l).backward(g)
+def van_fwd():
+    return TF.gelu(xg.clone())
+def van_fb():
+    TF.gelu(xr * 1.0).backward(g)
+def best(f, iters, rounds=5):
+    return min(host(f, iters) for _ in range(rounds))
+show('F.gelu(clone) fwd, input requires grad', best(van_fwd, 2000))
+show('F.gelu(mul) fwd+bwd', best(van_fb, 1000))
+if fewbit_amd.autograd_internals():
+    for direct in (True, False):
+        prev = fewbit_amd.autograd_route('direct_node', direct)
+        tag = 'direct node' if direct else 'autograd::Function'
+        show('torch.ops.fewbit.gelu(clone) fwd, input requires grad [%s]' % tag, best(raw_fwd, 2000))
+        show('torch.ops.fewbit.gelu(mul) fwd+bwd [%s]' % tag, best(raw_fb, 1000))
+        fewbit_amd.autograd_route('direct_node', prev)
+else:
+    show('torch.ops.fewbit.gelu(clone) fwd, input requires grad [autograd::Function]', best(raw_fwd, 2000))
+    show('torch.ops.fewbit.gelu(mul) fwd+bwd [autograd::Function]', best(raw_fb, 1000))
 # headline size through the module
 X = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
 G = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)

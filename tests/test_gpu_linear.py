@@ -17,7 +17,7 @@ DEV = 'cuda:0'
 @pytest.fixture(scope='module')
 def lref():
     with np.load(GOLDEN / 'linear_ref.npz') as z:
-        return {k: torch.from_numpy(z[k].copy()) for k in z.files}
+        return {k: torch.from_numpy(z[k].copy()) for k in z.files if z[k].dtype.kind in 'fiu'}
 
 
 def rel_err(got, want):

@@ -204,13 +204,33 @@ def _graph_nodes(fn):
     return names
 
 
-def test_raw_operator_in_place_on_a_linear_output_view():
+ROUTES = {'default': {}, 'function_node': {'direct_node': False}, 'returns_self': {'fresh_view': False},
+          'general_view_route': {'base_dirty': False}, 'all_public_api': {'direct_node': False, 'base_dirty': False}}
+
+
+@pytest.fixture
+def route(request):
+    """switch the operator library's autograd routes for one test (fewbit_amd.autograd_route), restore afterwards"""
+    import fewbit_amd
+    if request.param != 'default' and not fewbit_amd.autograd_internals():
+        pytest.skip('operator library built without the internal-API routes: only the public-API route exists')
+    prev = {k: fewbit_amd.autograd_route(k, v) for k, v in ROUTES[request.param].items()}
+    yield request.param
+    for k, v in prev.items():
+        fewbit_amd.autograd_route(k, v)
+
+
+@pytest.mark.parametrize('route', list(ROUTES), indirect=True)
+def test_raw_operator_in_place_on_a_linear_output_view(route):
     """The reference's own caller route (benchmark/bench-roberta.py:138-147): the RAW operator, in place, on the 3-D output
-    of nn.Linear -- a view of its 2-D addmm result.  The operator marks the view's BASE dirty (torch_ops.cpp,
-    whole_view_base), so autograd builds no CopySlices node; values, gradients and the saved bytes equal the 2-D route's."""
+    of nn.Linear -- a view of its 2-D addmm result.  The operator modifies the view's BASE (torch_ops.cpp, whole_view_base),
+    so autograd builds no CopySlices node; values, gradients and the saved bytes equal the 2-D route's.  Every autograd
+    route of the library (hand-written node / torch::autograd::Function, base write on or off, fresh view or `self`
+    returned) must give the same bytes and gradients; with the base write off autograd's general machinery (CopySlices) runs."""
     torch.manual_seed(0)
     lin = torch.nn.Linear(64, 256).to(DEV)
     x = torch.randn(8, 16, 64, device=DEV)
+    wgt = torch.randn(8, 16, 256, device=DEV)
     inner, levels = fewbit.functional.store.get_inner('gelu', 3, torch.device(DEV), torch.float32)
     for op_name, args in (('gelu', (inner, levels)), ('relu', ()), ('leaky_relu', (0.1,))):
         op = getattr(torch.ops.fewbit, op_name)
@@ -220,10 +240,18 @@ def test_raw_operator_in_place_on_a_linear_output_view():
         want_ptr = h.data_ptr()
         with fewbit.memory_usage_hooks() as usage:
             out = op(h, *args)
-            assert out.data_ptr() == want_ptr and out.shape == h.shape           # in place, the same tensor comes back
-            loss = (out * out).sum()                                             # (saves `out` once more: counted below)
+            assert out.data_ptr() == want_ptr and out.shape == h.shape           # in place: the same memory comes back
+            # (one gradient contribution through `out`, one through the OLD python object `h`, which stays usable: a sum of
+            # two terms is the same in either order, so the routes can be compared bit for bit)
+            loss = (out * wgt).sum() + 0.5 * h.sum()
         nodes = _graph_nodes(out.grad_fn)
-        assert 'CopySlices' not in nodes, nodes
+        general = ROUTES[route].get('base_dirty') is False
+        assert ('CopySlices' in nodes) == general, (route, nodes)
+        if route == 'default':
+            assert 'AsStridedBackward0' not in nodes and 'ViewBackward0' in nodes, nodes       # the returned view: a reshape
+        direct = ROUTES[route].get('direct_node', True)
+        if not general:                                   # (CopySlices hides the operator's node inside itself)
+            assert any('FewbitPackedBackward' in n for n in _graph_names(out.grad_fn)) == direct
         loss.backward()
         g_view, gb_view = lin.weight.grad.clone(), lin.bias.grad.clone()
         saved_view = usage.forward
@@ -233,11 +261,61 @@ def test_raw_operator_in_place_on_a_linear_output_view():
         assert not h2._is_view()
         with fewbit.memory_usage_hooks() as usage2:
             out2 = op(h2, *args)
-            loss2 = (out2 * out2).sum()
+            loss2 = (out2 * wgt.view(-1, 256)).sum() + 0.5 * h2.sum()
         loss2.backward()
         assert torch.equal(out.view(-1, 256), out2), op_name
-        assert torch.equal(g_view, lin.weight.grad) and torch.equal(gb_view, lin.bias.grad), op_name
-        assert saved_view == usage2.forward, (op_name, saved_view, usage2.forward)
+        assert torch.equal(g_view, lin.weight.grad) and torch.equal(gb_view, lin.bias.grad), (route, op_name)
+        if not general:
+            assert saved_view == usage2.forward, (op_name, saved_view, usage2.forward)
+
+
+def _graph_names(fn):
+    seen, stack, names = set(), [fn], []
+    while stack:
+        f = stack.pop()
+        if f is None or f in seen:
+            continue
+        seen.add(f)
+        names.append(f.name())
+        stack += [n for n, _ in f.next_functions]
+    return names
+
+
+@pytest.mark.parametrize('route', ['default', 'function_node'], indirect=True)
+def test_both_node_routes_save_the_same_bytes_and_give_the_same_gradients(route):
+    """every operator family x in place / out of place x 3 dtypes: packed state and gradient vs the oracle under both
+    autograd routes, plus autograd's own errors (leaf in place, second backward)"""
+    import oracle
+    g = torch.Generator().manual_seed(3)
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        x = (torch.randn(4099, generator=g) * 2).to(dtype)
+        gy = torch.randn(4099, generator=g).to(dtype)
+        inner, levels = fewbit.functional.store.get_inner('gelu', 3, torch.device('cpu'), dtype)
+        _, state_o, _ = oracle.quantize('gelu', x, inner)
+        gx_o = oracle.quantize_backward(gy, state_o, levels)
+        _, bits_o = oracle.stepwise1_forward('relu', x)
+        gr_o = oracle.stepwise1_backward('relu', gy, bits_o)
+        for inplace in (True, False):
+            xd = x.to(DEV).requires_grad_()
+            seen = []
+            with torch.autograd.graph.saved_tensors_hooks(lambda t: (seen.append(t), t)[1], lambda t: t):
+                if inplace:
+                    y = torch.ops.fewbit.gelu(xd * 1.0, inner.to(DEV), levels.to(DEV))
+                else:
+                    y = torch.ops.fewbit.continuous_out(xd * 1.0, inner.to(DEV), levels.to(DEV), 2, 0.0, 0.0)
+            assert ('FewbitPackedBackward' in y.grad_fn.name()) == (route == 'default')
+            assert torch.equal([t for t in seen if t.dtype == torch.uint8][0].cpu(), state_o)
+            y.backward(gy.to(DEV), retain_graph=True)
+            assert_bit_equal(xd.grad, gx_o, f'gelu {dtype} inplace={inplace} {route}')
+            y.backward(gy.to(DEV))
+            with pytest.raises(RuntimeError, match='second time'):
+                y.backward(gy.to(DEV))
+            xr = x.to(DEV).requires_grad_()
+            yr = torch.ops.fewbit.relu(xr * 1.0) if inplace else torch.ops.fewbit.stepwise1_out(xr * 1.0, 4, 0.0, 0.0)
+            yr.backward(gy.to(DEV))
+            assert_bit_equal(xr.grad, gr_o, f'relu {dtype} inplace={inplace} {route}')
+        with pytest.raises(RuntimeError, match='leaf Variable'):
+            torch.ops.fewbit.gelu(x.to(DEV).requires_grad_(), inner.to(DEV), levels.to(DEV))
 
 
 def test_in_place_on_a_view_keeps_in_place_semantics_for_later_users():

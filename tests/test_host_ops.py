@@ -159,8 +159,12 @@ def test_host_ops_without_autograd_and_errors():
     # host tensors of any layout are accepted, like the reference's CPU operator: logical (row-major) element order
     xt = torch.randn(6, 10).t()
     xg = xt.clone().requires_grad_()                                      # (clone keeps the transposed strides)
-    assert not xg.is_contiguous()
-    y = torch.ops.fewbit.silu(xg, inner, levels)
+    with pytest.raises(RuntimeError, match='leaf Variable'):               # in place on a leaf that requires grad: autograd's own error
+        torch.ops.fewbit.silu(xg, inner, levels)
+    xin = xg * 1.0                                                         # (element-wise ops keep the strides too)
+    assert not xin.is_contiguous()
+    y = torch.ops.fewbit.silu(xin, inner, levels)
+    assert y.data_ptr() == xin.data_ptr() and not y.is_contiguous()       # Tensor(a!): written back through the strides
     assert torch.equal(y, F.silu(xt.contiguous()))          # (ATen's strided and contiguous silu differ by an ulp)
     y.sum().backward()
     assert torch.equal(xg.grad, levels[torch.searchsorted(inner, xt.contiguous())])
@@ -206,3 +210,85 @@ def test_host_ops_every_16bit_pattern(dtype):
         torch.ops.fewbit.stepwise(xx.clone(), edge, levels)
     _, state_o, _ = oracle.quantize('identity', x, edge)
     assert torch.equal([t for t in saved if t.dtype == torch.uint8][0], state_o)
+
+
+# ---- the in-place rule on the host, and the two autograd routes ------------------------------------------------------
+IN_PLACE_OPS = [(n, 'table') for n in fewbit.functional.CONTINOUS if n != 'gelu'] + \
+               [('stepwise', 'table'), ('relu', ()), ('relu6', ()), ('hardsigmoid', ()), ('hardshrink', (0.5,)), ('softshrink', (0.5,)),
+                ('hardtanh', (-1.0, 1.0)), ('leaky_relu', (0.01,)), ('threshold', (0.25, -3.0))]
+
+
+@pytest.mark.parametrize('name,args', IN_PLACE_OPS)
+def test_host_operators_honour_their_in_place_schema_except_gelu(name, args):
+    """`Tensor(a!) self -> Tensor(a!)` on host tensors: every operator writes its result into `self` and returns it, with and
+    without an autograd node -- the same call has the same effect on its argument on the GPU and on the host.  The one
+    exception is pinned too: `gelu`, which the reference implements for the host out of place (fewbit/cpu/gelu.cc:7-31)."""
+    x = torch.randn(300) * 2
+    if args == 'table':
+        args = store.get_inner('silu' if name == 'stepwise' else name, 3, torch.device('cpu'), torch.float32)
+    op = getattr(torch.ops.fewbit, name)
+    for with_node in (True, False):
+        inp = x.clone().requires_grad_(with_node) * 1.0 if with_node else x.clone()
+        version = inp._version
+        out = op(inp, *args)
+        assert out.data_ptr() == inp.data_ptr() and inp._version > version, (name, with_node)
+        assert torch.equal(inp.detach(), out.detach()) and out.requires_grad == with_node
+        if name != 'stepwise':
+            ref = getattr(F, name)(x, *(() if len(args) == 2 and isinstance(args[0], torch.Tensor) else args))
+            assert torch.equal(out.detach(), ref), name
+    # gelu: fresh tensor, input intact, in both flavours
+    inner, levels = store.get_inner('gelu', 3, torch.device('cpu'), torch.float32)
+    for with_node in (True, False):
+        inp = x.clone().requires_grad_(with_node) * 1.0 if with_node else x.clone()
+        out = torch.ops.fewbit.gelu(inp, inner, levels)
+        assert out.data_ptr() != inp.data_ptr() and torch.equal(inp.detach(), x)
+
+
+def test_out_of_place_variants_never_touch_their_input_on_the_host():
+    inner, levels = store.get_inner('silu', 2, torch.device('cpu'), torch.float32)
+    x = torch.randn(64)
+    for inp in (x.clone(), x.clone().requires_grad_() * 1.0):
+        y = torch.ops.fewbit.continuous_out(inp, inner, levels, 8, 0.0, 0.0)         # 8 = silu (include/fewbit_hip.h)
+        z = torch.ops.fewbit.stepwise1_out(inp, 4, 0.0, 0.0)                         # 4 = relu
+        assert y.data_ptr() != inp.data_ptr() and z.data_ptr() != inp.data_ptr() and torch.equal(inp.detach(), x)
+        assert torch.equal(y.detach(), F.silu(x)) and torch.equal(z.detach(), F.relu(x))
+
+
+def test_direct_node_and_function_routes_agree_on_the_host():
+    """fewbit_torch_route('direct_node'): the hand-written backward node and the torch::autograd::Function fallback give the
+    same values, the same saved bytes, the same gradients and the same errors (host tensors; tests/test_gpu_ops.py repeats
+    this on the device)."""
+    import fewbit_amd
+    if not fewbit_amd.autograd_internals():
+        pytest.skip('operator library built without the internal-API routes')
+    inner, levels = store.get_inner('silu', 3, torch.device('cpu'), torch.float32)
+    x, gy = torch.randn(999) * 2, torch.randn(999)
+    results = {}
+    prev = fewbit_amd.autograd_route('direct_node')
+    try:
+        for direct in (True, False):
+            fewbit_amd.autograd_route('direct_node', direct)
+            assert fewbit_amd.autograd_route('direct_node') is direct
+            got = []
+            for op, args in ((torch.ops.fewbit.silu, (inner, levels)), (torch.ops.fewbit.leaky_relu, (0.2,)),
+                             (torch.ops.fewbit.gelu, store.get_inner('gelu', 2, torch.device('cpu'), torch.float32))):
+                xx = x.clone().requires_grad_()
+                saved = []
+                with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(t.clone()), t)[1], lambda t: t):
+                    y = op(xx * 1.0, *args)
+                name = y.grad_fn.name()
+                assert ('FewbitPackedBackward' in name) == direct, (name, direct)
+                y.backward(gy, retain_graph=True)
+                g1 = xx.grad.clone()
+                y.backward(gy)                                              # second pass: the graph was retained once
+                assert torch.equal(xx.grad, 2 * g1)
+                with pytest.raises(RuntimeError, match='second time'):
+                    y.backward(gy)
+                got.append((y.detach().clone(), [t for t in saved if t.dtype == torch.uint8][0], g1))
+            with pytest.raises(RuntimeError, match='leaf Variable'):
+                torch.ops.fewbit.silu(x.clone().requires_grad_(), inner, levels)
+            results[direct] = got
+    finally:
+        fewbit_amd.autograd_route('direct_node', prev)
+    for a, b in zip(results[True], results[False]):
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
