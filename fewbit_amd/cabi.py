@@ -15,6 +15,8 @@ __all__ = [
     'quantize_backward', 'bind_forward', 'bind_backward', 'bind_stepwise1_forward', 'bind_stepwise1_backward',
     'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError', 'describe_forward',
     'describe_backward', 'describe_stepwise1_forward', 'describe_stepwise1_backward', 'tune',
+    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices',
+    'philox4x32',
 ]
 
 import os
@@ -27,13 +29,17 @@ CONTINUOUS = ('celu', 'elu', 'gelu', 'hardswish', 'logsigmoid', 'mish', 'selu', 
               'softsign', 'tanh', 'tanhshrink', 'identity', 'identity_fold')
 STEPWISE1 = ('hardshrink', 'hardsigmoid', 'hardtanh', 'leaky_relu', 'relu', 'relu6', 'softshrink', 'threshold')
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+SKETCH_DISTS = ('rademacher', 'gaussian')      # enum fewbit_sketch_dist
+ABI_VERSION = 2                                # FEWBIT_HIP_ABI_VERSION this binding was written against
 
 # every symbol include/fewbit_hip.h declares
 SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwidth', 'fewbit_hip_state_nbytes',
            'fewbit_hip_quantize_forward', 'fewbit_hip_quantize_backward', 'fewbit_hip_stepwise1_forward',
            'fewbit_hip_stepwise1_backward', 'fewbit_hip_pack_codes', 'fewbit_hip_unpack_codes',
            'fewbit_hip_describe_quantize_forward', 'fewbit_hip_describe_quantize_backward',
-           'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune')
+           'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune',
+           'fewbit_hip_sketch_workspace', 'fewbit_hip_sketch', 'fewbit_hip_sketch_matrix', 'fewbit_hip_sketch_describe',
+           'fewbit_hip_sketch_tune_slices', 'fewbit_hip_philox4x32')
 
 
 class FewbitHipError(RuntimeError):
@@ -53,6 +59,10 @@ def lib() -> ctypes.CDLL:
         vp, sz, i32, dbl = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_double
         L.fewbit_hip_abi_version.restype = i32
         L.fewbit_hip_abi_version.argtypes = []
+        have = L.fewbit_hip_abi_version()
+        if have < ABI_VERSION:       # (an older build handed in through FEWBIT_HIP_LIB: say so instead of an AttributeError)
+            raise FewbitHipError(f'{LIB_PATH} has ABI version {have}, this binding needs {ABI_VERSION}: rebuild it '
+                                 '(make -C fewbit_amd/csrc)')
         L.fewbit_hip_last_error.restype = ctypes.c_char_p
         L.fewbit_hip_last_error.argtypes = []
         L.fewbit_hip_bitwidth.restype = i32
@@ -82,6 +92,19 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_describe_stepwise1_backward.argtypes = [i32, i32, sz, cp, sz]
         L.fewbit_hip_tune.restype = i32
         L.fewbit_hip_tune.argtypes = [cp, ctypes.c_longlong]
+        u64 = ctypes.c_uint64
+        L.fewbit_hip_sketch_workspace.restype = sz
+        L.fewbit_hip_sketch_workspace.argtypes = [sz, sz, sz]
+        L.fewbit_hip_sketch.restype = i32
+        L.fewbit_hip_sketch.argtypes = [i32, i32, vp, sz, sz, sz, sz, u64, dbl, vp, vp, sz, vp]
+        L.fewbit_hip_sketch_matrix.restype = i32
+        L.fewbit_hip_sketch_matrix.argtypes = [i32, i32, u64, sz, sz, sz, sz, vp, vp]
+        L.fewbit_hip_sketch_describe.restype = i32
+        L.fewbit_hip_sketch_describe.argtypes = [sz, sz, sz, cp, sz]
+        L.fewbit_hip_sketch_tune_slices.restype = i32
+        L.fewbit_hip_sketch_tune_slices.argtypes = [ctypes.c_longlong]
+        L.fewbit_hip_philox4x32.restype = None
+        L.fewbit_hip_philox4x32.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
         _lib = L
     return _lib
 
@@ -330,3 +353,66 @@ def tune(**settings: int) -> None:
     """Set launch-tuning keys of the library (see fewbit_hip_tune in include/fewbit_hip.h); -1 = built-in policy."""
     for key, value in settings.items():
         _check(lib().fewbit_hip_tune(key.encode(), int(value)))
+
+
+# ---- random-projection products (fewbit_amd/csrc/fewbit_sketch.hip): out = scale * S . m, S a function of the seed ------
+def sketch_workspace_bytes(rows: int, features: int, proj: int) -> int:
+    return lib().fewbit_hip_sketch_workspace(rows, features, proj)
+
+
+def sketch(dist: str, m: torch.Tensor, proj: int, seed: int, scale: float = 1.0, out: Optional[torch.Tensor] = None,
+           workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    """``scale * S @ m`` for the ``proj x rows`` random matrix S(seed) of kind ``dist`` ('rademacher' / 'gaussian'), which is
+    never materialised.  ``m``: 2-D, rows x features, unit stride along the features (any row stride)."""
+    if m.device.type != 'cuda':
+        raise FewbitHipError(f'm must live on the GPU (got {m.device})')
+    if m.dim() != 2 or (m.shape[1] > 1 and m.stride(1) != 1):
+        raise FewbitHipError('m must be 2-D with unit stride along its last dimension')
+    if m.dtype not in DTYPES:
+        raise FewbitHipError(f'unsupported dtype {m.dtype}')
+    rows, features = m.shape
+    ld = m.stride(0) if rows > 1 else features
+    with _on(m.device):
+        if out is None:
+            out = torch.empty((proj, features), dtype=m.dtype, device=m.device)
+        elif out.shape != (proj, features) or out.dtype != m.dtype or not out.is_contiguous():
+            raise FewbitHipError('out must be a contiguous proj x features tensor of the dtype of m')
+        need = sketch_workspace_bytes(rows, features, proj)
+        if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+            workspace = torch.empty(need, dtype=torch.uint8, device=m.device)
+        _same_device(m, out, *(() if workspace is None else (workspace, )))
+        _check(lib().fewbit_hip_sketch(SKETCH_DISTS.index(dist), DTYPES[m.dtype], m.data_ptr(), rows, features, ld, proj,
+                                       seed & 0xffffffffffffffff, scale, out.data_ptr(),
+                                       0 if workspace is None else workspace.data_ptr(),
+                                       0 if workspace is None else workspace.numel() * workspace.element_size(),
+                                       _stream(stream, m.device)))
+    return out
+
+
+def sketch_matrix(dist: str, dtype: torch.dtype, seed: int, nrows: int, ncols: int, row0: int = 0, col0: int = 0,
+                  device='cuda', stream: Optional[int] = None) -> torch.Tensor:
+    """S[row0:row0+nrows, col0:col0+ncols] as fp32, rounded as the product kernel rounds its operand for ``dtype`` (test seam)."""
+    device = torch.device(device)
+    with _on(device if device.index is not None else torch.device('cuda', torch.cuda.current_device())):
+        out = torch.empty((nrows, ncols), dtype=torch.float32, device=device)
+        _check(lib().fewbit_hip_sketch_matrix(SKETCH_DISTS.index(dist), DTYPES[dtype], seed & 0xffffffffffffffff, row0, col0,
+                                              nrows, ncols, out.data_ptr(), _stream(stream, out.device)))
+    return out
+
+
+def describe_sketch(rows: int, features: int, proj: int, device=None) -> dict:
+    return _describe(lib().fewbit_hip_sketch_describe, rows, features, proj, device=device)
+
+
+def tune_sketch_slices(slices: int) -> None:
+    """measurement hook: force the number of row slices (-1 = built-in policy)"""
+    _check(lib().fewbit_hip_sketch_tune_slices(int(slices)))
+
+
+def philox4x32(counter, key):
+    """Philox4x32-10 on the host, as the kernels evaluate it (no GPU needed)"""
+    c = (ctypes.c_uint32 * 4)(*counter)
+    k = (ctypes.c_uint32 * 2)(*key)
+    o = (ctypes.c_uint32 * 4)()
+    lib().fewbit_hip_philox4x32(c, k, o)
+    return tuple(o)

@@ -1,0 +1,617 @@
+// fewbit_sketch.hip -- the random-projection products of the randomized linear layers as ONE gfx950 kernel:
+//
+//     P = scale * S . M        S: proj x rows, random (Rademacher +-1 or Gaussian N(0,1)), never stored anywhere
+//                              M: rows x features (the layer's input X or the incoming gradient G), bf16 / fp16 / fp32
+//                              P: proj x features, the dtype of M
+//
+// What it replaces in the reference (skolai/fewbit): `proj = T.randn((proj_features, rows))` / `T.randint(...) - 0.5`
+// followed by `proj @ input_view` in LinearGRPFunc.forward (fewbit/functional/linear.py:133-146) and the same pair in
+// .backward (:195-208).  There S is a tensor in device memory (proj x rows elements, drawn twice: the backward re-draws it
+// from the saved generator state) and the product is a library GEMM.  Here S is a FUNCTION of (seed, row, column):
+// every lane of the matrix pipe computes its own A-operand fragment from a Philox4x32-10 counter in registers, feeds it
+// straight to v_mfma_f32_32x32x16_{bf16,f16}, and forward and backward regenerate the same S from the 64-bit seed alone.
+// HBM traffic of S: zero bytes (the reference: 2 x proj x rows x 4 B per layer and step).
+//
+// ---- the definition of S (a pure function; tests/sketch_reference.py evaluates the same formulas with PyTorch) -----------
+//   philox(c0, c1, c2, c3) = Philox4x32-10 with key (seed_lo, seed_hi)          [Salmon et al. 2011; the generator behind
+//                                                                               torch.cuda's and cuRAND's default engine]
+//   Rademacher:  S[i][r] = bit ? -1 : +1,   bit = bit ((j%2 ? 31 : 15) - (4*(s%4) + j/2)) of word s/4 of philox(i, 2*(r/256) + h, 0, 0)
+//                with s = (r%256)/16, h = (r/8)%2, j = r%8        (one call = 128 signs = this lane's 16 MFMA steps; the bit
+//                order is the one that turns a word into operand sign bits with one shift and one and-or per dword)
+//   Gaussian:    S[i][r] = Box-Muller on 16-bit uniforms: with w = word j/2 of philox(i, r/8, 0, 1), j = r%8,
+//                u1 = ((w & 0xffff) + 0.5) / 65536, u2 = (w >> 16) / 65536, rad = sqrt(-2 ln u1),
+//                S = rad * cos(2 pi u2) for even j, rad * sin(2 pi u2) for odd j, rounded to the operand dtype
+//                (one call = 8 normals = this lane's A fragment of one MFMA step; ln/sqrt/sin/cos are the hardware's
+//                v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32, ~1 ulp each -- the host model uses libm, and the test
+//                allows one step of the 16-bit operand dtype)
+//
+// ---- tiling ------------------------------------------------------------------------------------------------------------
+//   workgroup  256 threads = 4 waves; output tile 128 (S rows) x 256 (features); wave w owns S rows [32w, 32w+32) x all 256
+//              features = 8 MFMA column blocks of 32 -> 8 x 16 fp32 accumulators per lane.  Waves split the S rows and
+//              nothing else, so no S element is generated twice inside a workgroup.
+//   K loop     over the rows of M in stages of 64, double-buffered in LDS (2 x 32 KiB): loads of stage s+1 are in flight
+//              (registers) while stage s is multiplied; one barrier per stage.
+//   M -> LDS   M is row-major (features contiguous) but the MFMA B operand wants 8 consecutive K values (rows) of ONE
+//              feature per lane.  Each thread loads an 8-row x 8-feature block (8 x 16 B, coalesced along the rows),
+//              transposes it in registers with 32 v_perm_b32 and writes 8 x 16 B: the LDS image is [octet of rows][chunk]
+//              with chunk = 32*(feature%8) + feature/8 -- chunk-major, so that the 8 ds_write_b128 of a thread are
+//              conflict-free AND a B fragment is ONE conflict-free ds_read_b128.  The price is a permuted column order
+//              inside the tile: MFMA block t, column c  <->  feature 8c + t.  It costs nothing: the epilogue finds the 8
+//              accumulators of a lane (t = 0..7) holding 8 CONSECUTIVE features -> one 16/32-byte store per output row.
+//   split K    gridDim.z slices of the rows (multiples of 256) when the tile grid alone cannot fill 256 CUs (proj x
+//              features is small, rows is long): slices write fp32 partials, a second kernel adds them IN A FIXED ORDER
+//              (deterministic: the same seed gives the same bits), scales and casts.
+// Roofline class: MFMA (bf16 dense peak 2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md); flops = 2*proj*rows*features.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "fewbit_hip.h"
+
+#define FEWBIT_HIDDEN __attribute__((visibility("hidden")))
+
+namespace fewbit_hip {
+
+// shared with the core unit of fewbit_kernels.hip
+extern FEWBIT_HIDDEN thread_local char g_last_error[256];
+FEWBIT_HIDDEN int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+namespace sketch {
+
+constexpr int kWave = 64;
+constexpr int kThreads = 256;
+constexpr int BM = 128, BN = 256, BK = 64;
+constexpr int NT = BN / 32;                 // MFMA column blocks per wave
+constexpr int kStageBytes = BK * BN * 2;    // 32 KiB
+constexpr int kPhiloxRounds = 10;
+#ifndef FEWBIT_SKETCH_ABLATE
+#define FEWBIT_SKETCH_ABLATE 0      // measurement builds only (results are WRONG): 1 no staging of M after the first stage, 2 no barrier in
+#endif                              // the K loop, 4 constant A operand (no generator), 8 B fragments read once (no LDS reads in the loop)
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// ---- Philox4x32-10 -----------------------------------------------------------------------------------------------------
+struct Key { uint32_t k0, k1; };
+
+__host__ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, Key key, uint32_t (&out)[4]) {
+    uint32_t k0 = key.k0, k1 = key.k1;
+#pragma unroll
+    for (int r = 0; r < kPhiloxRounds; ++r) {
+        const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0, p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0, n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+        c1 = static_cast<uint32_t>(p1);
+        c3 = static_cast<uint32_t>(p0);
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// operand type of the matrix pipe: bf16 for bf16 AND fp32 inputs (fp32 is rounded to bf16 while it is staged), fp16 for fp16
+template <int DT> struct Operand {
+    typedef bf16x8 frag;
+    static constexpr uint32_t kOnes = 0x3F803F80u;        // (+1.0, +1.0)
+    static __device__ __forceinline__ uint32_t pack(float a, float b) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        bf16x2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};
+        return __builtin_bit_cast(uint32_t, v);
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Operand<FEWBIT_F16> {
+    typedef f16x8 frag;
+    static constexpr uint32_t kOnes = 0x3C003C00u;
+    static __device__ __forceinline__ uint32_t pack(float a, float b) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+        f16x2 v = {static_cast<_Float16>(a), static_cast<_Float16>(b)};
+        return __builtin_bit_cast(uint32_t, v);
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+// ---- S as a function -----------------------------------------------------------------------------------------------------
+// Rademacher: the 8 signs of MFMA step s (0..15) of the 256-row block whose 128 bits are `w`, as 4 packed operand dwords:
+// dword q = (+-1, +-1) with the sign bits taken from bits 15 - sh and 31 - sh of word s/4, sh = 4*(s%4) + q
+template <int DT> __device__ __forceinline__ u32x4 rademacher_fragment(const uint32_t (&w)[4], int s) {
+    const uint32_t word = w[s >> 2];
+    u32x4 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = ((word << (4 * (s & 3) + q)) & 0x80008000u) | Operand<DT>::kOnes;
+    return a;
+}
+
+// Gaussian: 8 normals from one Philox call (4 words -> 4 Box-Muller pairs)
+__device__ __forceinline__ void box_muller(uint32_t w, float &z0, float &z1) {
+    const float u1 = (static_cast<float>(w & 0xffffu) + 0.5f) * (1.0f / 65536.0f);
+    const float u2 = static_cast<float>(w >> 16) * (1.0f / 65536.0f);
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // -2 ln u = -2 ln2 * log2 u
+    z0 = rad * __builtin_amdgcn_cosf(u2);                                                             // v_cos_f32 takes turns
+    z1 = rad * __builtin_amdgcn_sinf(u2);
+}
+
+template <int DT> __device__ __forceinline__ u32x4 gaussian_fragment(uint32_t row, uint32_t octet, Key key) {
+    uint32_t w[4];
+    philox4x32(row, octet, 0u, 1u, key, w);
+    u32x4 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float z0, z1;
+        box_muller(w[q], z0, z1);
+        a[q] = Operand<DT>::pack(z0, z1);
+    }
+    return a;
+}
+
+// ---- M -> registers -> LDS -----------------------------------------------------------------------------------------------
+// A thread stages one 8-row x 8-feature block per stage: 8 pieces of 8 consecutive features, addressed as a wave-uniform
+// 64-bit stage base plus a 32-bit per-lane byte offset per row (fixed for the whole K loop: no per-stage address arithmetic).
+//   * feature chunks outside the matrix (the tile overhangs it) are read from column 0 instead: those columns of the tile
+//     only feed outputs that are never stored, so their values do not matter -- the address just has to be valid;
+//   * rows outside the slice exist only in its LAST stage: that stage is fetched by the guarded variant (row clamped to a
+//     valid one, data replaced by zeros before it is staged); every other stage runs with no compare and no select;
+//   * features % 8 != 0 (RAGGED): element-wise guarded loads in every stage (slow; a layer width is a multiple of 8).
+// The loads of a stage are issued back to back at its top and first touched AFTER its MFMAs (a load under a lane-divergent
+// branch, or a select right behind it, would make the compiler wait for the data on the spot).
+template <int DT> struct RawPiece { u32x4 v; };
+template <> struct RawPiece<FEWBIT_F32> { f32x4 lo, hi; };
+template <int DT> struct RawBlock { RawPiece<DT> row[8]; };
+struct Block8x8 { u32x4 row[8]; };
+
+template <int DT> __device__ __forceinline__ constexpr int elem_size() { return DT == FEWBIT_F32 ? 4 : 2; }
+
+template <int DT> __device__ __forceinline__ RawPiece<DT> load_raw(const uint8_t *p) {
+    RawPiece<DT> r;
+    if constexpr (DT == FEWBIT_F32) {
+        typedef f32x4 __attribute__((aligned(4))) f32x4u;
+        r.lo = *reinterpret_cast<const f32x4u *>(p);
+        r.hi = *reinterpret_cast<const f32x4u *>(p + 16);
+    } else {
+        typedef u32x4 __attribute__((aligned(2))) u32x4u;
+        r.v = *reinterpret_cast<const u32x4u *>(p);
+    }
+    return r;
+}
+
+// interior stage: `base` = first row of the stage (wave-uniform), off[j] = byte offset of this thread's piece of row j
+template <int DT> __device__ __forceinline__ void fetch_fast(RawBlock<DT> &b, const uint8_t *base, const uint32_t (&off)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b.row[j] = load_raw<DT>(base + off[j]);
+}
+
+// last stage of a slice: rows >= rows_left are clamped to the last valid one (and zeroed by finish_block)
+template <int DT> __device__ __forceinline__ void fetch_clamped(RawBlock<DT> &b, const uint8_t *base, const uint32_t (&off)[8], int row0, int rows_left) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int last = rows_left - 1 - row0;                 // index (within this thread's octet) of the last valid row; may be < 0
+        const int jc = j <= last ? j : (last > 0 ? last : 0);
+        const uint32_t o = last >= 0 ? off[0] + static_cast<uint32_t>(jc) * (off[1] - off[0]) : off[0] - static_cast<uint32_t>(row0) * (off[1] - off[0]);
+        b.row[j] = load_raw<DT>(base + o);
+    }
+}
+
+// element-wise guarded (ragged feature count, or anything else the vector paths cannot take)
+template <int DT>
+__device__ __forceinline__ void fetch_guarded(RawBlock<DT> &b, const void *m, size_t ld, size_t row0, size_t row_end, size_t f0, size_t features) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const size_t row = row0 + j;
+        if constexpr (DT == FEWBIT_F32) {
+            const float *p = static_cast<const float *>(m) + row * ld + f0;
+            float v[8];
+            for (int e = 0; e < 8; ++e) v[e] = (row < row_end && f0 + e < features) ? p[e] : 0.0f;
+            b.row[j].lo = f32x4{v[0], v[1], v[2], v[3]};
+            b.row[j].hi = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            const uint16_t *p = static_cast<const uint16_t *>(m) + row * ld + f0;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t hw = (row < row_end && f0 + e < features) ? p[e] : 0u;
+                z[e >> 1] |= hw << (16 * (e & 1));
+            }
+            b.row[j].v = z;
+        }
+    }
+}
+
+// raw pieces -> operand dwords (fp32 is rounded to bf16 here); MASK: rows at or beyond `valid` (within the octet) -> 0
+template <int DT, bool MASK> __device__ __forceinline__ void finish_block(const RawBlock<DT> &r, Block8x8 &b, int valid) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        u32x4 z;
+        if constexpr (DT == FEWBIT_F32) {
+            z[0] = Operand<DT>::pack(r.row[j].lo[0], r.row[j].lo[1]); z[1] = Operand<DT>::pack(r.row[j].lo[2], r.row[j].lo[3]);
+            z[2] = Operand<DT>::pack(r.row[j].hi[0], r.row[j].hi[1]); z[3] = Operand<DT>::pack(r.row[j].hi[2], r.row[j].hi[3]);
+        } else {
+            z = r.row[j].v;
+        }
+        if constexpr (MASK) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = j < valid ? z[e] : 0u;
+        }
+        b.row[j] = z;
+    }
+}
+
+// transpose the 8x8 block and store it: feature w of the block -> chunk 32*w + fc of octet `octet` of the stage buffer
+__device__ __forceinline__ void store_feature(const Block8x8 &b, uint8_t *stage, int octet, int fc, int w) {
+    const int e = w >> 1;
+    const uint32_t sel = (w & 1) ? 0x07060302u : 0x05040100u;
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = __builtin_amdgcn_perm(b.row[2 * q + 1][e], b.row[2 * q][e], sel);
+    *reinterpret_cast<u32x4 *>(stage + (static_cast<size_t>(octet) * BN + 32 * w + fc) * 16) = o;
+}
+
+__device__ __forceinline__ void store_block(const Block8x8 &b, uint8_t *stage, int octet, int fc) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) store_feature(b, stage, octet, fc, w);
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------------------------------
+// grid: x = column tiles (256 features), y = row tiles of S (128), z = K slices.  PARTIAL: write fp32 partial sums to
+// `out` + z * proj * features (no scale); otherwise the scaled result in the dtype of M.
+template <int DIST, int DT, bool PARTIAL, bool RAGGED>
+__global__ __launch_bounds__(kThreads, 2) void sketch_kernel(const void *__restrict__ m, size_t rows, size_t features, size_t ld, size_t proj,
+                                                             Key key, float scale, void *__restrict__ out, size_t kslice) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kStageBytes];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const size_t n0 = static_cast<size_t>(blockIdx.x) * BN, m0 = static_cast<size_t>(blockIdx.y) * BM;
+    const size_t k_begin = static_cast<size_t>(blockIdx.z) * kslice;
+    const size_t k_end = k_begin + kslice < rows ? k_begin + kslice : rows;
+    const uint32_t srow = static_cast<uint32_t>(m0 + 32 * wave + c);          // this lane's row of S
+
+    // staging role of this thread: octet `so` (8 rows) of the stage, features [8*sfc, 8*sfc + 8) of the tile
+    const int so = tid >> 5, sfc = tid & 31;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    const size_t klen = k_begin < k_end ? k_end - k_begin : 0;
+    const size_t nstages = (klen + BK - 1) / BK, nfull = klen / BK;
+    if (nstages == 0) return;                      // (block-uniform; cannot happen with the host's slicing)
+    // this thread's piece of row j of a stage: byte offset from the stage's first row (column 0 for a chunk outside the matrix)
+    constexpr int ES = elem_size<DT>();
+    const size_t col = n0 + 8 * sfc < features ? n0 + 8 * sfc : 0;
+    uint32_t off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) off[j] = static_cast<uint32_t>(((8 * so + j) * ld + col) * ES);
+    const uint8_t *stage_base = static_cast<const uint8_t *>(m) + k_begin * ld * ES;
+    const size_t stage_bytes = static_cast<size_t>(BK) * ld * ES;
+
+    RawBlock<DT> raw;
+    Block8x8 blk;
+    // mode of a stage's fetch: 0 interior (no guards), 1 the partial last stage (rows clamped + zeroed), 2 nothing to fetch
+    auto fetch = [&](size_t st, int mode) __attribute__((always_inline)) {
+        if constexpr (RAGGED) {
+            if (mode != 2) fetch_guarded<DT>(raw, m, ld, k_begin + st * BK + 8 * so, k_end, n0 + 8 * sfc, features);
+        } else {
+            if (mode == 0) fetch_fast<DT>(raw, stage_base + st * stage_bytes, off);
+            else if (mode == 1) fetch_clamped<DT>(raw, stage_base + st * stage_bytes, off, 8 * so, static_cast<int>(klen - st * BK));
+        }
+    };
+    auto stage_to_lds = [&](size_t st, int mode, uint8_t *buf) __attribute__((always_inline)) {
+        if (mode == 2) return;
+        if (!RAGGED && mode == 1) finish_block<DT, true>(raw, blk, static_cast<int>(klen - st * BK) - 8 * so);
+        else finish_block<DT, false>(raw, blk, 8);
+        store_block(blk, buf, so, sfc);
+    };
+    auto mode_of = [&](size_t st) { return st < nfull ? 0 : st < nstages ? 1 : 2; };
+
+    // Software pipeline, two stages deep in registers + LDS: while stage s is multiplied (LDS buffer s%2), stage s+1 -- loaded
+    // during stage s-1 -- is transposed and written to the other buffer, and the loads of stage s+2 go out into the registers
+    // that frees.  Every load has a whole stage to land before it is touched; one barrier per stage.
+    fetch(0, mode_of(0));
+    stage_to_lds(0, mode_of(0), lds);
+    fetch(1, (FEWBIT_SKETCH_ABLATE & 1) ? 2 : mode_of(1));
+    __syncthreads();
+
+    uint32_t signs[4] = {0u, 0u, 0u, 0u};
+    // the multiply phase of one stage; FAST: the staging of stage s+1 (registers -> LDS) and the loads of stage s+2 are
+    // unconditional and woven into the MFMA stream by the group barriers (one basic block)
+    auto stage = [&](size_t s, auto fast_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const size_t k0 = k_begin + s * BK;
+        uint8_t *cur = lds + (s & 1) * kStageBytes, *nxt = lds + ((s + 1) & 1) * kStageBytes;
+        const uint8_t *next_base = stage_base + (s + 2) * stage_bytes;
+        if constexpr (FAST) {
+            finish_block<DT, false>(raw, blk, 8);      // (bf16 / fp16: nothing to do; fp32: the 16 v_cvt_pk_bf16_f32)
+        } else {
+            const int m1 = (FEWBIT_SKETCH_ABLATE & 1) ? 2 : mode_of(s + 1), m2 = (FEWBIT_SKETCH_ABLATE & 1) ? 2 : mode_of(s + 2);   // block-uniform
+            stage_to_lds(s + 1, m1, nxt);
+            fetch(s + 2, m2);
+        }
+        if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) {
+            // one Philox call covers this lane's 16 MFMA steps = 256 rows = 4 stages (k_begin is a multiple of 256)
+            if ((s & 3) == 0 && !(FEWBIT_SKETCH_ABLATE & 4)) philox4x32(srow, static_cast<uint32_t>(2 * (k0 >> 8) + h), 0u, 0u, key, signs);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // B fragments: all 8 of a 16-row step are in registers before its first MFMA, and each register is refilled with the
+        // NEXT step's fragment right behind the MFMA that consumed it -- a full step (8 MFMAs = 256 cycles) of LDS latency cover.
+        // hipcc's scheduler would sink every read to just in front of its MFMA (two registers, no cover) and cluster the staging
+        // work in front of the MFMAs, so the order is pinned: one sched_barrier per MFMA slot, and inside a slot the order
+        // written here.  FAST: slot t of step 0 carries the transpose + LDS write of feature t of stage s+1, slot t of step 1
+        // the load of row t of stage s+2 (into the registers the transpose has just freed).
+        const uint8_t *frag = cur + (static_cast<size_t>(h) * BN + c) * 16;
+        u32x4 bq[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bq[t] = *reinterpret_cast<const u32x4 *>(frag + 32 * 16 * t);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            u32x4 a;
+            if constexpr ((FEWBIT_SKETCH_ABLATE & 4) != 0) a = u32x4{srow, srow, srow, srow};
+            else if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) a = rademacher_fragment<DT>(signs, static_cast<int>((s & 3) * 4 + ks));
+            else a = gaussian_fragment<DT>(srow, static_cast<uint32_t>((k0 >> 3) + 2 * ks + h), key);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = Operand<DT>::mfma(a, bq[t], acc[t]);
+                if (ks + 1 < BK / 16 && !(FEWBIT_SKETCH_ABLATE & 8))
+                    bq[t] = *reinterpret_cast<const u32x4 *>(frag + (static_cast<size_t>(2 * (ks + 1)) * BN + 32 * t) * 16);
+                if constexpr (FAST) {
+                    if (ks == 0) store_feature(blk, nxt, so, sfc, t);
+                    if (ks == 1) raw.row[t] = load_raw<DT>(next_base + off[t]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr ((FEWBIT_SKETCH_ABLATE & 2) == 0) __syncthreads();
+    };
+    // two loops, not one loop with a branch: the register allocator then sees the interior body (no branches, everything
+    // pinned) on its own -- with both bodies in one loop it spilt half of the accumulators
+    size_t s = 0;
+    if constexpr (!RAGGED && !(FEWBIT_SKETCH_ABLATE & 1)) {
+        for (; s + 2 < nfull; ++s) stage(s, std::true_type{});
+    }
+    for (; s < nstages; ++s) stage(s, std::false_type{});
+
+    // ---- epilogue: accumulator register r of block t is S row (r&3) + 8*(r>>2) + 4*h, feature 8c + t
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const size_t i = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const size_t f = n0 + 8 * c;
+        if (i >= proj || f >= features) continue;
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t] = acc[t][r];
+        if constexpr (PARTIAL) {
+            float *p = static_cast<float *>(out) + (static_cast<size_t>(blockIdx.z) * proj + i) * features + f;
+            if (f + 8 <= features) {
+                typedef f32x4 __attribute__((aligned(4))) f32x4u;
+                *reinterpret_cast<f32x4u *>(p) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4u *>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                for (int e = 0; e < 8; ++e) if (f + e < features) p[e] = v[e];
+            }
+        } else if constexpr (DT == FEWBIT_F32) {
+            float *p = static_cast<float *>(out) + i * features + f;
+            if (f + 8 <= features) {
+                typedef f32x4 __attribute__((aligned(4))) f32x4u;
+                *reinterpret_cast<f32x4u *>(p) = f32x4{v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale};
+                *reinterpret_cast<f32x4u *>(p + 4) = f32x4{v[4] * scale, v[5] * scale, v[6] * scale, v[7] * scale};
+            } else {
+                for (int e = 0; e < 8; ++e) if (f + e < features) p[e] = v[e] * scale;
+            }
+        } else {
+            uint16_t *p = static_cast<uint16_t *>(out) + i * features + f;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = Operand<DT>::pack(v[2 * e] * scale, v[2 * e + 1] * scale);
+            if (f + 8 <= features) {
+                typedef u32x4 __attribute__((aligned(2))) u32x4u;
+                *reinterpret_cast<u32x4u *>(p) = o;
+            } else {
+                for (int e = 0; e < 8; ++e) if (f + e < features) p[e] = static_cast<uint16_t>(o[e >> 1] >> (16 * (e & 1)));
+            }
+        }
+    }
+}
+
+// partial sums -> result: fixed summation order (slice 0, 1, 2, ...), one scale, one rounding
+template <int DT> __global__ __launch_bounds__(256) void sketch_reduce_kernel(const float *__restrict__ ws, size_t n, int slices, float scale, void *__restrict__ out) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = ws[i];
+    for (int z = 1; z < slices; ++z) s += ws[static_cast<size_t>(z) * n + i];
+    s *= scale;
+    if constexpr (DT == FEWBIT_F32) static_cast<float *>(out)[i] = s;
+    else if constexpr (DT == FEWBIT_F16) static_cast<_Float16 *>(out)[i] = static_cast<_Float16>(s);
+    else static_cast<__bf16 *>(out)[i] = static_cast<__bf16>(s);
+}
+
+// the matrix itself (test seam and debugging aid; the product path never calls it): out[i][r] = S[row0 + i][col0 + r] as fp32
+template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(Key key, size_t row0, size_t col0, size_t nrows, size_t ncols, int dtype, float *__restrict__ out) {
+    const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= nrows * ncols) return;
+    const size_t i = row0 + idx / ncols, r = col0 + idx % ncols;
+    const int j = static_cast<int>(r & 7);
+    float v;
+    if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) {
+        uint32_t w[4];
+        const int s = static_cast<int>((r & 255) >> 4), h = static_cast<int>((r >> 3) & 1);
+        philox4x32(static_cast<uint32_t>(i), static_cast<uint32_t>(2 * (r >> 8) + h), 0u, 0u, key, w);
+        v = ((w[s >> 2] >> (((j & 1) ? 31 : 15) - (4 * (s & 3) + (j >> 1)))) & 1u) ? -1.0f : 1.0f;
+    } else {
+        uint32_t w[4];
+        philox4x32(static_cast<uint32_t>(i), static_cast<uint32_t>(r >> 3), 0u, 1u, key, w);
+        float z0, z1;
+        box_muller(w[j >> 1], z0, z1);
+        v = (j & 1) ? z1 : z0;
+        // rounded as the product kernel rounds its operand
+        if (dtype == FEWBIT_F16) v = static_cast<float>(static_cast<_Float16>(v));
+        else v = static_cast<float>(static_cast<__bf16>(v));
+    }
+    out[idx] = v;
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------
+struct Plan { unsigned gx, gy, gz; size_t kslice; };
+
+int device_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+// K slices: the tile grid of a sketch is small (proj x features) and K = rows is long, so the rows are cut into `gz` slices
+// when that fills the chip better.  cost(z) = (rounds of the CU array with z x tiles workgroups) / z, plus 4 % per extra
+// slice for the partial-sum traffic; slices are multiples of 256 rows (the Rademacher block) and at least 1024 rows.
+Plan make_plan(size_t rows, size_t features, size_t proj, long long forced_slices) {
+    Plan p;
+    p.gx = static_cast<unsigned>((features + BN - 1) / BN);
+    p.gy = static_cast<unsigned>((proj + BM - 1) / BM);
+    const size_t tiles = static_cast<size_t>(p.gx) * p.gy;
+    const size_t slots = static_cast<size_t>(device_cus());
+    size_t max_z = rows / 1024;
+    if (max_z < 1) max_z = 1;
+    if (max_z > 16) max_z = 16;
+    size_t best = 1;
+    if (forced_slices > 0) {
+        best = static_cast<size_t>(forced_slices) < max_z ? static_cast<size_t>(forced_slices) : max_z;
+    } else {
+        double best_cost = 1e30;
+        for (size_t z = 1; z <= max_z; ++z) {
+            const size_t units = tiles * z;
+            const double rounds = static_cast<double>((units + slots - 1) / slots);
+            const double cost = rounds / static_cast<double>(z) * (1.0 + 0.04 * static_cast<double>(z - 1));
+            if (cost < best_cost - 1e-12) { best_cost = cost; best = z; }
+        }
+    }
+    size_t kslice = (rows + best - 1) / best;
+    kslice = (kslice + 255) / 256 * 256;
+    p.kslice = kslice;
+    p.gz = static_cast<unsigned>((rows + kslice - 1) / kslice);
+    if (p.gz < 1) p.gz = 1;
+    return p;
+}
+
+FEWBIT_HIDDEN std::atomic<long long> g_forced_slices{-1};
+
+template <int DIST, int DT>
+int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, Key key, float scale, void *out, void *workspace,
+           size_t workspace_bytes, hipStream_t s) {
+    const Plan p = make_plan(rows, features, proj, g_forced_slices.load(std::memory_order_relaxed));
+    const dim3 grid(p.gx, p.gy, p.gz);
+    const bool ragged = (features % 8) != 0;
+    if (p.gz == 1) {
+        if (ragged) hipLaunchKernelGGL((sketch_kernel<DIST, DT, false, true>), grid, dim3(kThreads), 0, s, m, rows, features, ld, proj, key, scale, out, p.kslice);
+        else hipLaunchKernelGGL((sketch_kernel<DIST, DT, false, false>), grid, dim3(kThreads), 0, s, m, rows, features, ld, proj, key, scale, out, p.kslice);
+    } else {
+        const size_t need = static_cast<size_t>(p.gz) * proj * features * sizeof(float);
+        if (workspace == nullptr || workspace_bytes < need)
+            return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", need, workspace_bytes);
+        if (ragged) hipLaunchKernelGGL((sketch_kernel<DIST, DT, true, true>), grid, dim3(kThreads), 0, s, m, rows, features, ld, proj, key, scale, workspace, p.kslice);
+        else hipLaunchKernelGGL((sketch_kernel<DIST, DT, true, false>), grid, dim3(kThreads), 0, s, m, rows, features, ld, proj, key, scale, workspace, p.kslice);
+        const size_t n = proj * features;
+        hipLaunchKernelGGL((sketch_reduce_kernel<DT>), dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s,
+                           static_cast<const float *>(workspace), n, static_cast<int>(p.gz), scale, out);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sketch: %s", hipGetErrorString(e));
+    return FEWBIT_OK;
+}
+
+template <int DIST>
+int launch_dtype(int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Key key, float scale, void *out,
+                 void *workspace, size_t workspace_bytes, hipStream_t s) {
+    switch (dtype) {
+    case FEWBIT_F32: return launch<DIST, FEWBIT_F32>(m, rows, features, ld, proj, key, scale, out, workspace, workspace_bytes, s);
+    case FEWBIT_F16: return launch<DIST, FEWBIT_F16>(m, rows, features, ld, proj, key, scale, out, workspace, workspace_bytes, s);
+    case FEWBIT_BF16: return launch<DIST, FEWBIT_BF16>(m, rows, features, ld, proj, key, scale, out, workspace, workspace_bytes, s);
+    default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: unknown dtype %d", dtype);
+    }
+}
+
+}  // namespace sketch
+}  // namespace fewbit_hip
+
+using namespace fewbit_hip;
+using namespace fewbit_hip::sketch;
+
+extern "C" {
+
+size_t fewbit_hip_sketch_workspace(size_t rows, size_t features, size_t proj) {
+    if (rows == 0 || features == 0 || proj == 0) return 0;
+    const Plan p = make_plan(rows, features, proj, g_forced_slices.load(std::memory_order_relaxed));
+    return p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : 0;
+}
+
+int fewbit_hip_sketch(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, uint64_t seed, double scale,
+                      void *out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (dist != FEWBIT_SKETCH_RADEMACHER && dist != FEWBIT_SKETCH_GAUSSIAN) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: unknown distribution %d", dist);
+    if (proj == 0 || features == 0) return FEWBIT_OK;
+    if (out == nullptr || (m == nullptr && rows != 0)) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: null pointer");
+    if (ld < features) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: leading dimension %zu < features %zu", ld, features);
+    if (proj > 0xffffffffull || (rows >> 3) > 0xffffffffull) return fail(FEWBIT_ERR_UNSUPPORTED, "sketch: proj and rows/8 must fit 32 bits");
+    if ((ld + 1) * 72 * 4 >= 0x80000000ull) return fail(FEWBIT_ERR_UNSUPPORTED, "sketch: leading dimension %zu too large (a K stage must span less than 2 GiB)", ld);
+    const Key key{static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rows == 0) {                                  // empty sum: zeros
+        const size_t es = dtype == FEWBIT_F32 ? 4 : 2;
+        if (hipMemsetAsync(out, 0, proj * features * es, s) != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sketch: memset failed");
+        return FEWBIT_OK;
+    }
+    if (dist == FEWBIT_SKETCH_RADEMACHER)
+        return launch_dtype<FEWBIT_SKETCH_RADEMACHER>(dtype, m, rows, features, ld, proj, key, static_cast<float>(scale), out, workspace, workspace_bytes, s);
+    return launch_dtype<FEWBIT_SKETCH_GAUSSIAN>(dtype, m, rows, features, ld, proj, key, static_cast<float>(scale), out, workspace, workspace_bytes, s);
+}
+
+int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, size_t col0, size_t nrows, size_t ncols, float *out, void *stream) {
+    if (dist != FEWBIT_SKETCH_RADEMACHER && dist != FEWBIT_SKETCH_GAUSSIAN) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: unknown distribution %d", dist);
+    if (nrows == 0 || ncols == 0) return FEWBIT_OK;
+    if (out == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: null pointer");
+    const Key key{static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
+    const size_t n = nrows * ncols;
+    const dim3 grid(static_cast<unsigned>((n + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dist == FEWBIT_SKETCH_RADEMACHER) hipLaunchKernelGGL((sketch_matrix_kernel<FEWBIT_SKETCH_RADEMACHER>), grid, dim3(256), 0, s, key, row0, col0, nrows, ncols, dtype, out);
+    else hipLaunchKernelGGL((sketch_matrix_kernel<FEWBIT_SKETCH_GAUSSIAN>), grid, dim3(256), 0, s, key, row0, col0, nrows, ncols, dtype, out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sketch_matrix: %s", hipGetErrorString(e));
+    return FEWBIT_OK;
+}
+
+int fewbit_hip_sketch_describe(size_t rows, size_t features, size_t proj, char *buf, size_t len) {
+    if (buf == nullptr || len == 0) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch_describe: no buffer");
+    const Plan p = make_plan(rows, features, proj, g_forced_slices.load(std::memory_order_relaxed));
+    snprintf(buf, len, "{\"kernel\": \"sketch_kernel (128x256 tile, K stage 64, v_mfma_f32_32x32x16)\", \"grid\": [%u, %u, %u], \"threads\": %d, "
+                       "\"k_slice\": %zu, \"lds_bytes\": %d, \"workspace_bytes\": %zu}",
+             p.gx, p.gy, p.gz, kThreads, p.kslice, 2 * kStageBytes, p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : static_cast<size_t>(0));
+    return FEWBIT_OK;
+}
+
+void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t o[4];
+    philox4x32(counter[0], counter[1], counter[2], counter[3], Key{key[0], key[1]}, o);
+    for (int i = 0; i < 4; ++i) out[i] = o[i];
+}
+
+int fewbit_hip_sketch_tune_slices(long long slices) {
+    g_forced_slices.store(slices, std::memory_order_relaxed);
+    return FEWBIT_OK;
+}
+
+}  // extern "C"

@@ -60,6 +60,7 @@
 #endif
 
 // ROCm builds of PyTorch expose HIP devices as device type `cuda`; these are the matching guard / stream types
+#include <ATen/hip/EmptyTensor.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
@@ -100,9 +101,11 @@ void check_table(const Tensor &self, const Tensor &table, const char *name) {
                 ", input ", self.scalar_type());
 }
 
+// the packed state: straight from the caching allocator (what at::empty ends in for a GPU tensor, without its two
+// dispatcher hops -- this allocation is on the path of every forward)
 Tensor new_state(const Tensor &like, int64_t numel, int nbits) {
     const auto nbytes = static_cast<int64_t>(fewbit_hip_state_nbytes(static_cast<size_t>(numel), nbits));
-    return torch::empty({nbytes}, torch::TensorOptions().device(like.device()).dtype(torch::kUInt8));
+    return Tensor(at::detail::empty_cuda({nbytes}, torch::kUInt8, like.device(), std::nullopt));
 }
 
 // ---- raw launches (no autograd) ------------------------------------------------------------------

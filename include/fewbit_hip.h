@@ -52,7 +52,9 @@
 extern "C" {
 #endif
 
-#define FEWBIT_HIP_ABI_VERSION 1
+/* 1: the quantized-activation path.  2: + fewbit_hip_describe_*, fewbit_hip_tune (added in round 3 without a bump) and the
+ * random-projection entry points fewbit_hip_sketch* (round 4).  Bindings check it and refuse an older library by name. */
+#define FEWBIT_HIP_ABI_VERSION 2
 
 typedef enum fewbit_status {
     FEWBIT_OK = 0,
@@ -156,6 +158,36 @@ int fewbit_hip_tune(const char *key, long long value);
 /* stand-alone codec (test seam): int32 codes <-> packed state, 1 <= nbits <= 8 */
 int fewbit_hip_pack_codes(const int32_t *codes, uint8_t *state, size_t n, int nbits, void *stream);
 int fewbit_hip_unpack_codes(const uint8_t *state, int32_t *codes, size_t n, int nbits, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Random-projection products of the randomized linear layers:  out = scale * S . M
+ *   replaces  `proj = T.randn((proj_features, rows)); proj @ input_view`  and the Rademacher twin,
+ *             fewbit/functional/linear.py:133-146 (forward) and :195-208 (backward, which re-draws the same matrix
+ *             from the saved generator state)
+ *   S    proj x rows, NEVER materialised: a pure function of (seed, row, column) evaluated in registers and fed to the
+ *        matrix cores (definition: fewbit_amd/csrc/fewbit_sketch.hip header; host model: tests/sketch_reference.py).
+ *        Forward and backward pass the same seed and get the same S.
+ *   m    rows x features, row-major with leading dimension `ld` (elements), dtype F32 / F16 / BF16; fp32 is rounded to bf16
+ *        while it is staged (the products run on the bf16 matrix pipe, accumulation is fp32)
+ *   out  proj x features, contiguous, the dtype of m
+ *   workspace  fewbit_hip_sketch_workspace(rows, features, proj) bytes of device memory (0 when the rows are not sliced);
+ *        contents are scratch.  The result is deterministic: the same arguments give the same bits.
+ */
+typedef enum fewbit_sketch_dist { FEWBIT_SKETCH_RADEMACHER = 0, FEWBIT_SKETCH_GAUSSIAN = 1 } fewbit_sketch_dist;
+
+size_t fewbit_hip_sketch_workspace(size_t rows, size_t features, size_t proj);
+int fewbit_hip_sketch(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, uint64_t seed,
+                      double scale, void *out, void *workspace, size_t workspace_bytes, void *stream);
+/* S[row0 .. row0+nrows) x [col0 .. col0+ncols) itself as fp32 (rounded as the product kernel rounds its operand for
+ * `dtype`) -- test seam and debugging aid; the product path never materialises S */
+int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, size_t col0, size_t nrows, size_t ncols, float *out,
+                             void *stream);
+/* launch shape a fewbit_hip_sketch call would use, as JSON: {"kernel", "grid": [x, y, z], "threads", "k_slice", ...} */
+int fewbit_hip_sketch_describe(size_t rows, size_t features, size_t proj, char *buf, size_t len);
+/* measurement hook: force the number of row slices (> 0), -1 = built-in policy */
+int fewbit_hip_sketch_tune_slices(long long slices);
+/* Philox4x32-10 on the HOST (the generator behind S; known-answer tests run it without a GPU) */
+void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,79 @@
+"""Random-projection product S.M on MI355X: the Philox-in-register MFMA kernel (fewbit_hip_sketch) against what it replaces
+(draw S into HBM with torch.randn / randint, then torch.matmul = hipBLASLt), at the shapes of RoBERTa-base's linear layers
+(rows = 128 x 128 tokens).  TFLOP/s = 2 * proj * rows * features / time; peak = 2500 (bf16 dense)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from fewbit_amd import cabi
+
+DEV = 'cuda'
+PEAK = 2500.0
+
+
+def timed(f, reps=20, warm=3):
+    for _ in range(warm):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps       # us
+
+
+def main():
+    out = []
+    slices = [int(s) for s in os.environ.get('SLICES', '-1').split(',')]
+    shapes = [(16384, 768, 1638), (16384, 3072, 1638), (16384, 768, 3276), (16384, 3072, 3276), (16384, 3072, 8192), (65536, 4096, 4096)]
+    if os.environ.get('QUICK'):
+        shapes = shapes[:2]
+    for dtype in (torch.bfloat16, torch.float32):
+        for rows, features, proj in shapes:
+            m = torch.randn(rows, features, device=DEV).to(dtype)
+            flops = 2.0 * proj * rows * features
+            rec = {'dtype': str(dtype).split('.')[-1], 'rows': rows, 'features': features, 'proj': proj}
+            for dist in ('rademacher', 'gaussian'):
+                for z in slices:
+                    cabi.tune_sketch_slices(z)
+                    plan = cabi.describe_sketch(rows, features, proj)
+                    ws = torch.empty(max(plan['workspace_bytes'], 1), dtype=torch.uint8, device=DEV)
+                    o = torch.empty(proj, features, dtype=dtype, device=DEV)
+                    us = timed(lambda: cabi.sketch(dist, m, proj, 1234, 1.0 / proj, out=o, workspace=ws))
+                    rec[f'{dist}_z{plan["grid"][2]}'] = {'us': round(us, 1), 'TFLOPs': round(flops / us / 1e6, 1), 'frac_of_bf16_peak': round(flops / us / 1e6 / PEAK, 3),
+                                                       'grid': plan['grid']}
+            cabi.tune_sketch_slices(-1)
+            # what it replaces: S in HBM + library GEMM (S drawn in the operand dtype of the matrix pipe)
+            op = torch.bfloat16 if dtype != torch.float16 else torch.float16
+            mo = m.to(op)
+
+            def torch_gauss():
+                S = torch.randn(proj, rows, device=DEV, dtype=op)
+                return (S @ mo) * (1.0 / proj)
+
+            def torch_rad():
+                S = torch.randint(0, 2, (proj, rows), device=DEV, dtype=torch.int8).to(op) * 2 - 1
+                return (S @ mo) * (1.0 / proj)
+
+            S = torch.randn(proj, rows, device=DEV, dtype=op)
+            rec['torch_randn_plus_matmul_us'] = round(timed(torch_gauss), 1)
+            rec['torch_randint_plus_matmul_us'] = round(timed(torch_rad), 1)
+            rec['torch_matmul_only_us'] = round(timed(lambda: S @ mo), 1)
+            rec['torch_matmul_only_TFLOPs'] = round(flops / rec['torch_matmul_only_us'] / 1e6, 1)
+            rec['S_bytes_not_materialised'] = proj * rows * 2
+            print(json.dumps(rec), flush=True)
+            out.append(rec)
+            del m, S, mo
+            torch.cuda.empty_cache()
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'sketch_bench.json'), 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()

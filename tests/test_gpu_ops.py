@@ -285,6 +285,8 @@ def _graph_names(fn):
 def test_both_node_routes_save_the_same_bytes_and_give_the_same_gradients(route):
     """every operator family x in place / out of place x 3 dtypes: packed state and gradient vs the oracle under both
     autograd routes, plus autograd's own errors (leaf in place, second backward)"""
+    # (non-leaf inputs are made with .clone(), not `* 1.0`: ATen's own fp16 multiply turns -0 into +0 in its remainder loop
+    # -- scratch/dbg_sign.py -- and MulBackward0 would put that into the gradient the oracle is compared with)
     import oracle
     g = torch.Generator().manual_seed(3)
     for dtype in (torch.float32, torch.bfloat16, torch.float16):
@@ -300,9 +302,9 @@ def test_both_node_routes_save_the_same_bytes_and_give_the_same_gradients(route)
             seen = []
             with torch.autograd.graph.saved_tensors_hooks(lambda t: (seen.append(t), t)[1], lambda t: t):
                 if inplace:
-                    y = torch.ops.fewbit.gelu(xd * 1.0, inner.to(DEV), levels.to(DEV))
+                    y = torch.ops.fewbit.gelu(xd.clone(), inner.to(DEV), levels.to(DEV))
                 else:
-                    y = torch.ops.fewbit.continuous_out(xd * 1.0, inner.to(DEV), levels.to(DEV), 2, 0.0, 0.0)
+                    y = torch.ops.fewbit.continuous_out(xd.clone(), inner.to(DEV), levels.to(DEV), 2, 0.0, 0.0)
             assert ('FewbitPackedBackward' in y.grad_fn.name()) == (route == 'default')
             assert torch.equal([t for t in seen if t.dtype == torch.uint8][0].cpu(), state_o)
             y.backward(gy.to(DEV), retain_graph=True)
@@ -311,7 +313,7 @@ def test_both_node_routes_save_the_same_bytes_and_give_the_same_gradients(route)
             with pytest.raises(RuntimeError, match='second time'):
                 y.backward(gy.to(DEV))
             xr = x.to(DEV).requires_grad_()
-            yr = torch.ops.fewbit.relu(xr * 1.0) if inplace else torch.ops.fewbit.stepwise1_out(xr * 1.0, 4, 0.0, 0.0)
+            yr = torch.ops.fewbit.relu(xr.clone()) if inplace else torch.ops.fewbit.stepwise1_out(xr.clone(), 4, 0.0, 0.0)
             yr.backward(gy.to(DEV))
             assert_bit_equal(xr.grad, gr_o, f'relu {dtype} inplace={inplace} {route}')
         with pytest.raises(RuntimeError, match='leaf Variable'):

@@ -672,9 +672,13 @@ def test_folded_key_every_fp32_pattern():
 
 
 def test_every_launch_shape_and_tile_width_gives_the_same_bytes():
-    """fewbit_hip_tune (groups per lane per stage, resident blocks per CU, resident / chunked shape) only changes HOW the tensor is swept; state, y and gx must not change by a bit.  Sizes around several tiles
-    and a ragged tail; bf16 (pattern-table and search forward, backward U = 1, 2, 4), fp32 (search forward U = 1, 2) and
-    the 1-bit family."""
+    """fewbit_hip_tune (groups per lane per stage, resident blocks per CU, resident / chunked shape) only changes HOW the tensor
+    is swept; state, y and gx must not change by a bit.  Sizes around several tiles and a ragged tail; bf16, fp32 and the
+    1-bit family.  Tile widths: the SHIPPED library holds U = 1, 2 for the backward, the 1-bit kernels and the fp32 search
+    forward, and U = 1 only for the 16-bit search forward and the pattern-table forward (UList<> in fewbit_kernels.hip; a
+    requested U the build does not hold runs the list's first entry, U = 1) -- what each call really used is read back from
+    fewbit_hip_describe_* and asserted, so this test cannot claim coverage of a width that never ran (U = 4 and the
+    table kernel's U = 2 exist only in the -DFEWBIT_SWEEP measurement build, swept by scratch/shape_sweep.py)."""
     import json
     keys = ('waves_per_cu', 'chunk', 'lut_chunk', 'lut_blocks_per_cu', 'lut_min', 'u_fwd', 'u_bwd', 'u_lut', 'u_step1')
     try:
@@ -691,12 +695,20 @@ def test_every_launch_shape_and_tile_width_gives_the_same_bytes():
             gx0 = cabi.quantize_backward(gy, s0, levels)
             r0, rs0 = cabi.stepwise1_forward('leaky_relu', x, 0.1)
             rg0 = cabi.stepwise1_backward('leaky_relu', gy, rs0, 0.1)
-            seen = set()
+            seen, widths = set(), set()
             for u in (1, 2, 4):
                 for wpc, chunk in ((-1, -1), (8, 0), (16, 1), (32, 3)):
                     for lut_min in (0, 1 << 60):
                         cabi.tune(u_fwd=u, u_bwd=u, u_lut=u, u_step1=u, waves_per_cu=wpc, chunk=chunk, lut_chunk=chunk, lut_min=lut_min)
-                        seen.add(json.dumps(cabi.describe_backward(dtype, n, 8), sort_keys=True))
+                        db = cabi.describe_backward(dtype, n, 8)
+                        df = cabi.describe_forward('gelu', dtype, n, 7)
+                        seen.add(json.dumps(db, sort_keys=True))
+                        held = u if u in (1, 2) else 1                 # what the shipped build holds (see the docstring)
+                        assert db['u'] == held, (db, u)
+                        table_or_16bit_search = 'lut' in df['kernel'] or dt != 'f32'
+                        assert df['u'] == (1 if table_or_16bit_search else held), (df, u)
+                        assert cabi.describe_stepwise1_backward('leaky_relu', dtype, n)['u'] == held
+                        widths.add((db['u'], df['u']))
                         y, s = cabi.quantize_forward('gelu', x, borders)
                         gx = cabi.quantize_backward(gy, s, levels)
                         assert torch.equal(s, s0) and torch.equal(bits(y), bits(y0)) and torch.equal(bits(gx), bits(gx0)), (dt, n, u, wpc, chunk, lut_min)
@@ -704,6 +716,7 @@ def test_every_launch_shape_and_tile_width_gives_the_same_bytes():
                         rg = cabi.stepwise1_backward('leaky_relu', gy, rs, 0.1)
                         assert torch.equal(rs, rs0) and torch.equal(bits(r), bits(r0)) and torch.equal(bits(rg), bits(rg0))
             assert len(seen) >= 6                          # the settings really did change the launch
+            assert {w[0] for w in widths} == {1, 2}        # both backward widths of the shipped build ran
             cabi.tune(**{k: -1 for k in keys})             # in place (the reference operator's own mode): the same bytes
             xi, gi = x.clone(), gy.clone()
             yi, si = cabi.quantize_forward('gelu', xi, borders, out=xi)

@@ -1,0 +1,104 @@
+"""fewbit_hip_sketch on the GPU (fewbit_amd/csrc/fewbit_sketch.hip): the random matrix the kernel generates IN REGISTERS is
+exactly the host model's (tests/sketch_reference.py evaluates the same Philox stream), and the product equals S . M."""
+import pytest
+import torch
+
+import sketch_reference as ref
+from fewbit_amd import cabi
+from helpers import ulp_distance
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('seed', (0, 1, 0x1234567890abcdef, 2**64 - 1))
+def test_rademacher_matrix_is_the_models_bit_for_bit(seed):
+    for (nr, nc, r0, c0) in ((70, 1000, 0, 0), (33, 515, 1000, 250), (4, 64, 2**31, 2**33 + 8)):
+        got = cabi.sketch_matrix('rademacher', torch.bfloat16, seed, nr, nc, r0, c0).cpu()
+        assert torch.equal(got, ref.rademacher(seed, nr, nc, r0, c0)), (seed, nr, nc)
+
+
+@pytest.mark.parametrize('dtype', (torch.bfloat16, torch.float16))
+def test_gaussian_matrix_is_the_models_up_to_one_step_of_the_operand_dtype(dtype):
+    """same Philox words, same Box-Muller; v_log/v_sqrt/v_sin/v_cos against libm: the rounded operand may differ by one step"""
+    for seed, (nr, nc, r0, c0) in ((5, (64, 1024, 0, 0)), (99, (17, 333, 123, 77))):
+        got = cabi.sketch_matrix('gaussian', dtype, seed, nr, nc, r0, c0).cpu()
+        want = ref.gaussian(seed, nr, nc, dtype, r0, c0)
+        d = ulp_distance(got.to(dtype), want.to(dtype))
+        # (near zero one operand step is tiny and cos / sin of a quarter turn is an exact 0 in hardware, 6e-17 in libm:
+        # there the comparison is absolute)
+        ok = (d <= 1) | ((got - want).abs() <= 2.0**-12)
+        assert bool(ok.all()), (int(d[~ok].max()), float((got - want).abs().max()))
+        assert float((d == 0).float().mean()) > 0.97
+        exact = ref.gaussian(seed, nr, nc, dtype, r0, c0, rounded=False)
+        assert float((got.double() - exact).abs().max()) < 0.02
+
+
+def _product_case(dist, dtype, rows, features, proj, seed, ld=None, scale=1.0):
+    g = torch.Generator().manual_seed(rows * 31 + features)
+    m = torch.randn(rows, ld or features, generator=g).to(dtype)[:, :features]
+    got = cabi.sketch(dist, m.to(DEV) if ld is None else m.to(DEV), proj, seed, scale)
+    assert got.shape == (proj, features) and got.dtype == dtype
+    S = ref.matrix(dist, seed, proj, rows, dtype).double()
+    op = torch.float16 if dtype == torch.float16 else torch.bfloat16
+    mm = m.to(op).double()
+    want = scale * (S @ mm)
+    bound = abs(scale) * (S.abs() @ mm.abs())                      # scale of the individual sums
+    err = (got.cpu().double() - want).abs()
+    # fp32 accumulation of exact products (+ for Gaussian one operand step on a few entries), then one rounding to `dtype`
+    out_eps = {torch.float32: 2.0**-22, torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}[dtype]
+    slack = (2.0**-8 if dist == 'gaussian' else 0.0) * bound / max(rows, 1)**0.5 * 8
+    assert bool((err <= out_eps * want.abs() + 1e-5 * bound + slack + 1e-30).all()), (dist, dtype, rows, features, proj, float((err / (bound + 1e-30)).max()))
+    return got
+
+
+@pytest.mark.parametrize('dist', ('rademacher', 'gaussian'))
+@pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16, torch.float16))
+def test_product_equals_the_model_matrix_times_m(dist, dtype):
+    for rows, features, proj in ((64, 256, 128), (100, 37, 5), (1000, 264, 130), (257, 8, 1), (4096, 512, 256), (3000, 770, 200)):
+        _product_case(dist, dtype, rows, features, proj, seed=rows + 17)
+    _product_case(dist, dtype, 512, 100, 64, seed=3, ld=136, scale=0.125)         # a strided view, a scale
+
+
+def test_row_slices_are_deterministic_and_agree():
+    """split K: every slicing gives the same sums up to fp32 re-association, and a repeated call the same BITS"""
+    m = torch.randn(8192, 384, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(DEV)
+    try:
+        outs = {}
+        for z in (1, 2, 4, 8):
+            cabi.tune_sketch_slices(z)
+            assert cabi.describe_sketch(8192, 384, 200)['grid'][2] == z
+            a = cabi.sketch('rademacher', m.float(), 200, 42)
+            b = cabi.sketch('rademacher', m.float(), 200, 42)
+            assert torch.equal(a, b)
+            outs[z] = a
+        for z in (2, 4, 8):
+            assert torch.allclose(outs[z], outs[1], rtol=1e-5, atol=1e-3)
+    finally:
+        cabi.tune_sketch_slices(-1)
+    plan = cabi.describe_sketch(16384, 3072, 1638)
+    assert plan['grid'][0] == 12 and plan['grid'][1] == 13 and plan['grid'][2] >= 1 and plan['threads'] == 256
+
+
+def test_empty_and_degenerate_shapes():
+    assert cabi.sketch('gaussian', torch.zeros(0, 16, device=DEV), 4, 1).abs().sum() == 0
+    assert cabi.sketch('rademacher', torch.zeros(16, 0, device=DEV), 4, 1).shape == (4, 0)
+    assert cabi.sketch('rademacher', torch.ones(16, 8, device=DEV), 0, 1).shape == (0, 8)
+    with pytest.raises(cabi.FewbitHipError):
+        cabi.sketch('rademacher', torch.ones(16, 8), 4, 1)                          # host tensor
+    with pytest.raises(cabi.FewbitHipError):
+        cabi.sketch('rademacher', torch.ones(8, 16, device=DEV).t(), 4, 1)          # features not contiguous
+
+
+def test_estimator_is_unbiased_on_the_gpu_kernel():
+    """E[(S G)^T (S X)] / proj = G^T X: mean over seeds of the kernel's own products converges to the exact product"""
+    g = torch.Generator().manual_seed(0)
+    x, gy = torch.randn(512, 48, generator=g).to(DEV), torch.randn(512, 40, generator=g).to(DEV)
+    exact = gy.T @ x
+    for dist in ('rademacher', 'gaussian'):
+        acc = torch.zeros_like(exact)
+        n = 300
+        for seed in range(n):
+            acc += cabi.sketch(dist, gy, 64, seed).T @ cabi.sketch(dist, x, 64, seed, 1.0 / 64)
+        rel = float(torch.linalg.norm(acc / n - exact) / torch.linalg.norm(exact))
+        assert rel < 0.25, (dist, rel)                                    # one draw: ~sqrt(512/64) = 2.8; mean of 300: ~0.16

@@ -1,0 +1,44 @@
+"""The generator behind the random-projection kernel, without a GPU: Philox4x32-10 of the library (host entry point of the
+C-ABI) and of the numpy model against the published known-answer vectors, and the statistics of the model's matrices."""
+import numpy as np
+import torch
+
+import sketch_reference as ref
+from fewbit_amd import cabi
+
+# Random123 kat_vectors, philox4x32 with 10 rounds: (counter, key, expected)
+KAT = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+       ((0xffffffff, ) * 4, (0xffffffff, ) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+       ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+
+
+def test_philox_known_answers_library_and_model():
+    for ctr, key, want in KAT:
+        assert cabi.philox4x32(ctr, key) == want
+        got = ref.philox4x32(*[np.array([c]) for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+    # the model on arrays == the library call by call
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 2**32, size=(4, 50), dtype=np.uint64)
+    got = ref.philox4x32(c[0], c[1], c[2], c[3], 0x12345678, 0x9abcdef0)
+    for n in range(50):
+        assert cabi.philox4x32(tuple(int(c[k][n]) for k in range(4)), (0x12345678, 0x9abcdef0)) == tuple(int(g[n]) for g in got)
+
+
+def test_model_matrices_have_the_right_moments_and_are_functions_of_the_seed():
+    S = ref.rademacher(7, 96, 2048)
+    assert set(S.unique().tolist()) == {-1.0, 1.0}
+    assert abs(float(S.mean())) < 0.01 and abs(float((S[:48] * S[48:]).mean())) < 0.01          # rows uncorrelated
+    assert abs(float((S[:, :-1] * S[:, 1:]).mean())) < 0.01                                       # neighbours uncorrelated
+    G = ref.gaussian(7, 96, 2048, rounded=False)
+    assert abs(float(G.mean())) < 0.01 and abs(float(G.var()) - 1.0) < 0.02
+    kurt = float((G**4).mean() / G.var()**2)
+    assert abs(kurt - 3.0) < 0.1
+    assert abs(float((G[:, 0::2] * G[:, 1::2]).mean())) < 0.01                                   # the two halves of a Box-Muller pair
+    # windows of the same matrix agree with the whole; another seed gives another matrix
+    assert torch.equal(ref.rademacher(7, 10, 300, row0=5, col0=250), ref.rademacher(7, 96, 2048)[5:15, 250:550])
+    assert torch.equal(ref.gaussian(7, 10, 300, row0=5, col0=250), ref.gaussian(7, 96, 2048)[5:15, 250:550])
+    assert not torch.equal(ref.rademacher(8, 96, 2048), S)
+    # E[S^T S] = proj * I: the property the estimator's unbiasedness rests on
+    S = ref.rademacher(3, 4096, 24)
+    assert float((S.T @ S / 4096 - torch.eye(24)).abs().max()) < 0.07
