@@ -15,7 +15,7 @@ __all__ = [
     'quantize_backward', 'bind_forward', 'bind_backward', 'bind_stepwise1_forward', 'bind_stepwise1_backward',
     'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError', 'describe_forward',
     'describe_backward', 'describe_stepwise1_forward', 'describe_stepwise1_backward', 'tune',
-    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices',
+    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves',
     'philox4x32',
 ]
 
@@ -39,7 +39,7 @@ SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwid
            'fewbit_hip_describe_quantize_forward', 'fewbit_hip_describe_quantize_backward',
            'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune',
            'fewbit_hip_sketch_workspace', 'fewbit_hip_sketch', 'fewbit_hip_sketch_matrix', 'fewbit_hip_sketch_describe',
-           'fewbit_hip_sketch_tune_slices', 'fewbit_hip_philox4x32')
+           'fewbit_hip_sketch_tune_slices', 'fewbit_hip_sketch_tune_waves', 'fewbit_hip_philox4x32')
 
 
 class FewbitHipError(RuntimeError):
@@ -103,6 +103,8 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_sketch_describe.argtypes = [sz, sz, sz, cp, sz]
         L.fewbit_hip_sketch_tune_slices.restype = i32
         L.fewbit_hip_sketch_tune_slices.argtypes = [ctypes.c_longlong]
+        L.fewbit_hip_sketch_tune_waves.restype = i32
+        L.fewbit_hip_sketch_tune_waves.argtypes = [ctypes.c_longlong]
         L.fewbit_hip_philox4x32.restype = None
         L.fewbit_hip_philox4x32.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
         _lib = L
@@ -407,6 +409,11 @@ def describe_sketch(rows: int, features: int, proj: int, device=None) -> dict:
 def tune_sketch_slices(slices: int) -> None:
     """measurement hook: force the number of row slices (-1 = built-in policy)"""
     _check(lib().fewbit_hip_sketch_tune_slices(int(slices)))
+
+
+def tune_sketch_waves(waves: int) -> None:
+    """measurement hook: waves per workgroup, 4 (128-row tile) or 8 (256-row tile); -1 = built-in policy"""
+    _check(lib().fewbit_hip_sketch_tune_waves(int(waves)))
 
 
 def philox4x32(counter, key):

@@ -63,10 +63,16 @@ FEWBIT_HIDDEN int fail(int code, const char *fmt, ...) __attribute__((format(pri
 namespace sketch {
 
 constexpr int kWave = 64;
-constexpr int kThreads = 256;
-constexpr int BM = 128, BN = 256, BK = 64;
+constexpr int BN = 256;                     // features per tile
 constexpr int NT = BN / 32;                 // MFMA column blocks per wave
-constexpr int kStageBytes = BK * BN * 2;    // 32 KiB
+// A workgroup of W waves owns 32*W rows of S and multiplies them with K stages of 16*W rows of M (one 8x8 block per thread):
+//   W = 4:  128 x 256 tile, stages of  64 rows, 2 x 32 KiB of LDS, two workgroups per CU
+//   W = 8:  256 x 256 tile, stages of 128 rows, 2 x 64 KiB of LDS, one workgroup per CU (half the staging work, LDS writes and
+//           L2 reads per MFMA; the upper four waves do their staging four steps later than the lower four)
+template <int W> struct Tile {
+    static constexpr int kThreads = 64 * W, BM = 32 * W, BK = 16 * W, kSteps = BK / 16, kStageBytes = BK * BN * 2;
+    static constexpr int kStagesPerBlock = 256 / BK;           // stages per 256-row Rademacher block
+};
 constexpr int kPhiloxRounds = 10;
 #ifndef FEWBIT_SKETCH_ABLATE
 #define FEWBIT_SKETCH_ABLATE 0      // measurement builds only (results are WRONG): 1 no staging of M after the first stage, 2 no barrier in
@@ -264,10 +270,12 @@ __device__ __forceinline__ void store_block(const Block8x8 &b, uint8_t *stage, i
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
 // grid: x = column tiles (256 features), y = row tiles of S (128), z = K slices.  PARTIAL: write fp32 partial sums to
 // `out` + z * proj * features (no scale); otherwise the scaled result in the dtype of M.
-template <int DIST, int DT, bool PARTIAL, bool RAGGED>
-__global__ __launch_bounds__(kThreads, 2) void sketch_kernel(const void *__restrict__ m, size_t rows, size_t features, size_t ld, size_t proj,
-                                                             Key key, float scale, void *__restrict__ out, size_t kslice) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kStageBytes];
+template <int DIST, int DT, bool PARTIAL, bool RAGGED, int W>
+__global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restrict__ m, size_t rows, size_t features, size_t ld, size_t proj,
+                                                           Key key, float scale, void *__restrict__ out, size_t kslice) {
+    constexpr int BM = Tile<W>::BM, BK = Tile<W>::BK, kStageBytes = Tile<W>::kStageBytes, kSteps = Tile<W>::kSteps;
+    constexpr int kPerBlock = Tile<W>::kStagesPerBlock;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];        // 2 * kStageBytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const size_t n0 = static_cast<size_t>(blockIdx.x) * BN, m0 = static_cast<size_t>(blockIdx.y) * BM;
@@ -326,8 +334,9 @@ __global__ __launch_bounds__(kThreads, 2) void sketch_kernel(const void *__restr
     uint32_t signs[4] = {0u, 0u, 0u, 0u};
     // the multiply phase of one stage; FAST: the staging of stage s+1 (registers -> LDS) and the loads of stage s+2 are
     // unconditional and woven into the MFMA stream by the group barriers (one basic block)
-    auto stage = [&](size_t s, auto fast_tag) __attribute__((always_inline)) {
+    auto stage = [&](size_t s, auto fast_tag, auto first_tag) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr int first = decltype(first_tag)::value;      // the step whose slots carry the LDS writes (the loads follow one step later)
         const size_t k0 = k_begin + s * BK;
         uint8_t *cur = lds + (s & 1) * kStageBytes, *nxt = lds + ((s + 1) & 1) * kStageBytes;
         const uint8_t *next_base = stage_base + (s + 2) * stage_bytes;
@@ -339,8 +348,8 @@ __global__ __launch_bounds__(kThreads, 2) void sketch_kernel(const void *__restr
             fetch(s + 2, m2);
         }
         if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) {
-            // one Philox call covers this lane's 16 MFMA steps = 256 rows = 4 stages (k_begin is a multiple of 256)
-            if ((s & 3) == 0 && !(FEWBIT_SKETCH_ABLATE & 4)) philox4x32(srow, static_cast<uint32_t>(2 * (k0 >> 8) + h), 0u, 0u, key, signs);
+            // one Philox call covers this lane's 16 MFMA steps = 256 rows = 4 or 2 stages (k_begin is a multiple of 256)
+            if ((s & (kPerBlock - 1)) == 0 && !(FEWBIT_SKETCH_ABLATE & 4)) philox4x32(srow, static_cast<uint32_t>(2 * (k0 >> 8) + h), 0u, 0u, key, signs);
         }
         __builtin_amdgcn_sched_barrier(0);
         // B fragments: all 8 of a 16-row step are in registers before its first MFMA, and each register is refilled with the
@@ -355,19 +364,19 @@ __global__ __launch_bounds__(kThreads, 2) void sketch_kernel(const void *__restr
         for (int t = 0; t < NT; ++t) bq[t] = *reinterpret_cast<const u32x4 *>(frag + 32 * 16 * t);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < kSteps; ++ks) {
             u32x4 a;
             if constexpr ((FEWBIT_SKETCH_ABLATE & 4) != 0) a = u32x4{srow, srow, srow, srow};
-            else if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) a = rademacher_fragment<DT>(signs, static_cast<int>((s & 3) * 4 + ks));
+            else if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) a = rademacher_fragment<DT>(signs, static_cast<int>((s & (kPerBlock - 1)) * kSteps + ks));
             else a = gaussian_fragment<DT>(srow, static_cast<uint32_t>((k0 >> 3) + 2 * ks + h), key);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = Operand<DT>::mfma(a, bq[t], acc[t]);
-                if (ks + 1 < BK / 16 && !(FEWBIT_SKETCH_ABLATE & 8))
+                if (ks + 1 < kSteps && !(FEWBIT_SKETCH_ABLATE & 8))
                     bq[t] = *reinterpret_cast<const u32x4 *>(frag + (static_cast<size_t>(2 * (ks + 1)) * BN + 32 * t) * 16);
                 if constexpr (FAST) {
-                    if (ks == 0) store_feature(blk, nxt, so, sfc, t);
-                    if (ks == 1) raw.row[t] = load_raw<DT>(next_base + off[t]);
+                    if (ks == first) store_feature(blk, nxt, so, sfc, t);
+                    if (ks == first + 1) raw.row[t] = load_raw<DT>(next_base + off[t]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -376,11 +385,19 @@ __global__ __launch_bounds__(kThreads, 2) void sketch_kernel(const void *__restr
     };
     // two loops, not one loop with a branch: the register allocator then sees the interior body (no branches, everything
     // pinned) on its own -- with both bodies in one loop it spilt half of the accumulators
+    // (W = 8: the upper four waves do their staging four steps later than the lower four, so that the two waves of a SIMD are
+    // not both in their VALU-heavy slots at once -- a wave-uniform choice between two copies of the loop, made once)
+    typedef std::integral_constant<int, 0> Step0;
+    typedef std::integral_constant<int, 4> Step4;
     size_t s = 0;
     if constexpr (!RAGGED && !(FEWBIT_SKETCH_ABLATE & 1)) {
-        for (; s + 2 < nfull; ++s) stage(s, std::true_type{});
+        if (W == 8 && wave >= 4) {
+            if constexpr (W == 8) for (; s + 2 < nfull; ++s) stage(s, std::true_type{}, Step4{});
+        } else {
+            for (; s + 2 < nfull; ++s) stage(s, std::true_type{}, Step0{});
+        }
     }
-    for (; s < nstages; ++s) stage(s, std::false_type{});
+    for (; s < nstages; ++s) stage(s, std::false_type{}, Step0{});
 
     // ---- epilogue: accumulator register r of block t is S row (r&3) + 8*(r>>2) + 4*h, feature 8c + t
 #pragma unroll
@@ -462,7 +479,7 @@ template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-struct Plan { unsigned gx, gy, gz; size_t kslice; };
+struct Plan { unsigned gx, gy, gz; size_t kslice; int waves; };
 
 int device_cus() {
     static std::atomic<int> cached[64];
@@ -476,31 +493,48 @@ int device_cus() {
     return v;
 }
 
+FEWBIT_HIDDEN std::atomic<long long> g_forced_slices{-1}, g_forced_waves{-1};
+
 // K slices: the tile grid of a sketch is small (proj x features) and K = rows is long, so the rows are cut into `gz` slices
 // when that fills the chip better.  cost(z) = (rounds of the CU array with z x tiles workgroups) / z, plus 4 % per extra
 // slice for the partial-sum traffic; slices are multiples of 256 rows (the Rademacher block) and at least 1024 rows.
-Plan make_plan(size_t rows, size_t features, size_t proj, long long forced_slices) {
-    Plan p;
-    p.gx = static_cast<unsigned>((features + BN - 1) / BN);
-    p.gy = static_cast<unsigned>((proj + BM - 1) / BM);
-    const size_t tiles = static_cast<size_t>(p.gx) * p.gy;
-    const size_t slots = static_cast<size_t>(device_cus());
+// `slots` = workgroups the chip holds at once: 2 per CU for the 4-wave tile, 1 per CU for the 8-wave tile.
+double plan_slices(size_t tiles, size_t slots, size_t rows, long long forced, size_t &best) {
     size_t max_z = rows / 1024;
     if (max_z < 1) max_z = 1;
     if (max_z > 16) max_z = 16;
-    size_t best = 1;
-    if (forced_slices > 0) {
-        best = static_cast<size_t>(forced_slices) < max_z ? static_cast<size_t>(forced_slices) : max_z;
-    } else {
-        double best_cost = 1e30;
-        for (size_t z = 1; z <= max_z; ++z) {
-            const size_t units = tiles * z;
-            const double rounds = static_cast<double>((units + slots - 1) / slots);
-            const double cost = rounds / static_cast<double>(z) * (1.0 + 0.04 * static_cast<double>(z - 1));
-            if (cost < best_cost - 1e-12) { best_cost = cost; best = z; }
-        }
+    best = 1;
+    double best_cost = 1e30;
+    for (size_t z = 1; z <= max_z; ++z) {
+        if (forced > 0 && z != static_cast<size_t>(forced) && !(static_cast<size_t>(forced) > max_z && z == max_z)) continue;
+        const size_t units = tiles * z;
+        const double rounds = static_cast<double>((units + slots - 1) / slots);
+        const double cost = rounds / static_cast<double>(z) * (1.0 + 0.04 * static_cast<double>(z - 1));
+        if (cost < best_cost - 1e-12) { best_cost = cost; best = z; }
     }
-    size_t kslice = (rows + best - 1) / best;
+    return best_cost;
+}
+
+Plan make_plan(size_t rows, size_t features, size_t proj) {
+    const long long forced_z = g_forced_slices.load(std::memory_order_relaxed), forced_w = g_forced_waves.load(std::memory_order_relaxed);
+    const size_t cus = static_cast<size_t>(device_cus());
+    Plan p;
+    p.gx = static_cast<unsigned>((features + BN - 1) / BN);
+    // tile height: 256 rows of S (8 waves) when that does not waste more of the last row tile than 128 rows (4 waves) would
+    // cost in staging -- time per row tile ~ (1 + staging share) with the share halved by the taller tile
+    size_t z4 = 1, z8 = 1;
+    const size_t t4 = static_cast<size_t>(p.gx) * ((proj + 127) / 128), t8 = static_cast<size_t>(p.gx) * ((proj + 255) / 256);
+    // (a round of 2 x CUs short tiles and a round of CUs tall tiles are the same MFMA work per CU; measured, the tall tile runs
+    // 3-10 % faster per MFMA: half the staging work and L2 reads)
+    const double c4 = plan_slices(t4, 2 * cus, rows, forced_z, z4);
+    const double c8 = plan_slices(t8, cus, rows, forced_z, z8) * 0.93;
+    bool tall = c8 <= c4;
+    if (forced_w == 4) tall = false;
+    if (forced_w == 8) tall = true;
+    p.waves = tall ? 8 : 4;
+    p.gy = static_cast<unsigned>((proj + (tall ? 255 : 127)) / (tall ? 256 : 128));
+    const size_t z = tall ? z8 : z4;
+    size_t kslice = (rows + z - 1) / z;
     kslice = (kslice + 255) / 256 * 256;
     p.kslice = kslice;
     p.gz = static_cast<unsigned>((rows + kslice - 1) / kslice);
@@ -508,23 +542,48 @@ Plan make_plan(size_t rows, size_t features, size_t proj, long long forced_slice
     return p;
 }
 
-FEWBIT_HIDDEN std::atomic<long long> g_forced_slices{-1};
+template <int DIST, int DT, bool PARTIAL, int W>
+int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Key key, float scale, void *out,
+                  hipStream_t s) {
+    const dim3 grid(p.gx, p.gy, p.gz), block(Tile<W>::kThreads);
+    constexpr size_t lds = 2 * Tile<W>::kStageBytes;
+    auto go = [&](auto kern) -> int {
+        if (lds > 65536) {                           // (more than the default limit of a workgroup: opt in once per kernel and device)
+            static std::atomic<unsigned long long> done{0};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const unsigned long long bit = 1ull << (dev & 63);
+            if (!(done.load(std::memory_order_relaxed) & bit)) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(FEWBIT_ERR_LAUNCH, "sketch: cannot reserve %zu bytes of LDS", lds);
+                }
+                done.fetch_or(bit, std::memory_order_relaxed);
+            }
+        }
+        hipLaunchKernelGGL(kern, grid, block, lds, s, m, rows, features, ld, proj, key, scale, out, p.kslice);
+        return FEWBIT_OK;
+    };
+    return ragged ? go(sketch_kernel<DIST, DT, PARTIAL, true, W>) : go(sketch_kernel<DIST, DT, PARTIAL, false, W>);
+}
 
 template <int DIST, int DT>
 int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, Key key, float scale, void *out, void *workspace,
            size_t workspace_bytes, hipStream_t s) {
-    const Plan p = make_plan(rows, features, proj, g_forced_slices.load(std::memory_order_relaxed));
-    const dim3 grid(p.gx, p.gy, p.gz);
+    const Plan p = make_plan(rows, features, proj);
     const bool ragged = (features % 8) != 0;
+    int rc;
     if (p.gz == 1) {
-        if (ragged) hipLaunchKernelGGL((sketch_kernel<DIST, DT, false, true>), grid, dim3(kThreads), 0, s, m, rows, features, ld, proj, key, scale, out, p.kslice);
-        else hipLaunchKernelGGL((sketch_kernel<DIST, DT, false, false>), grid, dim3(kThreads), 0, s, m, rows, features, ld, proj, key, scale, out, p.kslice);
+        rc = p.waves == 8 ? launch_kernel<DIST, DT, false, 8>(p, ragged, m, rows, features, ld, proj, key, scale, out, s)
+                          : launch_kernel<DIST, DT, false, 4>(p, ragged, m, rows, features, ld, proj, key, scale, out, s);
+        if (rc != FEWBIT_OK) return rc;
     } else {
         const size_t need = static_cast<size_t>(p.gz) * proj * features * sizeof(float);
         if (workspace == nullptr || workspace_bytes < need)
             return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", need, workspace_bytes);
-        if (ragged) hipLaunchKernelGGL((sketch_kernel<DIST, DT, true, true>), grid, dim3(kThreads), 0, s, m, rows, features, ld, proj, key, scale, workspace, p.kslice);
-        else hipLaunchKernelGGL((sketch_kernel<DIST, DT, true, false>), grid, dim3(kThreads), 0, s, m, rows, features, ld, proj, key, scale, workspace, p.kslice);
+        rc = p.waves == 8 ? launch_kernel<DIST, DT, true, 8>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s)
+                          : launch_kernel<DIST, DT, true, 4>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s);
+        if (rc != FEWBIT_OK) return rc;
         const size_t n = proj * features;
         hipLaunchKernelGGL((sketch_reduce_kernel<DT>), dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s,
                            static_cast<const float *>(workspace), n, static_cast<int>(p.gz), scale, out);
@@ -555,7 +614,7 @@ extern "C" {
 
 size_t fewbit_hip_sketch_workspace(size_t rows, size_t features, size_t proj) {
     if (rows == 0 || features == 0 || proj == 0) return 0;
-    const Plan p = make_plan(rows, features, proj, g_forced_slices.load(std::memory_order_relaxed));
+    const Plan p = make_plan(rows, features, proj);
     return p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : 0;
 }
 
@@ -596,10 +655,11 @@ int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, si
 
 int fewbit_hip_sketch_describe(size_t rows, size_t features, size_t proj, char *buf, size_t len) {
     if (buf == nullptr || len == 0) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch_describe: no buffer");
-    const Plan p = make_plan(rows, features, proj, g_forced_slices.load(std::memory_order_relaxed));
-    snprintf(buf, len, "{\"kernel\": \"sketch_kernel (128x256 tile, K stage 64, v_mfma_f32_32x32x16)\", \"grid\": [%u, %u, %u], \"threads\": %d, "
+    const Plan p = make_plan(rows, features, proj);
+    snprintf(buf, len, "{\"kernel\": \"sketch_kernel (%dx256 tile, K stage %d, v_mfma_f32_32x32x16)\", \"grid\": [%u, %u, %u], \"threads\": %d, "
                        "\"k_slice\": %zu, \"lds_bytes\": %d, \"workspace_bytes\": %zu}",
-             p.gx, p.gy, p.gz, kThreads, p.kslice, 2 * kStageBytes, p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : static_cast<size_t>(0));
+             32 * p.waves, 16 * p.waves, p.gx, p.gy, p.gz, 64 * p.waves, p.kslice, 2 * 16 * p.waves * BN * 2,
+             p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : static_cast<size_t>(0));
     return FEWBIT_OK;
 }
 
@@ -611,6 +671,12 @@ void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uin
 
 int fewbit_hip_sketch_tune_slices(long long slices) {
     g_forced_slices.store(slices, std::memory_order_relaxed);
+    return FEWBIT_OK;
+}
+
+int fewbit_hip_sketch_tune_waves(long long waves) {
+    if (waves != -1 && waves != 4 && waves != 8) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: waves per workgroup is 4 or 8 (or -1), got %lld", waves);
+    g_forced_waves.store(waves, std::memory_order_relaxed);
     return FEWBIT_OK;
 }
 

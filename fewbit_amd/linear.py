@@ -19,12 +19,22 @@ constructor / call signatures; the implementation is this repository's own:
   the imaginary part before the product (:189-197, :214-216); neither defect is reproduced (they are not covered by
   the reference's tests, which only run the default ``'gaussian'``, ``fewbit/modules/linear_test.py``);
 * without a user generator the sketch seed comes from the host default generator (so ``torch.manual_seed`` makes
-  runs reproducible) and never reads back from the device -- no stream synchronisation in forward or backward.
+  runs reproducible) and never reads back from the device -- no stream synchronisation in forward or backward;
+* on the GPU the dense sketches (``'gaussian'``, ``'rademacher'``) of fp32 / fp16 / bf16 tensors run on this package's own
+  gfx950 kernel (``fewbit_amd/csrc/fewbit_sketch.hip`` through the C-ABI ``fewbit_hip_sketch``): ``S`` is never
+  materialised -- it is a pure function of a 64-bit seed, generated in registers from a Philox4x32-10 counter and fed
+  straight to the matrix cores; what a layer keeps for backward is the ``p x features`` projection and ONE integer, and
+  backward regenerates the same ``S`` from that integer.  The reference draws ``proj x rows`` random numbers into device
+  memory twice per layer and step (fewbit/functional/linear.py:133-137,195-199).  fp32 operands are rounded to bf16 on their
+  way into the matrix pipe (accumulation is fp32): a zero-mean relative perturbation of 2^-9 per element under an estimator
+  whose own relative noise is ~ sqrt(rows / p).  ``use_native_sketch(False)`` (or ``FEWBIT_SKETCH_NATIVE=0``) selects
+  the PyTorch formulation (randn / randint + matmul) instead; host tensors, float64 and the sampled transforms always
+  take it.
 
-This is PyTorch-level code (GEMM- and FFT-bound); it is outside the quantized-activation hot path that the HIP
-kernels of this package implement.
+The sampled transforms ('dct', 'dft') are PyTorch-level code (FFT-bound).  SURVEY section 8f, row 4.
 """
 import contextlib
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -33,7 +43,7 @@ import torch.nn.functional as F
 from .fft import dct
 
 __all__ = ('MATMUL_TYPES', 'projection_dim', 'linear_crs', 'linear_grp', 'linear_randomized', 'LinearCRS', 'LinearGRP',
-           'RandomizedLinear')
+           'RandomizedLinear', 'use_native_sketch')
 
 MATMUL_TYPES = ('dct', 'dft', 'gaussian', 'rademacher')
 
@@ -74,6 +84,52 @@ def _replay_rng(token) -> torch.Generator:
     else:
         gen.set_state(payload)
     return gen
+
+
+# ---- the gfx950 kernel for the dense sketches ---------------------------------------------------------------------
+
+_NATIVE_SKETCH = os.environ.get('FEWBIT_SKETCH_NATIVE', '1') not in ('0', 'no', 'false')
+
+
+def use_native_sketch(on: Optional[bool] = None) -> bool:
+    """Query / set whether GPU tensors take the Philox-in-register MFMA kernel for 'gaussian' / 'rademacher' sketches
+    (default) or the PyTorch formulation.  Returns the previous setting."""
+    global _NATIVE_SKETCH
+    prev = _NATIVE_SKETCH
+    if on is not None:
+        _NATIVE_SKETCH = bool(on)
+    return prev
+
+
+def _native_sketch_applies(kind: str, mat: torch.Tensor, sketch_dtype) -> bool:
+    return (_NATIVE_SKETCH and _INJECTED is None and kind in ('gaussian', 'rademacher') and mat.device.type == 'cuda'
+            and mat.dtype in (torch.float32, torch.float16, torch.bfloat16) and mat.dim() == 2 and mat.shape[0] > 0
+            and sketch_dtype in (None, torch.bfloat16, mat.dtype))
+
+
+def _mix64(a: int, b: int) -> int:
+    """splitmix64 of (a, b): seed of one call from a device generator's (seed, offset) without touching the device"""
+    x = (a * 0x9E3779B97F4A7C15 + b + 0x632BE59BD9B4E019) & 0xffffffffffffffff
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xffffffffffffffff
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xffffffffffffffff
+    return x ^ (x >> 31)
+
+
+def _draw_seed(generator: Optional[torch.Generator]) -> int:
+    """64-bit seed of one sketch.  Host generators (the default one included) are advanced by one draw; a device generator
+    is advanced by bumping its Philox offset -- neither reads back from the device."""
+    if generator is None or generator.device.type == 'cpu':
+        return int(torch.randint(0, 2**62, (), dtype=torch.int64, generator=generator).item())
+    offset = generator.get_offset()
+    generator.set_offset(offset + 4)
+    return _mix64(generator.initial_seed(), offset)
+
+
+def _native_sketch(kind: str, mat: torch.Tensor, p: int, seed: int, scale: float) -> torch.Tensor:
+    from . import cabi
+    if mat.stride(1) != 1:
+        mat = mat.contiguous()
+    return cabi.sketch(kind, mat, p, seed, scale)
 
 
 _INJECTED: Optional[torch.Tensor] = None
@@ -131,8 +187,17 @@ class _LinearGRP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, weight, bias, p: int, kind: str, generator, sketch_dtype=None):
         flat = input.reshape(-1, input.shape[-1])
-        token, gen = _capture_rng(generator, input.device)
         rows = flat.shape[0]
+        ctx.native_seed = None
+        if _native_sketch_applies(kind, flat, sketch_dtype):
+            # S lives nowhere: the projection and the seed are all that is kept
+            ctx.native_seed = _draw_seed(generator)
+            sketch = _native_sketch(kind, flat.detach(), p, ctx.native_seed, 1.0 / p)
+            ctx.save_for_backward(sketch, weight)
+            ctx.p, ctx.kind = p, kind
+            ctx.has_bias = bias is not None
+            return F.linear(input, weight, bias)
+        token, gen = _capture_rng(generator, input.device)
         scale = 1.0 / p if kind in ('gaussian', 'rademacher') else rows / p
         draw_dtype = sketch_dtype or flat.dtype
         sketch = _sketch(kind, flat.detach(), p, gen, sketch_dtype, draw_dtype) * scale
@@ -148,7 +213,13 @@ class _LinearGRP(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             grad_input = grad_output @ weight
         flat = grad_output.reshape(-1, grad_output.shape[-1])
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.native_seed is not None:
+            # the same S again, from the same seed (a grad_output of another dtype than the forward's input -- autocast --
+            # still meets the same matrix: S does not depend on the operand dtype beyond its final rounding)
+            g2 = flat if flat.dtype in (torch.float32, torch.float16, torch.bfloat16) else flat.float()
+            proj = _native_sketch(ctx.kind, g2, ctx.p, ctx.native_seed, 1.0)
+            grad_weight = (proj.to(sketch.dtype).T @ sketch).to(weight.dtype)
+        elif ctx.needs_input_grad[1]:
             proj = _sketch(ctx.kind, flat, ctx.p, _replay_rng(ctx.token), ctx.sketch_dtype, ctx.draw_dtype)
             if proj.is_complex():                                               # Re((F G)^H (F X))
                 grad_weight = (proj.real.T @ sketch.real + proj.imag.T @ sketch.imag).to(weight.dtype)

@@ -184,8 +184,10 @@ int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, si
                              void *stream);
 /* launch shape a fewbit_hip_sketch call would use, as JSON: {"kernel", "grid": [x, y, z], "threads", "k_slice", ...} */
 int fewbit_hip_sketch_describe(size_t rows, size_t features, size_t proj, char *buf, size_t len);
-/* measurement hook: force the number of row slices (> 0), -1 = built-in policy */
+/* measurement hooks: force the number of row slices (> 0) / the waves per workgroup (4: 128-row tile, 8: 256-row tile);
+ * -1 = built-in policy.  Every setting computes the same sums (up to fp32 re-association across slices). */
 int fewbit_hip_sketch_tune_slices(long long slices);
+int fewbit_hip_sketch_tune_waves(long long waves);
 /* Philox4x32-10 on the HOST (the generator behind S; known-answer tests run it without a GPU) */
 void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -70,3 +70,69 @@ def test_estimator_statistics_on_the_gpu(lref):
             msd += float(((wi.grad - exact)**2).sum())
         assert float(torch.linalg.norm(acc / draws - exact) / torch.linalg.norm(exact)) <= 0.12, kind
         assert abs(msd / draws / float(lref[f'grp_{kind}_msd']) - 1.0) <= 0.12, (kind, msd / draws, float(lref[f'grp_{kind}_msd']))
+
+
+# ---- the dense sketches on the package's own kernel (fewbit_amd/csrc/fewbit_sketch.hip) ---------------------------------
+@pytest.mark.parametrize('kind', ('gaussian', 'rademacher'))
+@pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16))
+def test_layer_through_the_native_sketch_equals_the_host_model_of_the_same_stream(kind, dtype, monkeypatch):
+    """linear_grp on the GPU with the seed pinned: the weight gradient equals (S gy)^T (S x) / p for the matrix S the host
+    model (tests/sketch_reference.py) derives from the same Philox stream -- S itself never exists on the device"""
+    import sketch_reference as ref
+    import fewbit_amd.linear as L
+    seed = 0x5eed5eed5eed
+    monkeypatch.setattr(L, '_draw_seed', lambda generator: seed)
+    g = torch.Generator().manual_seed(1)
+    rows, fin, fout, p = 3 * 200, 72, 40, 96
+    x = torch.randn(3, 200, fin, generator=g).to(dtype)
+    w = (torch.randn(fout, fin, generator=g) * 0.2).to(dtype)
+    b = torch.randn(fout, generator=g).to(dtype)
+    gy = torch.randn(3, 200, fout, generator=g).to(dtype)
+    xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+    seen = []
+    with torch.autograd.graph.saved_tensors_hooks(lambda t: (seen.append(tuple(t.shape)), t)[1], lambda t: t):
+        y = fewbit.functional.linear_grp(xd, wd, bd, proj_dim=p, matmul=kind)
+    assert (p, fin) in seen and all(s[0] != rows for s in seen if len(s) == 2), seen       # the projection, not the input, not S
+    y.backward(gy.to(DEV))
+    op = torch.bfloat16
+    S = ref.matrix(kind, seed, p, rows, dtype).double()
+    xs, gs = x.reshape(rows, fin).to(op).double(), gy.reshape(rows, fout).to(op).double()
+    sx = (S @ xs / p).to(dtype).double()                     # what the layer kept (rounded to the layer's dtype)
+    want = (S @ gs).to(dtype).double().T @ sx
+    got = wd.grad.cpu().double()
+    tol = {torch.float32: 2e-3, torch.bfloat16: 3e-2}[dtype]  # Gaussian: one operand step on a few entries of S; bf16: output roundings
+    assert float((got - want).abs().max() / want.abs().max()) <= tol, float((got - want).abs().max() / want.abs().max())
+    assert torch.equal(y.detach().cpu(), torch.nn.functional.linear(x.to(DEV), w.to(DEV), b.to(DEV)).cpu())
+    assert torch.allclose(xd.grad.cpu().float(), (gy.to(DEV) @ w.to(DEV)).cpu().float(), rtol=1e-2 if dtype != torch.float32 else 1e-5, atol=1e-5)
+
+
+def test_native_sketch_replays_from_generators_and_can_be_switched_off():
+    import fewbit_amd.linear as L
+    x = torch.randn(512, 64, device=DEV, requires_grad=True)
+    lin = fewbit.RandomizedLinear(64, 32, proj_dim_ratio=0.25, matmul='rademacher', device=DEV)
+
+    def grad(gen):
+        lin.generator = gen
+        lin.zero_grad()
+        lin(x).sum().backward()
+        return lin.weight.grad.clone()
+
+    a = grad(torch.Generator().manual_seed(7))
+    assert torch.equal(a, grad(torch.Generator().manual_seed(7))) and not torch.equal(a, grad(torch.Generator().manual_seed(8)))
+    dg = torch.Generator(device=DEV).manual_seed(11)
+    state = dg.get_state()
+    b1, b2 = grad(dg), grad(dg)                                   # the device generator moves on between calls ...
+    assert not torch.equal(b1, b2)
+    dg.set_state(state)
+    assert torch.equal(b1, grad(dg))                              # ... and replays from its state
+    torch.manual_seed(3)
+    c1 = grad(None)
+    torch.manual_seed(3)
+    assert torch.equal(c1, grad(None))                            # default generator: torch.manual_seed reproduces
+    prev = L.use_native_sketch(False)
+    try:
+        torch.manual_seed(3)
+        d = grad(None)                                            # the PyTorch formulation: another S, same estimator
+        assert d.shape == c1.shape and not torch.equal(d, c1)
+    finally:
+        L.use_native_sketch(prev)

@@ -71,7 +71,7 @@ def patch_gelu_with_raw_op(model, dtype, device):
     return n
 
 
-def swap_linear(model, ratio, sketch_dtype=None):
+def swap_linear(model, ratio, sketch_dtype=None, matmul='gaussian'):
     """Every nn.Linear of the encoder -> fewbit.RandomizedLinear(proj_dim_ratio=ratio) sharing its parameters (the
     README's `convert_linear` recipe); the classification head stays exact."""
     from fewbit.util import convert_linear
@@ -80,7 +80,7 @@ def swap_linear(model, ratio, sketch_dtype=None):
     def fn(mod, path):
         if type(mod) is torch.nn.Linear and '/encoder/' in path:
             n[0] += 1
-            return convert_linear(mod, fewbit.RandomizedLinear, proj_dim_ratio=ratio, sketch_dtype=sketch_dtype)
+            return convert_linear(mod, fewbit.RandomizedLinear, proj_dim_ratio=ratio, sketch_dtype=sketch_dtype, matmul=matmul)
         return mod
 
     fewbit.map_module(model, fn)
@@ -128,6 +128,10 @@ def main():
                     help="the four rows of the reference README's table: GELU {vanilla, 3-bit} x linear {vanilla, randomized}")
     ap.add_argument('--linear-ratio', type=float, default=0.2, help='proj_dim_ratio of the randomized linear layers')
     ap.add_argument('--sketch-bf16', action='store_true', help='run the sketch GEMMs of fp32 layers in bf16')
+    ap.add_argument('--matmul', default='gaussian', choices=('gaussian', 'rademacher'), help='kind of dense sketch of the randomized layers')
+    ap.add_argument('--torch-sketch', action='store_true',
+                    help='draw S with torch.randn / randint and multiply with torch.matmul (what round 3 measured) instead of the '
+                         'Philox-in-register MFMA kernel (fewbit_amd/csrc/fewbit_sketch.hip)')
     args = ap.parse_args()
     dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[args.dtype]
     dev = torch.device('cuda:0')
@@ -135,12 +139,15 @@ def main():
     ids = torch.randint(5, 50000, (args.batch, args.seq), generator=g).to(dev)
     labels = torch.randint(0, 2, (args.batch,), generator=g).to(dev)
 
+    if args.torch_sketch:
+        import fewbit_amd.linear
+        fewbit_amd.linear.use_native_sketch(False)
     if args.table:
         rows = []
         for gelu, linear in ((False, False), (True, False), (False, True), (True, True)):
             model = build(dtype, dev)
             ng = swap_gelu(model, args.bits) if gelu else 0
-            nl = swap_linear(model, args.linear_ratio, torch.bfloat16 if args.sketch_bf16 else None) if linear else 0
+            nl = swap_linear(model, args.linear_ratio, torch.bfloat16 if args.sketch_bf16 else None, args.matmul) if linear else 0
             r = run(model, ids, labels, args.steps)
             rows.append({'gelu': f'{args.bits}-bit' if gelu else 'vanilla', 'linear': 'randomized' if linear else 'vanilla',
                          'gelu_modules_swapped': ng, 'linear_modules_swapped': nl, 'ms_per_step': round(r['ms_per_step'], 2),
@@ -152,6 +159,7 @@ def main():
             r['step_time_ratio'] = round(r['ms_per_step'] / rows[0]['ms_per_step'], 3)
         print(json.dumps({'config': f'RoBERTa-base (random init) batch {args.batch} x seq {args.seq}, {args.dtype}, '
                                     f'fwd+bwd+SGD step; randomized linear proj_dim_ratio={args.linear_ratio}'
+                                    + f', {args.matmul} sketch, ' + ('torch.randn/randint + torch.matmul' if args.torch_sketch else 'Philox-in-register MFMA kernel')
                                     + (', sketch GEMMs in bf16' if args.sketch_bf16 else ''),
                           'rows': rows}))
         return
