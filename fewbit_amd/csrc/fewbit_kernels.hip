@@ -81,7 +81,10 @@ struct Span {
 //               block granularity for free (device-scope atomics cost ~10 ns per claim on this part), which is what a
 //               large tensor needs: CUs/XCDs do not progress at the same rate and a static split waits for the slowest.
 // `slack`: full groups that must remain after the last tile (the wide-code backward over-reads a few bytes)
-template <int U, int WPB = kWavesPerBlock> __device__ __forceinline__ Span make_span(size_t n, int chunk, size_t slack = 0) {
+#ifndef FEWBIT_STATE_STAGE
+#define FEWBIT_STATE_STAGE 0     // experiment (round 4, profiles/r04_state_staging_ab.txt): pattern-table forward with the packed
+#endif                           // state of up to 4 CONSECUTIVE tiles of a wave staged in LDS and written as 16-byte pieces
+template <int U, int WPB = kWavesPerBlock, bool WAVE_CONTIGUOUS = false> __device__ __forceinline__ Span make_span(size_t n, int chunk, size_t slack = 0) {
     Span s;
     s.lane = threadIdx.x & (kWave - 1);
     const size_t wib = static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
@@ -94,9 +97,16 @@ template <int U, int WPB = kWavesPerBlock> __device__ __forceinline__ Span make_
     if (chunk > 0) {
         const size_t per_block = static_cast<size_t>(WPB) * static_cast<size_t>(chunk);
         const size_t b0 = static_cast<size_t>(blockIdx.x) * per_block;
-        s.t0 = b0 + wib;
-        s.t_end = b0 + per_block < s.ntiles ? b0 + per_block : s.ntiles;
-        s.stride = WPB;
+        if constexpr (WAVE_CONTIGUOUS) {          // wave j of the block takes the `chunk` consecutive tiles b0 + j*chunk ...
+            s.t0 = b0 + wib * static_cast<size_t>(chunk);
+            const size_t e = s.t0 + static_cast<size_t>(chunk);
+            s.t_end = e < s.ntiles ? e : s.ntiles;
+            s.stride = 1;
+        } else {
+            s.t0 = b0 + wib;
+            s.t_end = b0 + per_block < s.ntiles ? b0 + per_block : s.ntiles;
+            s.stride = WPB;
+        }
     } else {
         s.t0 = s.wave;
         s.t_end = s.ntiles;
@@ -353,7 +363,13 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
     constexpr uint32_t kInf = (DT == FEWBIT_BF16) ? 0x7f80u : 0x7c00u;
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ __attribute__((aligned(16))) uint8_t lut[65536];
-    const Span s = make_span<U, kLutWaves>(n, chunk);
+    constexpr bool kStage = (FEWBIT_STATE_STAGE != 0) && K == 3 && U == 1;
+#if FEWBIT_STATE_STAGE
+    __shared__ __attribute__((aligned(16))) uint8_t state_stage[kLutWaves * 768];
+#endif
+    // (staged variant: only in the chunked shape, where a wave's tiles are made consecutive)
+    const bool staged = kStage && chunk > 0;
+    const Span s = staged ? make_span<U, kLutWaves, true>(n, chunk) : make_span<U, kLutWaves, false>(n, chunk);
 
     // the table's global loads go out FIRST (lane j fetches border j, as a float and as a raw pattern): the build then
     // waits only for them, not for the first tile of x that pipeline2 issues right after
@@ -444,6 +460,28 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
                 }
                 const size_t g = (t * U + u) * kWave + s.lane;
                 GroupIO<DT>::template store<true>(y, g, v);
+#if FEWBIT_STATE_STAGE
+                if (staged) {
+                    // this tile's 192 state bytes -> slot (t - t0) % 4 of the wave's LDS strip (the same quad regroup as
+                    // store_state_quad: lane i of a quad holds dword min(i, 2) of the quad's 12 bytes); every 4th tile, and at
+                    // the end of the wave's chunk, the strip leaves as 16-byte pieces: lane L < 12 f writes bytes [16 L, 16 L + 16)
+                    // of the f staged tiles (lanes beyond repeat the last piece: same address, same data, no divergence)
+                    uint8_t *strip = state_stage + (threadIdx.x >> 6) * 768;
+                    const int i = s.lane & 3, j = i < 2 ? i : 2;
+                    const uint32_t lo = quad_perm<FEWBIT_QUAD_PERM(0, 1, 2, 2)>(w), hi = quad_perm<FEWBIT_QUAD_PERM(1, 2, 3, 3)>(w);
+                    const uint32_t d = (lo >> (8 * j)) | (hi << (24 - 8 * j));
+                    const size_t k_in = (t - s.t0) & 3;
+                    *reinterpret_cast<uint32_t *>(strip + k_in * 192 + 12 * (s.lane >> 2) + 4 * j) = d;
+                    const bool last = t + 1 >= s.t_end;
+                    if (k_in == 3 || last) {                                    // wave-uniform
+                        const int pieces = 12 * static_cast<int>(k_in + 1);
+                        const int piece = s.lane < pieces ? s.lane : pieces - 1;
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(strip + 16 * piece);
+                        const size_t first_tile = t - k_in;
+                        store_as<false, 1>(state + first_tile * (static_cast<size_t>(K) * kWave) + 16 * piece, v);
+                    }
+                } else
+#endif
                 if constexpr ((FEWBIT_ABLATE_LUT & 8) == 0) store_state_quad<K, (FEWBIT_ABLATE_LUT & 16) != 0>(state, g, s.lane, w);
                 else if (w == 0x12345u) store_state_quad<K, false>(state, g, s.lane, w);
             }
