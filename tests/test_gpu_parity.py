@@ -48,7 +48,7 @@ def make_x(n, dtype, borders, seed):
 
 
 def test_library_is_the_hip_build():
-    assert cabi.lib().fewbit_hip_abi_version() == 1
+    assert cabi.lib().fewbit_hip_abi_version() == cabi.ABI_VERSION
     assert cabi.LIB_PATH.name.startswith('libfewbit_hip')
 
 
