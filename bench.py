@@ -648,10 +648,12 @@ def build_line(args, world, res, per_rank=None, launcher='single process'):
             line['per_gpu_span'] = [r['span'] for r in per_rank]
     elif 'sha256' in res:
         line['per_gpu_sha256'], line['per_gpu_span'] = [res['sha256']], [res['span']]
-    line['evidence'] = {'rocprofv3_kernel_stats': 'profiles/r03_bench_kernel_stats.csv (this command with --no-extras)',
-                        'pmc_traffic': 'profiles/r03_pmc_traffic.json', 'per_config_rocprofv3_and_pmc': 'profiles/r03_configs.json',
-                        'shape_sweeps': 'profiles/r03_shape_sweep_*.txt', 'copy_floor_at_this_size': 'profiles/r03_stream_bench_32MiB.txt',
-                        'regenerate': 'bash tools/profile_round.sh r03'}
+    line['evidence'] = {'rocprofv3_kernel_stats': 'profiles/r04_bench_kernel_stats.csv (this command with --no-extras)',
+                        'pmc_traffic': 'profiles/r04_pmc_traffic.json', 'per_config_rocprofv3_and_pmc': 'profiles/r04_configs.json',
+                        'shape_sweeps': 'profiles/r03_shape_sweep_*.txt, profiles/r04_state_staging_ab.txt',
+                        'copy_floor_at_this_size': 'profiles/r04_stream_bench_32MiB.txt',
+                        'multi_rank_launch_paths': 'profiles/r04_bench_line_{4,8}ranks_*_shared.json, profiles/r04_strong_*',
+                        'regenerate': 'bash tools/profile_round.sh r04'}
     return line
 
 

@@ -127,7 +127,7 @@ def _draw_seed(generator: Optional[torch.Generator]) -> int:
 
 def _native_sketch(kind: str, mat: torch.Tensor, p: int, seed: int, scale: float) -> torch.Tensor:
     from . import cabi
-    if mat.stride(1) != 1:
+    if mat.stride(1) != 1 or mat.stride(0) < mat.shape[1]:      # (e.g. the expanded gradient of a sum: strides (0, 0))
         mat = mat.contiguous()
     return cabi.sketch(kind, mat, p, seed, scale)
 

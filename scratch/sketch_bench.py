@@ -15,17 +15,21 @@ DEV = 'cuda'
 PEAK = 2500.0
 
 
-def timed(f, reps=20, warm=3):
+def timed(f, reps=20, warm=5, rounds=3):
+    """median over `rounds` of the average of `reps` back-to-back calls (HIP events on the launch stream), in us"""
     for _ in range(warm):
         f()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        f()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps       # us
+    out = []
+    for _ in range(rounds):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e3 / reps)
+    return sorted(out)[len(out) // 2]
 
 
 def main():

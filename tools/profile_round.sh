@@ -12,7 +12,7 @@
 #      micro-benchmark, host cost per call, clock-transient timeline, the fp32 ULP histogram written by the GPU test-suite
 #   6. RoBERTa-base step (both routes) and the rocprofv3 kernel stats of the few-bit kernels inside it
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
 export TMPDIR=/tmp
@@ -33,6 +33,20 @@ python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$OUT/${R
 # N > 1 on the one GPU of this box (ranks SHARE it: validation of the launch paths, not a scaling point): bench.py starting
 # its own children, and the driver's torch.distributed.run form (gloo process group for the barrier and the max only)
 python3 bench.py --gpus 2 --steps 20 --warmup 5 > "$OUT/${R}_bench_line_2ranks_selflaunch_one_gpu.json" 2>> "$RAW/bench.err"
+# the launch path an 8-GPU lease takes (8 / 4 self-launched ranks, here sharing the one GPU), weak (the driver's contract) ...
+for spec in "8 c2" "4 c2" "8 c4"; do set -- $spec
+    python3 bench.py --gpus $1 --config $2 --steps 20 --warmup 5 > "$OUT/${R}_bench_line_${1}ranks_${2}_shared.json" 2>> "$RAW/bench.err"
+done
+# ... and strong: ONE 4096x4096 (and one 16384x4096) tensor cut over N ranks; ranks sharing the GPU, and rank 0's slice of an
+# M-way cut ALONE on the GPU (--emulate-world: what each of M separate GPUs runs; the line carries the projected M-GPU figure)
+for n in 1 2 4 8; do
+    python3 bench.py --gpus $n --scaling strong --steps 200 --warmup 20 --no-extras --no-cpu-baseline > "$OUT/${R}_strong_c2_${n}ranks_one_gpu.json" 2>> "$RAW/bench.err"
+    python3 bench.py --gpus $n --config c4_tensor --scaling strong --steps 100 --warmup 20 --no-extras --no-cpu-baseline > "$OUT/${R}_strong_c4tensor_${n}ranks_one_gpu.json" 2>> "$RAW/bench.err"
+done
+for m in 2 4 8; do
+    python3 bench.py --gpus 1 --scaling strong --emulate-world $m --steps 400 --warmup 50 --no-extras --no-cpu-baseline > "$OUT/${R}_strong_c2_emulated_world_$m.json" 2>> "$RAW/bench.err"
+    python3 bench.py --gpus 1 --config c4_tensor --scaling strong --emulate-world $m --steps 200 --warmup 50 --no-extras --no-cpu-baseline > "$OUT/${R}_strong_c4tensor_emulated_world_$m.json" 2>> "$RAW/bench.err"
+done
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 \
     bench.py --gpus 2 --steps 200 --warmup 10 2>> "$RAW/bench.err" | tail -1 > "$OUT/${R}_bench_line_2ranks_torchrun_one_gpu.json"
 # 6. BASELINE config 5: RoBERTa-base step, module route and the reference's raw-operator route, and the few-bit kernels' own
@@ -52,6 +66,15 @@ if [ -x scratch/stream_bench ]; then
     scratch/stream_bench 4 > "$OUT/${R}_stream_bench_4MiB.txt" 2>&1
 fi
 python3 scratch/hostcost.py > "$RAW/hostcost.log" 2>&1 && cp gpurun_out/hostcost.json "$OUT/${R}_hostcost.json"
+# 7. the random-projection kernel: TFLOP/s per shape against torch.randn/randint + torch.matmul, the README
+#    table of RoBERTa-base with the native and the torch sketches, rocprofv3 kernel stats + PMC of one shape
+python3 scratch/sketch_bench.py > "$RAW/sketch_bench.log" 2>&1 && cp gpurun_out/sketch_bench.json "$OUT/${R}_sketch_bench.json"
+for v in "fp32 gaussian" "fp32 gaussian --torch-sketch" "fp32 gaussian --torch-sketch --sketch-bf16" "fp32 rademacher" "bf16 gaussian" "bf16 gaussian --torch-sketch" "bf16 rademacher"; do
+    set -- $v; dt=$1; mm=$2; shift 2; tag=$(echo "$dt $mm $@" | tr " " "_" | tr -d "-" | sed 's/_$//')
+    timeout 600 python3 tools/roberta_bench.py --table --dtype $dt --matmul $mm --steps 6 "$@" 2>> "$RAW/roberta.err" | tail -1 > "$OUT/${R}_roberta_table_$tag.json"
+done
+bash tools/profile_sketch.sh ${R}_rademacher_bf16 rademacher 16384 3072 1638 bf16 10 > "$OUT/${R}_sketch_rocprof_rademacher_16384x3072_p1638_bf16.txt" 2>&1
+bash tools/profile_sketch.sh ${R}_gaussian_bf16 gaussian 16384 3072 1638 bf16 10 > "$OUT/${R}_sketch_rocprof_gaussian_16384x3072_p1638_bf16.txt" 2>&1
 python3 scratch/timeline.py 0.0 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_clock_transient_timeline.txt"
 [ -f gpurun_out/fp32_ulp.json ] && cp gpurun_out/fp32_ulp.json "$OUT/${R}_fp32_ulp.json"   # written by pytest -m gpu
 ls -la "$OUT"
