@@ -84,6 +84,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
+#ifdef FEWBIT_SKETCH_TRACE
+// measurement builds only: shader-clock stamps (s_memtime) of workgroup (0,0,0), per wave and stage: [stage top, MFMAs issued, barrier passed]
+__device__ unsigned long long g_sketch_trace[8 * 512 * 3];
+#define SKETCH_STAMP(stage_idx, slot)                                                                                         \
+    do {                                                                                                                      \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (stage_idx) < 512)                          \
+            g_sketch_trace[(static_cast<size_t>(wave) * 512 + (stage_idx)) * 3 + (slot)] = __builtin_readcyclecounter();     \
+    } while (0)
+#else
+#define SKETCH_STAMP(stage_idx, slot) do { } while (0)
+#endif
+
 // ---- Philox4x32-10 -----------------------------------------------------------------------------------------------------
 struct Key { uint32_t k0, k1; };
 
@@ -338,6 +350,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
         constexpr bool FAST = decltype(fast_tag)::value;
         constexpr int first = decltype(first_tag)::value;      // the step whose slots carry the LDS writes (the loads follow one step later)
         const size_t k0 = k_begin + s * BK;
+        SKETCH_STAMP(s, 0);
         uint8_t *cur = lds + (s & 1) * kStageBytes, *nxt = lds + ((s + 1) & 1) * kStageBytes;
         const uint8_t *next_base = stage_base + (s + 2) * stage_bytes;
         if constexpr (FAST) {
@@ -381,7 +394,9 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        SKETCH_STAMP(s, 1);
         if constexpr ((FEWBIT_SKETCH_ABLATE & 2) == 0) __syncthreads();
+        SKETCH_STAMP(s, 2);
     };
     // two loops, not one loop with a branch: the register allocator then sees the interior body (no branches, everything
     // pinned) on its own -- with both bodies in one loop it spilt half of the accumulators
@@ -389,6 +404,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     // not both in their VALU-heavy slots at once -- a wave-uniform choice between two copies of the loop, made once)
     typedef std::integral_constant<int, 0> Step0;
     typedef std::integral_constant<int, 4> Step4;
+    // (a static s_setprio 1 / 2 for the upper half measured 1 % slower, 161.2 / 161.4 against 159.7 us at 16384x3072, proj 1638)
     size_t s = 0;
     if constexpr (!RAGGED && !(FEWBIT_SKETCH_ABLATE & 1)) {
         if (W == 8 && wave >= 4) {
@@ -668,6 +684,12 @@ void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uin
     philox4x32(counter[0], counter[1], counter[2], counter[3], Key{key[0], key[1]}, o);
     for (int i = 0; i < 4; ++i) out[i] = o[i];
 }
+
+#ifdef FEWBIT_SKETCH_TRACE
+int fewbit_hip_sketch_debug_trace(unsigned long long *host, size_t count) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sketch_trace), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int fewbit_hip_sketch_tune_slices(long long slices) {
     g_forced_slices.store(slices, std::memory_order_relaxed);
