@@ -48,6 +48,7 @@ Besides the contract fields the line carries (N = 1, unless --no-extras):
   cold       the same workload rotating through > 1 GiB of independent buffer sets (Infinity Cache out of the picture)
   configs    every other BASELINE config on one GPU, warm and cold, with kernel names and its own cpu_baseline
   op_level   clone + torch.ops.fewbit.gelu + autograd.grad at this size beside torch.nn.functional.gelu
+  sketch     the random-projection kernel of the randomized linear layers at RoBERTa's widest layer: MFMA roofline
   cpu_baseline, cpu_baseline_1thread   the reference's own CPU path (oracle/_ref) on the host cores, bounded samples
 """
 import argparse
@@ -321,6 +322,39 @@ def measure_op_level(cfg, device, reps=200):
                    f"{cfg['rows']}x{cfg['cols']} {cfg['dtype']}; `vanilla` = the same with torch.nn.functional.{cfg['fn']}; us_gpu: between two "
                    "events on the stream, eager; us_wall: host time per eager iteration (us_wall ~ us_gpu => host-bound); us_graph_replay: "
                    "one hipGraph replay of the same launches (three kernels + their boundaries, ~1.8 us each, which a graph does not remove)")
+    return out
+
+
+def measure_sketch(device):
+    """the random-projection product of the randomized linear layers (fewbit_hip_sketch, S generated in registers
+    -> MFMA) at RoBERTa-base's widest layer (16384 tokens x 3072 features, proj_dim_ratio 0.1), bf16, against what it replaces
+    (S drawn into HBM + torch.matmul).  Roofline class MFMA: 2*p*rows*features flops against the 2.5 PFLOP/s dense bf16 peak."""
+    from fewbit_amd import cabi
+    rows, features, proj = 16384, 3072, 1638
+    m = torch.randn(rows, features, device=device).to(torch.bfloat16)
+    flops = 2.0 * proj * rows * features
+    out = {'workload': f'out = S . M, S {proj} x {rows} (never materialised), M {rows} x {features} bf16', 'flops': flops,
+           'S_bytes_not_materialised': proj * rows * 2, 'plan': cabi.describe_sketch(rows, features, proj)}
+    ws = torch.empty(max(out['plan']['workspace_bytes'], 1), dtype=torch.uint8, device=device)
+    o = torch.empty(proj, features, dtype=torch.bfloat16, device=device)
+
+    def timed(f, reps=20):
+        for _ in range(5):
+            f()
+        best = []
+        for _ in range(3):
+            best.append(event_time_us([f], reps, preroll=1))
+        return sorted(best)[1]
+
+    for dist in ('rademacher', 'gaussian'):
+        us = timed(lambda: cabi.sketch(dist, m, proj, 1234, 1.0 / proj, out=o, workspace=ws))
+        out[dist] = {'us': round(us, 1), 'roofline': {'bound': 'mfma', 'achieved': round(flops / us / 1e6, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                                       'frac': round(flops / us / 1e6 / 2500.0, 4)}}
+    S = torch.randn(proj, rows, device=device, dtype=torch.bfloat16)
+    out['torch'] = {'randn_plus_matmul_us': round(timed(lambda: torch.randn(proj, rows, device=device, dtype=torch.bfloat16) @ m), 1),
+                    'randint_plus_matmul_us': round(timed(lambda: (torch.randint(0, 2, (proj, rows), device=device, dtype=torch.int8).to(torch.bfloat16) * 2 - 1) @ m), 1),
+                    'matmul_alone_us': round(timed(lambda: S @ m), 1)}
+    out['evidence'] = 'profiles/r04_sketch_bench.json, profiles/r04_sketch_rocprof_*.txt, DESIGN.md 3.1 / 5.1'
     return out
 
 
@@ -706,6 +740,7 @@ def add_extras(line, args, device):
         line['op_level'] = _guarded('op_level', lambda: measure_op_level(cfg, device))
         line['configs'] = {name: _guarded(f'configs.{name}', lambda name=name, c=c: _other_config(name, c, args, device))
                            for name, c in CONFIGS.items() if name not in (args.config, 'c4_tensor')}
+        line['sketch'] = _guarded('sketch', lambda: measure_sketch(device))
     if not args.no_cpu_baseline:
         reps_all, reps_one = CPU_SAMPLES[args.config]
         line['cpu_baseline'] = _guarded('cpu_baseline', lambda: cpu_baseline(args.config, cfg, reps_all))
