@@ -334,8 +334,8 @@ def measure_sketch(device):
     m = torch.randn(rows, features, device=device).to(torch.bfloat16)
     flops = 2.0 * proj * rows * features
     out = {'workload': f'out = S . M, S {proj} x {rows} (never materialised), M {rows} x {features} bf16', 'flops': flops,
-           'S_bytes_not_materialised': proj * rows * 2, 'plan': cabi.describe_sketch(rows, features, proj)}
-    ws = torch.empty(max(out['plan']['workspace_bytes'], 1), dtype=torch.uint8, device=device)
+           'S_bytes_not_materialised': proj * rows * 2}
+    ws = torch.empty(max(max(cabi.sketch_workspace_bytes(d, rows, features, proj) for d in cabi.SKETCH_DISTS), 1), dtype=torch.uint8, device=device)
     o = torch.empty(proj, features, dtype=torch.bfloat16, device=device)
 
     def timed(f, reps=20):
@@ -348,7 +348,7 @@ def measure_sketch(device):
 
     for dist in ('rademacher', 'gaussian'):
         us = timed(lambda: cabi.sketch(dist, m, proj, 1234, 1.0 / proj, out=o, workspace=ws))
-        out[dist] = {'us': round(us, 1), 'roofline': {'bound': 'mfma', 'achieved': round(flops / us / 1e6, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
+        out[dist] = {'us': round(us, 1), 'plan': cabi.describe_sketch(dist, rows, features, proj), 'roofline': {'bound': 'mfma', 'achieved': round(flops / us / 1e6, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
                                                        'frac': round(flops / us / 1e6 / 2500.0, 4)}}
     S = torch.randn(proj, rows, device=device, dtype=torch.bfloat16)
     out['torch'] = {'randn_plus_matmul_us': round(timed(lambda: torch.randn(proj, rows, device=device, dtype=torch.bfloat16) @ m), 1),

@@ -15,7 +15,7 @@ __all__ = [
     'quantize_backward', 'bind_forward', 'bind_backward', 'bind_stepwise1_forward', 'bind_stepwise1_backward',
     'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError', 'describe_forward',
     'describe_backward', 'describe_stepwise1_forward', 'describe_stepwise1_backward', 'tune',
-    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves',
+    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves', 'tune_sketch_halves',
     'philox4x32',
 ]
 
@@ -39,7 +39,7 @@ SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwid
            'fewbit_hip_describe_quantize_forward', 'fewbit_hip_describe_quantize_backward',
            'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune',
            'fewbit_hip_sketch_workspace', 'fewbit_hip_sketch', 'fewbit_hip_sketch_matrix', 'fewbit_hip_sketch_describe',
-           'fewbit_hip_sketch_tune_slices', 'fewbit_hip_sketch_tune_waves', 'fewbit_hip_philox4x32')
+           'fewbit_hip_sketch_tune_slices', 'fewbit_hip_sketch_tune_waves', 'fewbit_hip_sketch_tune_halves', 'fewbit_hip_philox4x32')
 
 
 class FewbitHipError(RuntimeError):
@@ -94,17 +94,19 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_tune.argtypes = [cp, ctypes.c_longlong]
         u64 = ctypes.c_uint64
         L.fewbit_hip_sketch_workspace.restype = sz
-        L.fewbit_hip_sketch_workspace.argtypes = [sz, sz, sz]
+        L.fewbit_hip_sketch_workspace.argtypes = [i32, sz, sz, sz]
         L.fewbit_hip_sketch.restype = i32
         L.fewbit_hip_sketch.argtypes = [i32, i32, vp, sz, sz, sz, sz, u64, dbl, vp, vp, sz, vp]
         L.fewbit_hip_sketch_matrix.restype = i32
         L.fewbit_hip_sketch_matrix.argtypes = [i32, i32, u64, sz, sz, sz, sz, vp, vp]
         L.fewbit_hip_sketch_describe.restype = i32
-        L.fewbit_hip_sketch_describe.argtypes = [sz, sz, sz, cp, sz]
+        L.fewbit_hip_sketch_describe.argtypes = [i32, sz, sz, sz, cp, sz]
         L.fewbit_hip_sketch_tune_slices.restype = i32
         L.fewbit_hip_sketch_tune_slices.argtypes = [ctypes.c_longlong]
         L.fewbit_hip_sketch_tune_waves.restype = i32
         L.fewbit_hip_sketch_tune_waves.argtypes = [ctypes.c_longlong]
+        L.fewbit_hip_sketch_tune_halves.restype = i32
+        L.fewbit_hip_sketch_tune_halves.argtypes = [ctypes.c_longlong]
         L.fewbit_hip_philox4x32.restype = None
         L.fewbit_hip_philox4x32.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
         _lib = L
@@ -358,8 +360,8 @@ def tune(**settings: int) -> None:
 
 
 # ---- random-projection products (fewbit_amd/csrc/fewbit_sketch.hip): out = scale * S . m, S a function of the seed ------
-def sketch_workspace_bytes(rows: int, features: int, proj: int) -> int:
-    return lib().fewbit_hip_sketch_workspace(rows, features, proj)
+def sketch_workspace_bytes(dist: str, rows: int, features: int, proj: int) -> int:
+    return lib().fewbit_hip_sketch_workspace(SKETCH_DISTS.index(dist), rows, features, proj)
 
 
 def sketch(dist: str, m: torch.Tensor, proj: int, seed: int, scale: float = 1.0, out: Optional[torch.Tensor] = None,
@@ -379,7 +381,7 @@ def sketch(dist: str, m: torch.Tensor, proj: int, seed: int, scale: float = 1.0,
             out = torch.empty((proj, features), dtype=m.dtype, device=m.device)
         elif out.shape != (proj, features) or out.dtype != m.dtype or not out.is_contiguous():
             raise FewbitHipError('out must be a contiguous proj x features tensor of the dtype of m')
-        need = sketch_workspace_bytes(rows, features, proj)
+        need = sketch_workspace_bytes(dist, rows, features, proj)
         if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
             workspace = torch.empty(need, dtype=torch.uint8, device=m.device)
         _same_device(m, out, *(() if workspace is None else (workspace, )))
@@ -402,8 +404,8 @@ def sketch_matrix(dist: str, dtype: torch.dtype, seed: int, nrows: int, ncols: i
     return out
 
 
-def describe_sketch(rows: int, features: int, proj: int, device=None) -> dict:
-    return _describe(lib().fewbit_hip_sketch_describe, rows, features, proj, device=device)
+def describe_sketch(dist: str, rows: int, features: int, proj: int, device=None) -> dict:
+    return _describe(lib().fewbit_hip_sketch_describe, SKETCH_DISTS.index(dist), rows, features, proj, device=device)
 
 
 def tune_sketch_slices(slices: int) -> None:
@@ -414,6 +416,11 @@ def tune_sketch_slices(slices: int) -> None:
 def tune_sketch_waves(waves: int) -> None:
     """measurement hook: waves per workgroup, 4 (128-row tile) or 8 (256-row tile); -1 = built-in policy"""
     _check(lib().fewbit_hip_sketch_tune_waves(int(waves)))
+
+
+def tune_sketch_halves(halves: int) -> None:
+    """measurement hook: column halves per workgroup, 1 or 2 (the 128 x 512 tile); -1 = built-in policy"""
+    _check(lib().fewbit_hip_sketch_tune_halves(int(halves)))
 
 
 def philox4x32(counter, key):

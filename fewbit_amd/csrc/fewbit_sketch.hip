@@ -69,9 +69,18 @@ constexpr int NT = BN / 32;                 // MFMA column blocks per wave
 //   W = 4:  128 x 256 tile, stages of  64 rows, 2 x 32 KiB of LDS, two workgroups per CU
 //   W = 8:  256 x 256 tile, stages of 128 rows, 2 x 64 KiB of LDS, one workgroup per CU (half the staging work, LDS writes and
 //           L2 reads per MFMA; the upper four waves do their staging four steps later than the lower four)
-template <int W> struct Tile {
-    static constexpr int kThreads = 64 * W, BM = 32 * W, BK = 16 * W, kSteps = BK / 16, kStageBytes = BK * BN * 2;
+//   W = 8, NH = 2 (the Gaussian sketch): 128 x 512 tile -- the eight waves are 4 row groups x 2 column halves, waves (g, 0) and
+//           (g, 1) need the SAME rows of S, so each generates half of the stage's A fragments and hands them to the other
+//           through LDS (16 KiB per stage): every element of S is generated once per 512 columns instead of once per 256, which
+//           halves the generator work per MFMA -- the Gaussian sketch is VALU-bound (section "S as a function").
+//           Stages of 64 rows, 2 x 64 KiB (M) + 2 x 16 KiB (A fragments) = all 160 KiB of the CU.
+template <int W, int NH = 1> struct Tile {
+    static constexpr int kThreads = 64 * W, RG = W / NH, BM = 32 * RG, BNT = BN * NH, BK = 16 * W / NH, kSteps = BK / 16;
+    static constexpr int kStageBytes = BK * BNT * 2;
+    static constexpr int kABytes = NH > 1 ? RG * kSteps * 1024 : 0;     // one stage's A fragments: 1 KiB per (row group, step)
+    static constexpr int kLdsBytes = 2 * kStageBytes + 2 * kABytes;
     static constexpr int kStagesPerBlock = 256 / BK;           // stages per 256-row Rademacher block
+    static constexpr int kChunksPerRow = BNT / 8;              // 16-byte chunks per octet of rows in the LDS image
 };
 constexpr int kPhiloxRounds = 10;
 #ifndef FEWBIT_SKETCH_ABLATE
@@ -265,38 +274,43 @@ template <int DT, bool MASK> __device__ __forceinline__ void finish_block(const 
 }
 
 // transpose the 8x8 block and store it: feature w of the block -> chunk 32*w + fc of octet `octet` of the stage buffer
-__device__ __forceinline__ void store_feature(const Block8x8 &b, uint8_t *stage, int octet, int fc, int w) {
+// (`pitch` = features of the tile: 256, or 512 with two column halves -- feature chunk fc = 32*half + c' then goes to chunk
+// 256*half + 32*w + c' of its octet)
+template <int PITCH> __device__ __forceinline__ void store_feature(const Block8x8 &b, uint8_t *stage, int octet, int fc, int w) {
     const int e = w >> 1;
     const uint32_t sel = (w & 1) ? 0x07060302u : 0x05040100u;
     u32x4 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = __builtin_amdgcn_perm(b.row[2 * q + 1][e], b.row[2 * q][e], sel);
-    *reinterpret_cast<u32x4 *>(stage + (static_cast<size_t>(octet) * BN + 32 * w + fc) * 16) = o;
+    const int chunk = PITCH == BN ? 32 * w + fc : 256 * (fc >> 5) + 32 * w + (fc & 31);
+    *reinterpret_cast<u32x4 *>(stage + (static_cast<size_t>(octet) * PITCH + chunk) * 16) = o;
 }
 
-__device__ __forceinline__ void store_block(const Block8x8 &b, uint8_t *stage, int octet, int fc) {
+template <int PITCH> __device__ __forceinline__ void store_block(const Block8x8 &b, uint8_t *stage, int octet, int fc) {
 #pragma unroll
-    for (int w = 0; w < 8; ++w) store_feature(b, stage, octet, fc, w);
+    for (int w = 0; w < 8; ++w) store_feature<PITCH>(b, stage, octet, fc, w);
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
 // grid: x = column tiles (256 features), y = row tiles of S (128), z = K slices.  PARTIAL: write fp32 partial sums to
 // `out` + z * proj * features (no scale); otherwise the scaled result in the dtype of M.
-template <int DIST, int DT, bool PARTIAL, bool RAGGED, int W>
+template <int DIST, int DT, bool PARTIAL, bool RAGGED, int W, int NH>
 __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restrict__ m, size_t rows, size_t features, size_t ld, size_t proj,
                                                            Key key, float scale, void *__restrict__ out, size_t kslice) {
-    constexpr int BM = Tile<W>::BM, BK = Tile<W>::BK, kStageBytes = Tile<W>::kStageBytes, kSteps = Tile<W>::kSteps;
-    constexpr int kPerBlock = Tile<W>::kStagesPerBlock;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];        // 2 * kStageBytes
+    typedef Tile<W, NH> T_;
+    constexpr int BM = T_::BM, BK = T_::BK, BNT = T_::BNT, RG = T_::RG, kStageBytes = T_::kStageBytes, kSteps = T_::kSteps;
+    constexpr int kPerBlock = T_::kStagesPerBlock, kABytes = T_::kABytes;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];        // 2 * kStageBytes of M, then 2 * kABytes of A fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const size_t n0 = static_cast<size_t>(blockIdx.x) * BN, m0 = static_cast<size_t>(blockIdx.y) * BM;
+    const int rg = NH > 1 ? wave % RG : wave, hf = NH > 1 ? wave / RG : 0;    // row group of S, column half of the tile
+    const size_t n0 = static_cast<size_t>(blockIdx.x) * BNT, m0 = static_cast<size_t>(blockIdx.y) * BM;
     const size_t k_begin = static_cast<size_t>(blockIdx.z) * kslice;
     const size_t k_end = k_begin + kslice < rows ? k_begin + kslice : rows;
-    const uint32_t srow = static_cast<uint32_t>(m0 + 32 * wave + c);          // this lane's row of S
+    const uint32_t srow = static_cast<uint32_t>(m0 + 32 * rg + c);            // this lane's row of S
 
     // staging role of this thread: octet `so` (8 rows) of the stage, features [8*sfc, 8*sfc + 8) of the tile
-    const int so = tid >> 5, sfc = tid & 31;
+    const int so = tid / T_::kChunksPerRow, sfc = tid % T_::kChunksPerRow;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
         if (mode == 2) return;
         if (!RAGGED && mode == 1) finish_block<DT, true>(raw, blk, static_cast<int>(klen - st * BK) - 8 * so);
         else finish_block<DT, false>(raw, blk, 8);
-        store_block(blk, buf, so, sfc);
+        store_block<BNT>(blk, buf, so, sfc);
     };
     auto mode_of = [&](size_t st) { return st < nfull ? 0 : st < nstages ? 1 : 2; };
 
@@ -344,6 +358,41 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     __syncthreads();
 
     uint32_t signs[4] = {0u, 0u, 0u, 0u};
+    // A fragment of step `ks` of stage `st` for this lane's row of S (Rademacher: `signs` must hold the Philox words of the
+    // 256-row block that contains the stage)
+    auto refresh_signs = [&](size_t st) __attribute__((always_inline)) {
+        if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) {
+            // one Philox call covers this lane's 16 MFMA steps = 256 rows = 4 or 2 stages (k_begin is a multiple of 256)
+            if ((st & (kPerBlock - 1)) == 0 && !(FEWBIT_SKETCH_ABLATE & 4))
+                philox4x32(srow, static_cast<uint32_t>(2 * ((k_begin + st * BK) >> 8) + h), 0u, 0u, key, signs);
+        }
+    };
+    auto make_fragment = [&](size_t st, int ks) __attribute__((always_inline)) -> u32x4 {
+        if constexpr ((FEWBIT_SKETCH_ABLATE & 4) != 0) return u32x4{srow, srow, srow, srow};
+        else if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) return rademacher_fragment<DT>(signs, static_cast<int>((st & (kPerBlock - 1)) * kSteps + ks));
+        else return gaussian_fragment<DT>(srow, static_cast<uint32_t>(((k_begin + st * BK) >> 3) + 2 * ks + h), key);
+    };
+    // NH = 2: this wave's share of the A fragments of stage `st` (steps [hf * kSteps / 2, (hf + 1) * kSteps / 2)) -> the LDS
+    // exchange buffer of that stage; its partner (same rows, other column half) writes the other steps
+    uint8_t *abuf = lds + 2 * kStageBytes;
+    auto publish_fragments = [&](size_t st, auto checked_tag) __attribute__((always_inline)) {
+        if constexpr (NH > 1) {
+            if constexpr (decltype(checked_tag)::value) {
+                if (st >= nstages) return;             // block-uniform (the interior loop never gets here)
+            }
+            refresh_signs(st);
+#pragma unroll
+            for (int j = 0; j < kSteps / NH; ++j) {
+                const int ks = hf * (kSteps / NH) + j;
+                const u32x4 a = make_fragment(st, ks);
+                *reinterpret_cast<u32x4 *>(abuf + (st & 1) * kABytes + ((rg * kSteps + ks) * 64 + lane) * 16) = a;
+            }
+        }
+    };
+    if constexpr (NH > 1) {
+        publish_fragments(0, std::true_type{});
+        __syncthreads();
+    }
     // the multiply phase of one stage; FAST: the staging of stage s+1 (registers -> LDS) and the loads of stage s+2 are
     // unconditional and woven into the MFMA stream by the group barriers (one basic block)
     auto stage = [&](size_t s, auto fast_tag, auto first_tag) __attribute__((always_inline)) {
@@ -360,35 +409,40 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
             stage_to_lds(s + 1, m1, nxt);
             fetch(s + 2, m2);
         }
-        if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) {
-            // one Philox call covers this lane's 16 MFMA steps = 256 rows = 4 or 2 stages (k_begin is a multiple of 256)
-            if ((s & (kPerBlock - 1)) == 0 && !(FEWBIT_SKETCH_ABLATE & 4)) philox4x32(srow, static_cast<uint32_t>(2 * (k0 >> 8) + h), 0u, 0u, key, signs);
-        }
+        if constexpr (NH == 1) refresh_signs(s);
+        if constexpr (NH > 1 && !FAST) publish_fragments(s + 1, std::true_type{});
         __builtin_amdgcn_sched_barrier(0);
         // B fragments: all 8 of a 16-row step are in registers before its first MFMA, and each register is refilled with the
         // NEXT step's fragment right behind the MFMA that consumed it -- a full step (8 MFMAs = 256 cycles) of LDS latency cover.
         // hipcc's scheduler would sink every read to just in front of its MFMA (two registers, no cover) and cluster the staging
         // work in front of the MFMAs, so the order is pinned: one sched_barrier per MFMA slot, and inside a slot the order
-        // written here.  FAST: slot t of step 0 carries the transpose + LDS write of feature t of stage s+1, slot t of step 1
-        // the load of row t of stage s+2 (into the registers the transpose has just freed).
-        const uint8_t *frag = cur + (static_cast<size_t>(h) * BN + c) * 16;
+        // written here.  FAST: slot t of step `first` carries the transpose + LDS write of feature t of stage s+1, slot t of
+        // step `first + 1` the load of row t of stage s+2 (into the registers the transpose has just freed); with two column
+        // halves the wave's share of the NEXT stage's A fragments is generated in front of step `first` as well -- the two waves
+        // of a SIMD (same rows, other half) have different `first`, so one generates while the other multiplies.
+        const uint8_t *frag = cur + (static_cast<size_t>(h) * BNT + 256 * hf + c) * 16;
         u32x4 bq[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) bq[t] = *reinterpret_cast<const u32x4 *>(frag + 32 * 16 * t);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < kSteps; ++ks) {
+            if constexpr (NH > 1 && FAST) {
+                if (ks == first) {
+                    publish_fragments(s + 1, std::false_type{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             u32x4 a;
-            if constexpr ((FEWBIT_SKETCH_ABLATE & 4) != 0) a = u32x4{srow, srow, srow, srow};
-            else if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) a = rademacher_fragment<DT>(signs, static_cast<int>((s & (kPerBlock - 1)) * kSteps + ks));
-            else a = gaussian_fragment<DT>(srow, static_cast<uint32_t>((k0 >> 3) + 2 * ks + h), key);
+            if constexpr (NH > 1) a = *reinterpret_cast<const u32x4 *>(abuf + (s & 1) * kABytes + ((rg * kSteps + ks) * 64 + lane) * 16);
+            else a = make_fragment(s, ks);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = Operand<DT>::mfma(a, bq[t], acc[t]);
                 if (ks + 1 < kSteps && !(FEWBIT_SKETCH_ABLATE & 8))
-                    bq[t] = *reinterpret_cast<const u32x4 *>(frag + (static_cast<size_t>(2 * (ks + 1)) * BN + 32 * t) * 16);
+                    bq[t] = *reinterpret_cast<const u32x4 *>(frag + (static_cast<size_t>(2 * (ks + 1)) * BNT + 32 * t) * 16);
                 if constexpr (FAST) {
-                    if (ks == first) store_feature(blk, nxt, so, sfc, t);
+                    if (ks == first) store_feature<BNT>(blk, nxt, so, sfc, t);
                     if (ks == first + 1) raw.row[t] = load_raw<DT>(next_base + off[t]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -403,12 +457,13 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     // (W = 8: the upper four waves do their staging four steps later than the lower four, so that the two waves of a SIMD are
     // not both in their VALU-heavy slots at once -- a wave-uniform choice between two copies of the loop, made once)
     typedef std::integral_constant<int, 0> Step0;
-    typedef std::integral_constant<int, 4> Step4;
+    typedef std::integral_constant<int, (W == 8 ? kSteps / 2 : 0)> StepMid;
     // (a static s_setprio 1 / 2 for the upper half measured 1 % slower, 161.2 / 161.4 against 159.7 us at 16384x3072, proj 1638)
+    // (the same for the upper half of the 128 x 512 Gaussian tile: 3.5 % slower, 218.0 against 210.4 us)
     size_t s = 0;
     if constexpr (!RAGGED && !(FEWBIT_SKETCH_ABLATE & 1)) {
         if (W == 8 && wave >= 4) {
-            if constexpr (W == 8) for (; s + 2 < nfull; ++s) stage(s, std::true_type{}, Step4{});
+            if constexpr (W == 8) for (; s + 2 < nfull; ++s) stage(s, std::true_type{}, StepMid{});
         } else {
             for (; s + 2 < nfull; ++s) stage(s, std::true_type{}, Step0{});
         }
@@ -418,8 +473,8 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     // ---- epilogue: accumulator register r of block t is S row (r&3) + 8*(r>>2) + 4*h, feature 8c + t
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const size_t i = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const size_t f = n0 + 8 * c;
+        const size_t i = m0 + 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const size_t f = n0 + 256 * hf + 8 * c;
         if (i >= proj || f >= features) continue;
         float v[8];
 #pragma unroll
@@ -495,7 +550,7 @@ template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-struct Plan { unsigned gx, gy, gz; size_t kslice; int waves; };
+struct Plan { unsigned gx, gy, gz; size_t kslice; int waves, halves; };
 
 int device_cus() {
     static std::atomic<int> cached[64];
@@ -509,7 +564,7 @@ int device_cus() {
     return v;
 }
 
-FEWBIT_HIDDEN std::atomic<long long> g_forced_slices{-1}, g_forced_waves{-1};
+FEWBIT_HIDDEN std::atomic<long long> g_forced_slices{-1}, g_forced_waves{-1}, g_forced_halves{-1};
 
 // K slices: the tile grid of a sketch is small (proj x features) and K = rows is long, so the rows are cut into `gz` slices
 // when that fills the chip better.  cost(z) = (rounds of the CU array with z x tiles workgroups) / z, plus 4 % per extra
@@ -531,13 +586,34 @@ double plan_slices(size_t tiles, size_t slots, size_t rows, long long forced, si
     return best_cost;
 }
 
-Plan make_plan(size_t rows, size_t features, size_t proj) {
+Plan make_plan(int dist, size_t rows, size_t features, size_t proj) {
     const long long forced_z = g_forced_slices.load(std::memory_order_relaxed), forced_w = g_forced_waves.load(std::memory_order_relaxed);
+    const long long forced_h = g_forced_halves.load(std::memory_order_relaxed);
     const size_t cus = static_cast<size_t>(device_cus());
     Plan p;
+    // the Gaussian sketch is bound by the generator (VALU): the 128 x 512 tile generates every element of S once per 512
+    // columns instead of once per 256 (two column halves share their A fragments through LDS); worth it from 512 features on
+    bool wide = dist == FEWBIT_SKETCH_GAUSSIAN && features > 256;
+    if (forced_h == 1) wide = false;
+    if (forced_h == 2) wide = true;
+    if (wide) {
+        p.waves = 8;
+        p.halves = 2;
+        p.gx = static_cast<unsigned>((features + 2 * BN - 1) / (2 * BN));
+        p.gy = static_cast<unsigned>((proj + 127) / 128);
+        size_t z = 1;
+        plan_slices(static_cast<size_t>(p.gx) * p.gy, cus, rows, forced_z, z);
+        size_t kslice = (rows + z - 1) / z;
+        kslice = (kslice + 255) / 256 * 256;
+        p.kslice = kslice;
+        p.gz = static_cast<unsigned>((rows + kslice - 1) / kslice);
+        if (p.gz < 1) p.gz = 1;
+        return p;
+    }
+    p.halves = 1;
     p.gx = static_cast<unsigned>((features + BN - 1) / BN);
     // tile height: 256 rows of S (8 waves) when that does not waste more of the last row tile than 128 rows (4 waves) would
-    // cost in staging -- time per row tile ~ (1 + staging share) with the share halved by the taller tile
+    // cost in staging
     size_t z4 = 1, z8 = 1;
     const size_t t4 = static_cast<size_t>(p.gx) * ((proj + 127) / 128), t8 = static_cast<size_t>(p.gx) * ((proj + 255) / 256);
     // (a round of 2 x CUs short tiles and a round of CUs tall tiles are the same MFMA work per CU; measured, the tall tile runs
@@ -558,11 +634,11 @@ Plan make_plan(size_t rows, size_t features, size_t proj) {
     return p;
 }
 
-template <int DIST, int DT, bool PARTIAL, int W>
+template <int DIST, int DT, bool PARTIAL, int W, int NH = 1>
 int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Key key, float scale, void *out,
                   hipStream_t s) {
-    const dim3 grid(p.gx, p.gy, p.gz), block(Tile<W>::kThreads);
-    constexpr size_t lds = 2 * Tile<W>::kStageBytes;
+    const dim3 grid(p.gx, p.gy, p.gz), block(Tile<W, NH>::kThreads);
+    constexpr size_t lds = Tile<W, NH>::kLdsBytes;
     auto go = [&](auto kern) -> int {
         if (lds > 65536) {                           // (more than the default limit of a workgroup: opt in once per kernel and device)
             static std::atomic<unsigned long long> done{0};
@@ -580,25 +656,27 @@ int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t
         hipLaunchKernelGGL(kern, grid, block, lds, s, m, rows, features, ld, proj, key, scale, out, p.kslice);
         return FEWBIT_OK;
     };
-    return ragged ? go(sketch_kernel<DIST, DT, PARTIAL, true, W>) : go(sketch_kernel<DIST, DT, PARTIAL, false, W>);
+    return ragged ? go(sketch_kernel<DIST, DT, PARTIAL, true, W, NH>) : go(sketch_kernel<DIST, DT, PARTIAL, false, W, NH>);
 }
 
 template <int DIST, int DT>
 int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, Key key, float scale, void *out, void *workspace,
            size_t workspace_bytes, hipStream_t s) {
-    const Plan p = make_plan(rows, features, proj);
+    const Plan p = make_plan(DIST, rows, features, proj);
     const bool ragged = (features % 8) != 0;
     int rc;
     if (p.gz == 1) {
-        rc = p.waves == 8 ? launch_kernel<DIST, DT, false, 8>(p, ragged, m, rows, features, ld, proj, key, scale, out, s)
-                          : launch_kernel<DIST, DT, false, 4>(p, ragged, m, rows, features, ld, proj, key, scale, out, s);
+        rc = p.halves == 2 ? launch_kernel<DIST, DT, false, 8, 2>(p, ragged, m, rows, features, ld, proj, key, scale, out, s)
+             : p.waves == 8 ? launch_kernel<DIST, DT, false, 8>(p, ragged, m, rows, features, ld, proj, key, scale, out, s)
+                            : launch_kernel<DIST, DT, false, 4>(p, ragged, m, rows, features, ld, proj, key, scale, out, s);
         if (rc != FEWBIT_OK) return rc;
     } else {
         const size_t need = static_cast<size_t>(p.gz) * proj * features * sizeof(float);
         if (workspace == nullptr || workspace_bytes < need)
             return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", need, workspace_bytes);
-        rc = p.waves == 8 ? launch_kernel<DIST, DT, true, 8>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s)
-                          : launch_kernel<DIST, DT, true, 4>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s);
+        rc = p.halves == 2 ? launch_kernel<DIST, DT, true, 8, 2>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s)
+             : p.waves == 8 ? launch_kernel<DIST, DT, true, 8>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s)
+                            : launch_kernel<DIST, DT, true, 4>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s);
         if (rc != FEWBIT_OK) return rc;
         const size_t n = proj * features;
         hipLaunchKernelGGL((sketch_reduce_kernel<DT>), dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s,
@@ -628,9 +706,9 @@ using namespace fewbit_hip::sketch;
 
 extern "C" {
 
-size_t fewbit_hip_sketch_workspace(size_t rows, size_t features, size_t proj) {
+size_t fewbit_hip_sketch_workspace(int dist, size_t rows, size_t features, size_t proj) {
     if (rows == 0 || features == 0 || proj == 0) return 0;
-    const Plan p = make_plan(rows, features, proj);
+    const Plan p = make_plan(dist, rows, features, proj);
     return p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : 0;
 }
 
@@ -669,12 +747,13 @@ int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, si
     return FEWBIT_OK;
 }
 
-int fewbit_hip_sketch_describe(size_t rows, size_t features, size_t proj, char *buf, size_t len) {
+int fewbit_hip_sketch_describe(int dist, size_t rows, size_t features, size_t proj, char *buf, size_t len) {
     if (buf == nullptr || len == 0) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch_describe: no buffer");
-    const Plan p = make_plan(rows, features, proj);
-    snprintf(buf, len, "{\"kernel\": \"sketch_kernel (%dx256 tile, K stage %d, v_mfma_f32_32x32x16)\", \"grid\": [%u, %u, %u], \"threads\": %d, "
+    const Plan p = make_plan(dist, rows, features, proj);
+    snprintf(buf, len, "{\"kernel\": \"sketch_kernel (%dx%d tile, K stage %d, v_mfma_f32_32x32x16)\", \"grid\": [%u, %u, %u], \"threads\": %d, "
                        "\"k_slice\": %zu, \"lds_bytes\": %d, \"workspace_bytes\": %zu}",
-             32 * p.waves, 16 * p.waves, p.gx, p.gy, p.gz, 64 * p.waves, p.kslice, 2 * 16 * p.waves * BN * 2,
+             32 * p.waves / p.halves, 256 * p.halves, 16 * p.waves / p.halves, p.gx, p.gy, p.gz, 64 * p.waves, p.kslice,
+             p.halves == 2 ? Tile<8, 2>::kLdsBytes : 2 * 16 * p.waves * BN * 2,
              p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : static_cast<size_t>(0));
     return FEWBIT_OK;
 }
@@ -693,6 +772,12 @@ int fewbit_hip_sketch_debug_trace(unsigned long long *host, size_t count) {
 
 int fewbit_hip_sketch_tune_slices(long long slices) {
     g_forced_slices.store(slices, std::memory_order_relaxed);
+    return FEWBIT_OK;
+}
+
+int fewbit_hip_sketch_tune_halves(long long halves) {
+    if (halves != -1 && halves != 1 && halves != 2) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: column halves per workgroup is 1 or 2 (or -1), got %lld", halves);
+    g_forced_halves.store(halves, std::memory_order_relaxed);
     return FEWBIT_OK;
 }
 

@@ -9,7 +9,7 @@ cabi.tune_sketch_slices(z)
 w = int(sys.argv[6]) if len(sys.argv) > 6 else -1
 cabi.tune_sketch_waves(w)
 m = torch.randn(rows, features, device='cuda').to(torch.bfloat16)
-plan = cabi.describe_sketch(rows, features, proj)
+plan = cabi.describe_sketch(dist, rows, features, proj)
 ws = torch.empty(max(plan['workspace_bytes'], 1), dtype=torch.uint8, device='cuda')
 o = torch.empty(proj, features, dtype=torch.bfloat16, device='cuda')
 f = lambda: cabi.sketch(dist, m, proj, 1234, 1.0 / proj, out=o, workspace=ws)

@@ -8,8 +8,11 @@ dist = sys.argv[1] if len(sys.argv) > 1 else 'rademacher'
 w = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rows, features, proj = 16384, 3072, 1638
 cabi.tune_sketch_waves(w)
+halves = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+cabi.tune_sketch_halves(halves)
+if halves == 2: w = 8
 m = torch.randn(rows, features, device='cuda').to(torch.bfloat16)
-plan = cabi.describe_sketch(rows, features, proj)
+plan = cabi.describe_sketch(dist, rows, features, proj)
 for _ in range(3): cabi.sketch(dist, m, proj, 1, 1.0)
 torch.cuda.synchronize()
 L = cabi.lib()
@@ -17,7 +20,7 @@ L.fewbit_hip_sketch_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 buf = np.zeros(8 * 512 * 3, dtype=np.uint64)
 assert L.fewbit_hip_sketch_debug_trace(buf.ctypes.data, buf.size) == 0
 t = buf.reshape(8, 512, 3).astype(np.int64)
-nst = plan['k_slice'] // (16 * w)
+nst = plan['k_slice'] // (16 * w // halves)
 print(plan, 'stages per slice', nst)
 for wave in range(w):
     tt = t[wave, :nst]

@@ -52,12 +52,18 @@ def _product_case(dist, dtype, rows, features, proj, seed, ld=None, scale=1.0):
     return got
 
 
+@pytest.mark.parametrize('halves', (1, 2))
 @pytest.mark.parametrize('dist', ('rademacher', 'gaussian'))
 @pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16, torch.float16))
-def test_product_equals_the_model_matrix_times_m(dist, dtype):
-    for rows, features, proj in ((64, 256, 128), (100, 37, 5), (1000, 264, 130), (257, 8, 1), (4096, 512, 256), (3000, 770, 200)):
-        _product_case(dist, dtype, rows, features, proj, seed=rows + 17)
-    _product_case(dist, dtype, 512, 100, 64, seed=3, ld=136, scale=0.125)         # a strided view, a scale
+def test_product_equals_the_model_matrix_times_m(dist, dtype, halves):
+    """`halves` = 2: the 128 x 512 tile, whose wave pairs hand each other their A fragments through LDS"""
+    cabi.tune_sketch_halves(halves)
+    try:
+        for rows, features, proj in ((64, 256, 128), (100, 37, 5), (1000, 264, 130), (257, 8, 1), (4096, 512, 256), (3000, 770, 200), (2048, 1024, 300)):
+            _product_case(dist, dtype, rows, features, proj, seed=rows + 17)
+        _product_case(dist, dtype, 512, 100, 64, seed=3, ld=136, scale=0.125)         # a strided view, a scale
+    finally:
+        cabi.tune_sketch_halves(-1)
 
 
 def test_row_slices_are_deterministic_and_agree():
@@ -67,7 +73,7 @@ def test_row_slices_are_deterministic_and_agree():
         outs = {}
         for z in (1, 2, 4, 8):
             cabi.tune_sketch_slices(z)
-            assert cabi.describe_sketch(8192, 384, 200)['grid'][2] == z
+            assert cabi.describe_sketch('rademacher', 8192, 384, 200)['grid'][2] == z
             a = cabi.sketch('rademacher', m.float(), 200, 42)
             b = cabi.sketch('rademacher', m.float(), 200, 42)
             assert torch.equal(a, b)
@@ -75,18 +81,28 @@ def test_row_slices_are_deterministic_and_agree():
         for z in (2, 4, 8):
             assert torch.allclose(outs[z], outs[1], rtol=1e-5, atol=1e-3)
         cabi.tune_sketch_slices(-1)
+        cabi.tune_sketch_halves(1)
         for w in (4, 8):                                 # both tile heights: the same sums
             cabi.tune_sketch_waves(w)
-            assert cabi.describe_sketch(8192, 384, 200)['threads'] == 64 * w
+            assert cabi.describe_sketch('rademacher', 8192, 384, 200)['threads'] == 64 * w
             for dist in ('rademacher', 'gaussian'):
                 outs[(dist, w)] = cabi.sketch(dist, m, 200, 42)
+        cabi.tune_sketch_waves(-1)
+        cabi.tune_sketch_halves(2)                       # the 128 x 512 tile (A fragments shared through LDS), both sketches
+        for dist in ('rademacher', 'gaussian'):
+            assert '128x512' in cabi.describe_sketch(dist, 8192, 384, 200)['kernel']
+            outs[(dist, 'wide')] = cabi.sketch(dist, m, 200, 42)
         for dist in ('rademacher', 'gaussian'):
             assert torch.allclose(outs[(dist, 4)].float(), outs[(dist, 8)].float(), rtol=2e-2, atol=0.5)
+            assert torch.allclose(outs[(dist, 4)].float(), outs[(dist, 'wide')].float(), rtol=2e-2, atol=0.5)
     finally:
         cabi.tune_sketch_slices(-1)
         cabi.tune_sketch_waves(-1)
-    plan = cabi.describe_sketch(16384, 3072, 1638)
+        cabi.tune_sketch_halves(-1)
+    plan = cabi.describe_sketch('rademacher', 16384, 3072, 1638)
     assert plan['threads'] in (256, 512) and plan['grid'][0] == 12 and plan['grid'][1] == -(-1638 // (plan['threads'] // 2)) and plan['grid'][2] >= 1
+    plan = cabi.describe_sketch('gaussian', 16384, 3072, 1638)
+    assert '128x512' in plan['kernel'] and plan['grid'][:2] == [6, 13] and plan['lds_bytes'] == 163840
 
 
 def test_empty_and_degenerate_shapes():
