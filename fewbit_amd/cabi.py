@@ -94,13 +94,13 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_tune.argtypes = [cp, ctypes.c_longlong]
         u64 = ctypes.c_uint64
         L.fewbit_hip_sketch_workspace.restype = sz
-        L.fewbit_hip_sketch_workspace.argtypes = [i32, sz, sz, sz]
+        L.fewbit_hip_sketch_workspace.argtypes = [i32, i32, sz, sz, sz]
         L.fewbit_hip_sketch.restype = i32
         L.fewbit_hip_sketch.argtypes = [i32, i32, vp, sz, sz, sz, sz, u64, dbl, vp, vp, sz, vp]
         L.fewbit_hip_sketch_matrix.restype = i32
         L.fewbit_hip_sketch_matrix.argtypes = [i32, i32, u64, sz, sz, sz, sz, vp, vp]
         L.fewbit_hip_sketch_describe.restype = i32
-        L.fewbit_hip_sketch_describe.argtypes = [i32, sz, sz, sz, cp, sz]
+        L.fewbit_hip_sketch_describe.argtypes = [i32, i32, sz, sz, sz, cp, sz]
         L.fewbit_hip_sketch_tune_slices.restype = i32
         L.fewbit_hip_sketch_tune_slices.argtypes = [ctypes.c_longlong]
         L.fewbit_hip_sketch_tune_waves.restype = i32
@@ -360,8 +360,8 @@ def tune(**settings: int) -> None:
 
 
 # ---- random-projection products (fewbit_amd/csrc/fewbit_sketch.hip): out = scale * S . m, S a function of the seed ------
-def sketch_workspace_bytes(dist: str, rows: int, features: int, proj: int) -> int:
-    return lib().fewbit_hip_sketch_workspace(SKETCH_DISTS.index(dist), rows, features, proj)
+def sketch_workspace_bytes(dist: str, rows: int, features: int, proj: int, dtype: torch.dtype = torch.bfloat16) -> int:
+    return lib().fewbit_hip_sketch_workspace(SKETCH_DISTS.index(dist), DTYPES[dtype], rows, features, proj)
 
 
 def sketch(dist: str, m: torch.Tensor, proj: int, seed: int, scale: float = 1.0, out: Optional[torch.Tensor] = None,
@@ -381,7 +381,7 @@ def sketch(dist: str, m: torch.Tensor, proj: int, seed: int, scale: float = 1.0,
             out = torch.empty((proj, features), dtype=m.dtype, device=m.device)
         elif out.shape != (proj, features) or out.dtype != m.dtype or not out.is_contiguous():
             raise FewbitHipError('out must be a contiguous proj x features tensor of the dtype of m')
-        need = sketch_workspace_bytes(dist, rows, features, proj)
+        need = sketch_workspace_bytes(dist, rows, features, proj, m.dtype)
         if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
             workspace = torch.empty(need, dtype=torch.uint8, device=m.device)
         _same_device(m, out, *(() if workspace is None else (workspace, )))
@@ -404,8 +404,8 @@ def sketch_matrix(dist: str, dtype: torch.dtype, seed: int, nrows: int, ncols: i
     return out
 
 
-def describe_sketch(dist: str, rows: int, features: int, proj: int, device=None) -> dict:
-    return _describe(lib().fewbit_hip_sketch_describe, SKETCH_DISTS.index(dist), rows, features, proj, device=device)
+def describe_sketch(dist: str, rows: int, features: int, proj: int, dtype: torch.dtype = torch.bfloat16, device=None) -> dict:
+    return _describe(lib().fewbit_hip_sketch_describe, SKETCH_DISTS.index(dist), DTYPES[dtype], rows, features, proj, device=device)
 
 
 def tune_sketch_slices(slices: int) -> None:

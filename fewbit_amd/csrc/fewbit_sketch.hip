@@ -586,14 +586,16 @@ double plan_slices(size_t tiles, size_t slots, size_t rows, long long forced, si
     return best_cost;
 }
 
-Plan make_plan(int dist, size_t rows, size_t features, size_t proj) {
+Plan make_plan(int dist, int dtype, size_t rows, size_t features, size_t proj) {
     const long long forced_z = g_forced_slices.load(std::memory_order_relaxed), forced_w = g_forced_waves.load(std::memory_order_relaxed);
     const long long forced_h = g_forced_halves.load(std::memory_order_relaxed);
     const size_t cus = static_cast<size_t>(device_cus());
     Plan p;
-    // the Gaussian sketch is bound by the generator (VALU): the 128 x 512 tile generates every element of S once per 512
-    // columns instead of once per 256 (two column halves share their A fragments through LDS); worth it from 512 features on
-    bool wide = dist == FEWBIT_SKETCH_GAUSSIAN && features > 256;
+    // the Gaussian sketch is bound by the generator (instruction issue): the 128 x 512 tile generates every element of S once per
+    // 512 columns instead of once per 256 (two column halves share their A fragments through LDS).  Measured (16384 rows,
+    // bf16): 3072 features +11-16 % at p = 1638 / 3276 / 8192; 768 features (one and a half wide tiles) -8 %; fp32 input no gain
+    // (its staging registers already spill) -- so: 16-bit input, and a feature count the 512-wide tile divides or >= 2048
+    bool wide = dist == FEWBIT_SKETCH_GAUSSIAN && dtype != FEWBIT_F32 && features >= 1024 && (features % (2 * BN) == 0 || features >= 2048);
     if (forced_h == 1) wide = false;
     if (forced_h == 2) wide = true;
     if (wide) {
@@ -662,7 +664,7 @@ int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t
 template <int DIST, int DT>
 int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, Key key, float scale, void *out, void *workspace,
            size_t workspace_bytes, hipStream_t s) {
-    const Plan p = make_plan(DIST, rows, features, proj);
+    const Plan p = make_plan(DIST, DT, rows, features, proj);
     const bool ragged = (features % 8) != 0;
     int rc;
     if (p.gz == 1) {
@@ -706,9 +708,9 @@ using namespace fewbit_hip::sketch;
 
 extern "C" {
 
-size_t fewbit_hip_sketch_workspace(int dist, size_t rows, size_t features, size_t proj) {
+size_t fewbit_hip_sketch_workspace(int dist, int dtype, size_t rows, size_t features, size_t proj) {
     if (rows == 0 || features == 0 || proj == 0) return 0;
-    const Plan p = make_plan(dist, rows, features, proj);
+    const Plan p = make_plan(dist, dtype, rows, features, proj);
     return p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : 0;
 }
 
@@ -747,9 +749,9 @@ int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, si
     return FEWBIT_OK;
 }
 
-int fewbit_hip_sketch_describe(int dist, size_t rows, size_t features, size_t proj, char *buf, size_t len) {
+int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features, size_t proj, char *buf, size_t len) {
     if (buf == nullptr || len == 0) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch_describe: no buffer");
-    const Plan p = make_plan(dist, rows, features, proj);
+    const Plan p = make_plan(dist, dtype, rows, features, proj);
     snprintf(buf, len, "{\"kernel\": \"sketch_kernel (%dx%d tile, K stage %d, v_mfma_f32_32x32x16)\", \"grid\": [%u, %u, %u], \"threads\": %d, "
                        "\"k_slice\": %zu, \"lds_bytes\": %d, \"workspace_bytes\": %zu}",
              32 * p.waves / p.halves, 256 * p.halves, 16 * p.waves / p.halves, p.gx, p.gy, p.gz, 64 * p.waves, p.kslice,

@@ -170,12 +170,12 @@ int fewbit_hip_unpack_codes(const uint8_t *state, int32_t *codes, size_t n, int 
  *   m    rows x features, row-major with leading dimension `ld` (elements), dtype F32 / F16 / BF16; fp32 is rounded to bf16
  *        while it is staged (the products run on the bf16 matrix pipe, accumulation is fp32)
  *   out  proj x features, contiguous, the dtype of m
- *   workspace  fewbit_hip_sketch_workspace(dist, rows, features, proj) bytes of device memory (0 when the rows are not sliced);
+ *   workspace  fewbit_hip_sketch_workspace(dist, dtype, rows, features, proj) bytes of device memory (0 when the rows are not sliced);
  *        contents are scratch.  The result is deterministic: the same arguments give the same bits.
  */
 typedef enum fewbit_sketch_dist { FEWBIT_SKETCH_RADEMACHER = 0, FEWBIT_SKETCH_GAUSSIAN = 1 } fewbit_sketch_dist;
 
-size_t fewbit_hip_sketch_workspace(int dist, size_t rows, size_t features, size_t proj);
+size_t fewbit_hip_sketch_workspace(int dist, int dtype, size_t rows, size_t features, size_t proj);
 int fewbit_hip_sketch(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, uint64_t seed,
                       double scale, void *out, void *workspace, size_t workspace_bytes, void *stream);
 /* S[row0 .. row0+nrows) x [col0 .. col0+ncols) itself as fp32 (rounded as the product kernel rounds its operand for
@@ -183,7 +183,7 @@ int fewbit_hip_sketch(int dist, int dtype, const void *m, size_t rows, size_t fe
 int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, size_t col0, size_t nrows, size_t ncols, float *out,
                              void *stream);
 /* launch shape a fewbit_hip_sketch call would use, as JSON: {"kernel", "grid": [x, y, z], "threads", "k_slice", ...} */
-int fewbit_hip_sketch_describe(int dist, size_t rows, size_t features, size_t proj, char *buf, size_t len);
+int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features, size_t proj, char *buf, size_t len);
 /* measurement hooks: force the number of row slices (> 0) / the waves per workgroup (4: 128-row tile, 8: 256-row tile) / the
  * column halves per workgroup (2: the 128 x 512 tile whose wave pairs share their A fragments through LDS, the Gaussian
  * sketch's default from 512 features on); -1 = built-in policy.  Every setting computes the same sums (up to fp32

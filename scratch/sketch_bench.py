@@ -46,7 +46,7 @@ def main():
             for dist in ('rademacher', 'gaussian'):
                 for z in slices:
                     cabi.tune_sketch_slices(z)
-                    plan = cabi.describe_sketch(dist, rows, features, proj)
+                    plan = cabi.describe_sketch(dist, rows, features, proj, dtype)
                     ws = torch.empty(max(plan['workspace_bytes'], 1), dtype=torch.uint8, device=DEV)
                     o = torch.empty(proj, features, dtype=dtype, device=DEV)
                     us = timed(lambda: cabi.sketch(dist, m, proj, 1234, 1.0 / proj, out=o, workspace=ws))

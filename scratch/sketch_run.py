@@ -10,7 +10,7 @@ reps = int(sys.argv[6]) if len(sys.argv) > 6 else 10
 if len(sys.argv) > 7:
     cabi.tune_sketch_slices(int(sys.argv[7]))
 m = torch.randn(rows, features, device='cuda').to(dtype)
-plan = cabi.describe_sketch(dist, rows, features, proj)
+plan = cabi.describe_sketch(dist, rows, features, proj, dtype)
 ws = torch.empty(max(plan['workspace_bytes'], 1), dtype=torch.uint8, device='cuda')
 o = torch.empty(proj, features, dtype=dtype, device='cuda')
 for _ in range(reps):
