@@ -127,3 +127,70 @@ def test_estimator_is_unbiased_on_the_gpu_kernel():
             acc += cabi.sketch(dist, gy, 64, seed).T @ cabi.sketch(dist, x, 64, seed, 1.0 / 64)
         rel = float(torch.linalg.norm(acc / n - exact) / torch.linalg.norm(exact))
         assert rel < 0.25, (dist, rel)                                    # one draw: ~sqrt(512/64) = 2.8; mean of 300: ~0.16
+
+
+def test_seeded_fuzz_of_shapes_dtypes_strides_and_tiles():
+    """60 random cases around the tile edges (128 / 256 rows of S, 256 / 512 features, stages of 64 / 128 rows, 256-row
+    Rademacher blocks, 1024-row slices): distribution, dtype, ragged sizes, a row stride, a scale, the tile height / width and
+    the slicing are drawn per case; every product must equal the host model's"""
+    import random
+    rnd = random.Random(20260402)
+    edges_r = (1, 7, 8, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 3000)
+    edges_f = (1, 8, 9, 40, 255, 256, 257, 264, 511, 512, 520, 768, 1032)
+    edges_p = (1, 31, 32, 33, 127, 128, 129, 255, 256, 257, 300)
+    try:
+        for case in range(60):
+            dist = rnd.choice(('rademacher', 'gaussian'))
+            dtype = rnd.choice((torch.float32, torch.bfloat16, torch.float16))
+            rows, features, proj = rnd.choice(edges_r), rnd.choice(edges_f), rnd.choice(edges_p)
+            cabi.tune_sketch_waves(rnd.choice((-1, 4, 8)))
+            cabi.tune_sketch_halves(rnd.choice((-1, 1, 2)))
+            cabi.tune_sketch_slices(rnd.choice((-1, 1, 2, 3)))
+            ld = features + rnd.choice((0, 0, 8, 3)) if features > 1 else None
+            _product_case(dist, dtype, rows, features, proj, seed=rnd.getrandbits(64), ld=ld if ld != features else None,
+                          scale=rnd.choice((1.0, 1.0 / proj, -0.5)))
+    finally:
+        cabi.tune_sketch_waves(-1)
+        cabi.tune_sketch_halves(-1)
+        cabi.tune_sketch_slices(-1)
+
+
+def test_sketch_and_randomized_layer_capture_into_a_hip_graph():
+    """no call of the path synchronises or reads back from the device: the kernel (and a whole randomized layer step with its seed
+    drawn on the host) can be captured once and replayed on new data"""
+    import fewbit
+    m = torch.zeros(2048, 512, device=DEV, dtype=torch.bfloat16)
+    out = torch.empty(130, 512, device=DEV, dtype=torch.bfloat16)
+    ws = torch.empty(max(cabi.sketch_workspace_bytes('rademacher', 2048, 512, 130), 1), dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        cabi.sketch('rademacher', m, 130, 5, 1.0, out=out, workspace=ws)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cabi.sketch('rademacher', m, 130, 5, 1.0, out=out, workspace=ws)
+    data = torch.randn(2048, 512, generator=torch.Generator().manual_seed(2)).to(torch.bfloat16)
+    m.copy_(data.to(DEV))
+    g.replay()
+    torch.cuda.synchronize()
+    want = ref.rademacher(5, 130, 2048).double() @ data.double()
+    assert float((out.cpu().double() - want).abs().max() / want.abs().max()) < 2.0**-7
+    # a layer step: forward + backward of RandomizedLinear inside one graph
+    lin = fewbit.RandomizedLinear(64, 32, proj_dim_ratio=0.25, matmul='rademacher', device=DEV)
+    x = torch.zeros(512, 64, device=DEV, requires_grad=True)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            gw, = torch.autograd.grad(lin(x).sum(), lin.weight)
+    torch.cuda.current_stream().wait_stream(side)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        gw, = torch.autograd.grad(lin(x).sum(), lin.weight)
+    with torch.no_grad():
+        x.copy_(torch.randn(512, 64, device=DEV))
+    g2.replay()
+    torch.cuda.synchronize()
+    exact = torch.ones(512, 32, device=DEV).T @ x.detach()
+    assert gw.shape == exact.shape and float(torch.linalg.norm(gw - exact) / torch.linalg.norm(exact)) < 4.0     # one draw: ~sqrt(rows/p) = 2
+    assert float(gw.abs().max()) > 0
