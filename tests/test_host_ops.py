@@ -292,3 +292,35 @@ def test_direct_node_and_function_routes_agree_on_the_host():
         fewbit_amd.autograd_route('direct_node', prev)
     for a, b in zip(results[True], results[False]):
         assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+def test_in_place_on_a_whole_view_on_the_host_takes_the_base_route_and_stays_correct():
+    """the host operators share the view handling of the GPU ones: in place on a view that covers its whole base (the 3-D
+    output of nn.Linear) modifies the base, returns a fresh view of it, and every alias keeps working"""
+    import fewbit_amd
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(16, 24)
+    x = torch.randn(4, 5, 16)
+    inner, levels = store.get_inner('silu', 3, torch.device('cpu'), torch.float32)
+    wgt = torch.randn(4, 5, 24)
+
+    def run(shape3d):
+        lin.zero_grad(set_to_none=True)
+        h = lin(x if shape3d else x.view(-1, 16))
+        assert h._is_view() == shape3d
+        out = torch.ops.fewbit.silu(h, inner, levels)
+        assert out.data_ptr() == h.data_ptr() and torch.equal(out.detach(), h.detach())
+        ((out * (wgt if shape3d else wgt.view(-1, 24))).sum() + 0.5 * h.sum()).backward()
+        return out.detach().reshape(-1, 24).clone(), lin.weight.grad.clone(), out.grad_fn.name()
+
+    y3, g3, name3 = run(True)
+    y2, g2, _ = run(False)
+    assert torch.equal(y3, y2) and torch.allclose(g3, g2, rtol=1e-5, atol=1e-6)
+    if fewbit_amd.autograd_internals():
+        assert 'ViewBackward' in name3 or 'Reshape' in name3 or 'View' in name3, name3      # the fresh view, not CopySlices
+        prev = fewbit_amd.autograd_route('base_dirty', False)
+        try:
+            y3g, g3g, _ = run(True)                       # autograd's general in-place-on-view route: the same numbers
+        finally:
+            fewbit_amd.autograd_route('base_dirty', prev)
+        assert torch.equal(y3g, y2) and torch.allclose(g3g, g2, rtol=1e-5, atol=1e-6)
