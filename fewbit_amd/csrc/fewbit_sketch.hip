@@ -12,7 +12,7 @@
 // straight to v_mfma_f32_32x32x16_{bf16,f16}, and forward and backward regenerate the same S from the 64-bit seed alone.
 // HBM traffic of S: zero bytes (the reference: 2 x proj x rows x 4 B per layer and step).
 //
-// ---- the definition of S (a pure function; tests/sketch_reference.py evaluates the same formulas with PyTorch) -----------
+// ---- the definition of S (a pure function; tests/sketch_reference.py evaluates the same formulas with numpy) -------------
 //   philox(c0, c1, c2, c3) = Philox4x32-10 with key (seed_lo, seed_hi)          [Salmon et al. 2011; the generator behind
 //                                                                               torch.cuda's and cuRAND's default engine]
 //   Rademacher:  S[i][r] = bit ? -1 : +1,   bit = bit ((j%2 ? 31 : 15) - (4*(s%4) + j/2)) of word s/4 of philox(i, 2*(r/256) + h, 0, 0)
@@ -25,12 +25,13 @@
 //                v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32, ~1 ulp each -- the host model uses libm, and the test
 //                allows one step of the 16-bit operand dtype)
 //
-// ---- tiling ------------------------------------------------------------------------------------------------------------
-//   workgroup  256 threads = 4 waves; output tile 128 (S rows) x 256 (features); wave w owns S rows [32w, 32w+32) x all 256
-//              features = 8 MFMA column blocks of 32 -> 8 x 16 fp32 accumulators per lane.  Waves split the S rows and
-//              nothing else, so no S element is generated twice inside a workgroup.
-//   K loop     over the rows of M in stages of 64, double-buffered in LDS (2 x 32 KiB): loads of stage s+1 are in flight
-//              (registers) while stage s is multiplied; one barrier per stage.
+// ---- tiling (three shapes, `Tile<W, NH>` below; the host picks one per call, make_plan) -------------------------------------
+//   workgroup  W waves (4 or 8); wave w owns 32 rows of S x 256 features = 8 MFMA column blocks of 32 -> 8 x 16 fp32
+//              accumulators per lane.  Waves split the S rows (and, in the 128 x 512 tile, the columns in two halves whose wave
+//              pairs share their A fragments through LDS), so no S element is generated twice inside a workgroup.
+//   K loop     over the rows of M in stages of 64 or 128, double-buffered in LDS, two stages deep: while stage s is multiplied
+//              stage s+1 (loaded during stage s-1) is transposed into the other buffer and the loads of stage s+2 go out; the
+//              staging work and the loads are pinned into the MFMA stream slot by slot; one barrier per stage.
 //   M -> LDS   M is row-major (features contiguous) but the MFMA B operand wants 8 consecutive K values (rows) of ONE
 //              feature per lane.  Each thread loads an 8-row x 8-feature block (8 x 16 B, coalesced along the rows),
 //              transposes it in registers with 32 v_perm_b32 and writes 8 x 16 B: the LDS image is [octet of rows][chunk]
@@ -41,6 +42,7 @@
 //   split K    gridDim.z slices of the rows (multiples of 256) when the tile grid alone cannot fill 256 CUs (proj x
 //              features is small, rows is long): slices write fp32 partials, a second kernel adds them IN A FIXED ORDER
 //              (deterministic: the same seed gives the same bits), scales and casts.
+// Measurement builds: -DFEWBIT_SKETCH_ABLATE=bits (stages compiled out), -DFEWBIT_SKETCH_TRACE (per-stage shader-clock stamps).
 // Roofline class: MFMA (bf16 dense peak 2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md); flops = 2*proj*rows*features.
 #include <hip/hip_runtime.h>
 
@@ -72,7 +74,7 @@ constexpr int NT = BN / 32;                 // MFMA column blocks per wave
 //   W = 8, NH = 2 (the Gaussian sketch): 128 x 512 tile -- the eight waves are 4 row groups x 2 column halves, waves (g, 0) and
 //           (g, 1) need the SAME rows of S, so each generates half of the stage's A fragments and hands them to the other
 //           through LDS (16 KiB per stage): every element of S is generated once per 512 columns instead of once per 256, which
-//           halves the generator work per MFMA -- the Gaussian sketch is VALU-bound (section "S as a function").
+//           halves the generator work per MFMA -- the Gaussian sketch is bound by instruction issue.
 //           Stages of 64 rows, 2 x 64 KiB (M) + 2 x 16 KiB (A fragments) = all 160 KiB of the CU.
 template <int W, int NH = 1> struct Tile {
     static constexpr int kThreads = 64 * W, RG = W / NH, BM = 32 * RG, BNT = BN * NH, BK = 16 * W / NH, kSteps = BK / 16;
