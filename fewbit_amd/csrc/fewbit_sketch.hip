@@ -461,7 +461,10 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     typedef std::integral_constant<int, 0> Step0;
     typedef std::integral_constant<int, (W == 8 ? kSteps / 2 : 0)> StepMid;
     // (a static s_setprio 1 / 2 for the upper half measured 1 % slower, 161.2 / 161.4 against 159.7 us at 16384x3072, proj 1638)
-    // (the same for the upper half of the 128 x 512 Gaussian tile: 3.5 % slower, 218.0 against 210.4 us)
+    // (the same for the upper half of the 128 x 512 Gaussian tile: 3.5 % slower, 218.0 against 210.4 us; letting the two waves
+    // of a SIMD take turns -- the younger one at priority 1 in every other step, or every other pair of steps -- changes nothing:
+    // 159.6 / 159.1 against 160.5 us.  The older wave finishes a stage ~1600 cycles ahead and waits at the barrier, but the
+    // SIMD's issue slots are busy either way)
     size_t s = 0;
     if constexpr (!RAGGED && !(FEWBIT_SKETCH_ABLATE & 1)) {
         if (W == 8 && wave >= 4) {
