@@ -2,6 +2,8 @@
 // What a non-PyTorch host (the reference's C++ launchers, or any FFI) would do:
 //   quantize_forward  : y = gelu(x), packed 3-bit codes -> state
 //   quantize_backward : gx = levels[code] * gy
+//   sketch            : out = S . m with the Rademacher matrix S(seed) that exists only inside the kernel; the host rebuilds
+//                       S from the ABI's own host Philox (fewbit_hip_philox4x32) and the published bit order
 // and a check against a scalar restatement on the host.  Build: make -C fewbit_amd/csrc demo
 #include <fewbit_hip.h>
 #include <hip/hip_runtime.h>
@@ -80,5 +82,45 @@ int main() {
     }
     std::printf("fewbit C-ABI v%d demo: n=%zu state=%zu bytes, mismatches: codes %zu, gradients %zu, forward %zu\n",
                 fewbit_hip_abi_version(), n, nstate, bad_code, bad_gx, bad_y);
-    return (bad_code || bad_gx || bad_y) ? 1 : 0;
+
+    // ---- random projection: out[p x f] = S[p x r] . m[r x f], S = S(seed) never in memory (fp32 m is rounded to bf16 inside) ----
+    const size_t rows = 700, feats = 40, proj = 24;
+    const uint64_t sk_seed = 0x0123456789abcdefull;
+    std::vector<float> m(rows * feats), out(proj * feats);
+    for (size_t i = 0; i < m.size(); ++i) {
+        seed = seed * 1664525u + 1013904223u;
+        m[i] = static_cast<float>(static_cast<int>(seed >> 24) - 128) / 64.0f;      // exactly representable in bf16
+    }
+    float *dm, *dout;
+    void *dws = nullptr;
+    const size_t ws_bytes = fewbit_hip_sketch_workspace(FEWBIT_SKETCH_RADEMACHER, FEWBIT_F32, rows, feats, proj);
+    HIP_OK(hipMalloc(&dm, m.size() * 4));
+    HIP_OK(hipMalloc(&dout, out.size() * 4));
+    if (ws_bytes) HIP_OK(hipMalloc(&dws, ws_bytes));
+    HIP_OK(hipMemcpyAsync(dm, m.data(), m.size() * 4, hipMemcpyHostToDevice, stream));
+    rc = fewbit_hip_sketch(FEWBIT_SKETCH_RADEMACHER, FEWBIT_F32, dm, rows, feats, feats, proj, sk_seed, 1.0, dout, dws, ws_bytes, stream);
+    if (rc != FEWBIT_OK) {
+        std::fprintf(stderr, "fewbit_hip_sketch error %d: %s\n", rc, fewbit_hip_last_error());
+        return 3;
+    }
+    HIP_OK(hipMemcpyAsync(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    // S[i][r]: word s/4 of philox(i, 2*(r/256) + h, 0, 0), bit (j odd ? 31 : 15) - (4*(s%4) + j/2); s = (r%256)/16, h = (r/8)%2, j = r%8
+    const uint32_t key[2] = {static_cast<uint32_t>(sk_seed), static_cast<uint32_t>(sk_seed >> 32)};
+    size_t bad_sketch = 0;
+    for (size_t i = 0; i < proj; ++i) {
+        std::vector<double> want(feats, 0.0);
+        for (size_t r = 0; r < rows; ++r) {
+            const uint32_t s = static_cast<uint32_t>((r % 256) / 16), h = static_cast<uint32_t>((r / 8) % 2), j = static_cast<uint32_t>(r % 8);
+            const uint32_t ctr[4] = {static_cast<uint32_t>(i), static_cast<uint32_t>(2 * (r / 256) + h), 0u, 0u};
+            uint32_t w[4];
+            fewbit_hip_philox4x32(ctr, key, w);
+            const double sign = ((w[s / 4] >> (((j & 1) ? 31 : 15) - (4 * (s % 4) + j / 2))) & 1u) ? -1.0 : 1.0;
+            for (size_t f = 0; f < feats; ++f) want[f] += sign * m[r * feats + f];
+        }
+        for (size_t f = 0; f < feats; ++f) bad_sketch += std::fabs(out[i * feats + f] - want[f]) > 1e-3;
+    }
+    std::printf("  sketch %zu x %zu . %zu x %zu (Rademacher, seed %llx): mismatches %zu\n", proj, rows, rows, feats,
+                static_cast<unsigned long long>(sk_seed), bad_sketch);
+    return (bad_code || bad_gx || bad_y || bad_sketch) ? 1 : 0;
 }

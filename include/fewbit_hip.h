@@ -186,7 +186,7 @@ int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, si
 int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features, size_t proj, char *buf, size_t len);
 /* measurement hooks: force the number of row slices (> 0) / the waves per workgroup (4: 128-row tile, 8: 256-row tile) / the
  * column halves per workgroup (2: the 128 x 512 tile whose wave pairs share their A fragments through LDS, the Gaussian
- * sketch's default from 512 features on); -1 = built-in policy.  Every setting computes the same sums (up to fp32
+ * sketch's default for wide layers in a 16-bit dtype); -1 = built-in policy.  Every setting computes the same sums (up to fp32
  * re-association across slices). */
 int fewbit_hip_sketch_tune_slices(long long slices);
 int fewbit_hip_sketch_tune_waves(long long waves);

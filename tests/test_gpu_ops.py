@@ -513,7 +513,7 @@ def test_randomized_linear_on_gpu(matmul):
 
 def test_torch_free_host_program_on_the_c_abi():
     """examples/cabi_demo.cpp: plain C++ + the HIP runtime + libfewbit_hip.so (no torch, no python) -- forward and
-    backward of one million elements checked on the host by the program itself."""
+    backward of one million elements, and one random-projection product, checked on the host by the program itself."""
     import subprocess
     from helpers import ROOT
     exe = ROOT / 'examples' / 'cabi_demo'
@@ -521,6 +521,7 @@ def test_torch_free_host_program_on_the_c_abi():
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'mismatches: codes 0, gradients 0, forward 0' in out.stdout
+    assert '(Rademacher, seed 123456789abcdef): mismatches 0' in out.stdout      # the random-projection kernel, S rebuilt on the host
 
 
 def test_inference_mode_and_no_grad_run_the_kernels():
