@@ -64,7 +64,6 @@ FEWBIT_HIDDEN int fail(int code, const char *fmt, ...) __attribute__((format(pri
 
 namespace sketch {
 
-constexpr int kWave = 64;
 constexpr int BN = 256;                     // features per tile
 constexpr int NT = BN / 32;                 // MFMA column blocks per wave
 // A workgroup of W waves owns 32*W rows of S and multiplies them with K stages of 16*W rows of M (one 8x8 block per thread):
@@ -400,7 +399,6 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     auto stage = [&](size_t s, auto fast_tag, auto first_tag) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_tag)::value;
         constexpr int first = decltype(first_tag)::value;      // the step whose slots carry the LDS writes (the loads follow one step later)
-        const size_t k0 = k_begin + s * BK;
         SKETCH_STAMP(s, 0);
         uint8_t *cur = lds + (s & 1) * kStageBytes, *nxt = lds + ((s + 1) & 1) * kStageBytes;
         const uint8_t *next_base = stage_base + (s + 2) * stage_bytes;
