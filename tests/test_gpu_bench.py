@@ -125,3 +125,23 @@ def test_strong_scaling_bytes_are_slices_of_the_unsharded_result(gpus):
         sb, se = state_range(b, e, cfg['bits'])
         got = line['per_gpu_sha256'][r]
         assert got['y'] == sha(y[b:e]) and got['gx'] == sha(gx[b:e]) and got['state'] == sha(state[sb:se]), f'rank {r}'
+
+
+def test_the_drivers_torchrun_form_with_two_ranks():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` (the driver's N > 1 command): gloo carries the
+    barrier and the max only; one line from rank 0; --scaling strong --digests there too"""
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1']
+    for port, extra, scaling in (('29531', (), 'weak'), ('29532', ('--scaling', 'strong', '--digests'), 'strong')):
+        r = subprocess.run(base + ['--master-port', port, str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2', *extra],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, r.stdout[-2000:]
+        line = json.loads(lines[0])
+        _check_contract(line, 2, 5, 2, scaling=scaling)
+        assert 'torch.distributed.run' in line['config']['launcher'] and len(line['per_gpu_device']) == 2
+        if scaling == 'strong':
+            assert sum(line['per_gpu_elements']) == 4096 * 4096 and len(line['per_gpu_sha256']) == 2
