@@ -70,6 +70,16 @@ def test_estimator_statistics_on_the_gpu(lref):
             msd += float(((wi.grad - exact)**2).sum())
         assert float(torch.linalg.norm(acc / draws - exact) / torch.linalg.norm(exact)) <= 0.12, kind
         assert abs(msd / draws / float(lref[f'grp_{kind}_msd']) - 1.0) <= 0.12, (kind, msd / draws, float(lref[f'grp_{kind}_msd']))
+    # column-row sampling (LinearCRS) drawn on the device: the reference's mean and mean squared deviation as well
+    nopairs = int(lref['crs_nopairs'])
+    acc, msd = torch.zeros_like(exact), 0.0
+    for _ in range(draws):
+        wi = w.clone().requires_grad_()
+        fewbit.functional.linear_crs(x, wi, b, nopairs).backward(gy)
+        acc += wi.grad
+        msd += float(((wi.grad - exact)**2).sum())
+    assert float(torch.linalg.norm(acc / draws - exact) / torch.linalg.norm(exact)) <= 0.15
+    assert abs(msd / draws / float(lref['crs_msd']) - 1.0) <= 0.15, (msd / draws, float(lref['crs_msd']))
 
 
 # ---- the dense sketches on the package's own kernel (fewbit_amd/csrc/fewbit_sketch.hip) ---------------------------------
