@@ -96,11 +96,11 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 #ifdef FEWBIT_SKETCH_TRACE
 // measurement builds only: shader-clock stamps (s_memtime) of workgroup (0,0,0), per wave and stage: [stage top, MFMAs issued, barrier passed]
-__device__ unsigned long long g_sketch_trace[8 * 512 * 3];
+__device__ unsigned long long g_sketch_trace[8 * 512 * 12];      // slots 0..2 as above, 3 + ks: MFMA step ks begins
 #define SKETCH_STAMP(stage_idx, slot)                                                                                         \
     do {                                                                                                                      \
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (stage_idx) < 512)                          \
-            g_sketch_trace[(static_cast<size_t>(wave) * 512 + (stage_idx)) * 3 + (slot)] = __builtin_readcyclecounter();     \
+            g_sketch_trace[(static_cast<size_t>(wave) * 512 + (stage_idx)) * 12 + (slot)] = __builtin_readcyclecounter();     \
     } while (0)
 #else
 #define SKETCH_STAMP(stage_idx, slot) do { } while (0)
@@ -427,6 +427,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < kSteps; ++ks) {
+            SKETCH_STAMP(s, 3 + ks);
             if constexpr (NH > 1 && FAST) {
                 if (ks == first) {
                     publish_fragments(s + 1, std::false_type{});
