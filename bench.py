@@ -2,7 +2,7 @@
 """bench.py -- forward+backward throughput of the few-bit activation hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4|c4_tensor] [--scaling weak|strong]
-                    [--digests] [--no-extras] [--no-cpu-baseline]
+                    [--digests] [--no-extras] [--no-cpu-baseline] [--no-pmc]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W [--config c4]
 
@@ -44,7 +44,9 @@ metric = algorithmic bytes / time; algorithmic bytes per element = 4*s + k/4 (fw
 bwd: read gy, read state, write gx; s = element size, k = bits) -- SURVEY.md 8(d).
 
 Besides the contract fields the line carries (N = 1, unless --no-extras):
-  roofline   dominant kernel (name from fewbit_hip_describe_*), its algorithmic GB/s against the 8 TB/s HBM peak
+  roofline   dominant kernel (name from fewbit_hip_describe_*), its algorithmic GB/s against the 8 TB/s HBM peak; `traffic` =
+             HBM bytes per launch from two rocprofv3 --pmc child runs of this very command (measure_traffic; --no-pmc skips them
+             and the figure recorded under profiles/ is replayed, labelled so)
   cold       the same workload rotating through > 1 GiB of independent buffer sets (Infinity Cache out of the picture)
   configs    every other BASELINE config on one GPU, warm and cold, with kernel names and its own cpu_baseline
   op_level   clone + torch.ops.fewbit.gelu + autograd.grad at this size beside torch.nn.functional.gelu
@@ -691,6 +693,52 @@ def build_line(args, world, res, per_rank=None, launcher='single process'):
     return line
 
 
+def under_profiler():
+    e = os.environ
+    return any(k.startswith(('ROCPROF', 'ROCPROFILER_', 'ROCP_')) for k in e) or 'rocprofiler' in e.get('LD_PRELOAD', '')
+
+
+def measure_traffic(args, algorithmic, steps=50):
+    """HBM bytes per launch of the forward (dominant) kernel from the PMC counters, measured by THIS run: two child processes,
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` (separate passes, nothing else traced), each
+    over `bench.py --no-extras --no-cpu-baseline` of the same config; per-dispatch counter rows of the forward kernel averaged;
+    gfx950 correction of MI355X_MICROARCH.md's HBM section: FETCH_SIZE (KiB) counts half of a wide coalesced read -> doubled,
+    WRITE_SIZE (KiB) as is.  The same passes run from tools/profile_round.sh are kept under profiles/ as the cross-check."""
+    import csv
+    tool = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(tool):
+        raise RuntimeError('rocprofv3 not found')
+    if under_profiler():
+        raise RuntimeError('already running under a profiler')
+    means, counts = {}, {}
+    with tempfile.TemporaryDirectory(prefix='fewbit_pmc_', dir='/tmp') as tmp:
+        for name in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, name)
+            cmd = [tool, '--pmc', name, '--kernel-trace', '--output-format', 'csv', '-d', out, '-o', 'pmc', '--',
+                   sys.executable, str(Path(__file__).resolve()), '--config', args.config, '--steps', str(steps), '--warmup', '5',
+                   '--no-extras', '--no-cpu-baseline']
+            env = dict(os.environ, TMPDIR='/tmp')
+            run = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=240)
+            if run.returncode != 0:
+                raise RuntimeError(f'rocprofv3 --pmc {name} rc={run.returncode}: {run.stderr[-200:]}')
+            vals = []
+            for f in Path(out).rglob('*counter_collection.csv'):
+                with open(f, newline='') as fh:
+                    for row in csv.DictReader(fh):
+                        if row['Counter_Name'] == name and 'fewbit_hip::' in row['Kernel_Name'] and 'forward' in row['Kernel_Name']:
+                            vals.append(float(row['Counter_Value']))
+            if not vals:
+                raise RuntimeError(f'no {name} rows for the forward kernel')
+            means[name], counts[name] = sum(vals) / len(vals), len(vals)
+    fetch, write = int(round(means['FETCH_SIZE'] * 1024 * 2)), int(round(means['WRITE_SIZE'] * 1024))
+    return {'hbm_bytes_per_launch': fetch + write, 'fetch_bytes_corrected': fetch, 'write_bytes': write,
+            'FETCH_SIZE_KiB_raw': round(means['FETCH_SIZE'], 1), 'WRITE_SIZE_KiB': round(means['WRITE_SIZE'], 1),
+            'dispatches': counts['FETCH_SIZE'], 'over_algorithmic': round((fetch + write) / algorithmic, 4),
+            'source': 'measured by this run: rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (two child '
+                      f'processes) over `bench.py --config {args.config} --steps {steps} --warmup 5 --no-extras --no-cpu-baseline`; FETCH_SIZE x2 '
+                      '(gfx950), KiB units; per launch of the forward kernel'}
+
+
 def _guarded(what, fn):
     """The extras never take the contract's line down with them: a failure is recorded in place of the result."""
     try:
@@ -741,6 +789,12 @@ def add_extras(line, args, device):
         line['configs'] = {name: _guarded(f'configs.{name}', lambda name=name, c=c: _other_config(name, c, args, device))
                            for name, c in CONFIGS.items() if name not in (args.config, 'c4_tensor')}
         line['sketch'] = _guarded('sketch', lambda: measure_sketch(device))
+        if not args.no_pmc:
+            live = _guarded('pmc_traffic', lambda: measure_traffic(args, fb))
+            line['roofline']['traffic_live'] = live
+            if 'error' not in live:                      # this run's own counters replace the recorded figure
+                line['roofline']['traffic_recorded'] = line['roofline']['traffic']
+                line['roofline']['traffic'], line['roofline']['traffic_source'] = live['hbm_bytes_per_launch'], live['source']
     if not args.no_cpu_baseline:
         reps_all, reps_one = CPU_SAMPLES[args.config]
         line['cpu_baseline'] = _guarded('cpu_baseline', lambda: cpu_baseline(args.config, cfg, reps_all))
@@ -824,6 +878,7 @@ def main():
                          'steps): MI355X drops its clocks 1.5-10 ms after load begins and recovers by ~15 ms (scratch/timeline.py)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='timed region only (what the rocprofv3 passes run)')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child runs behind roofline.traffic')
     ap.add_argument('--worker-rank', type=int, default=None, help=argparse.SUPPRESS)     # set by parent_launch
     ap.add_argument('--sync-dir', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--launch-timeout', type=float, default=900.0, help=argparse.SUPPRESS)

@@ -60,6 +60,27 @@ def test_single_gpu_line():
     assert 'shared_gpu' not in line
 
 
+def test_pmc_traffic_is_measured_by_the_run_itself():
+    """roofline.traffic: two rocprofv3 --pmc child runs of bench.py's own timed command (FETCH_SIZE x2 + WRITE_SIZE, KiB)."""
+    import argparse
+    import importlib.util
+    import shutil
+    if not (shutil.which('rocprofv3') or os.path.exists('/opt/rocm/bin/rocprofv3')):
+        pytest.skip('rocprofv3 not on this box')
+    spec = importlib.util.spec_from_file_location('bench_module', ROOT / 'bench.py')
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    if bench.under_profiler():
+        pytest.skip('the test-suite itself runs under a profiler')
+    algorithmic = bench.step_bytes(bench.CONFIGS['c2'])[1]
+    assert algorithmic == 4096 * 4096 * (2 * 2 + 3 / 8)
+    got = bench.measure_traffic(argparse.Namespace(config='c2'), algorithmic, steps=10)
+    assert got['dispatches'] >= 10
+    # nothing re-read, nothing written twice: x is served from the Infinity Cache or HBM (both counted at the fabric), y + state written once
+    assert 0.98 <= got['over_algorithmic'] <= 1.03, got
+    assert got['write_bytes'] >= 4096 * 4096 * (2 + 3 / 8)
+
+
 def test_self_launched_ranks_line():
     line = _bench('--gpus', '2', '--steps', '5', '--warmup', '2')
     _check_contract(line, 2, 5, 2)
