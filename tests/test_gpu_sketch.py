@@ -116,6 +116,47 @@ def test_empty_and_degenerate_shapes():
         cabi.sketch('rademacher', torch.ones(8, 16, device=DEV).t(), 4, 1)          # features not contiguous
 
 
+@pytest.mark.parametrize('dist', ('rademacher', 'gaussian'))
+@pytest.mark.parametrize('dtype,rows,features,ld', ((torch.bfloat16, 2**21 + 5, 1032, 1040), (torch.float32, 2**20 + 77, 1100, 1100)))
+def test_inputs_beyond_four_gib_against_the_materialised_matrix(dist, dtype, rows, features, ld):
+    """Byte offsets past 2^32 (4.4 GB bf16 with a row stride, 4.6 GB fp32): the product against S itself (fewbit_hip_sketch_matrix,
+    the same entries rounded the same way) times m in fp64, in row chunks.  fp32 accumulation over 2^21 rows: the error of a
+    sum is a random walk of roundings, bounded here by 2^-24 x sqrt(rows) x 16 relative to sum |s||m|."""
+    es = torch.empty(0, dtype=dtype).element_size()
+    assert rows * ld * es > 2**32
+    proj, seed = 48, 0xfeedbeefcafe
+    g = torch.Generator(device=DEV).manual_seed(5)
+    m = torch.randn(rows, ld, generator=g, device=DEV, dtype=torch.float32).to(dtype)[:, :features]
+    got = cabi.sketch(dist, m, proj, seed)
+    op = torch.float16 if dtype == torch.float16 else torch.bfloat16
+    want = torch.zeros(proj, features, dtype=torch.float64, device=DEV)
+    bound = torch.zeros_like(want)
+    step = 2**18
+    for r0 in range(0, rows, step):
+        n = min(step, rows - r0)
+        S = cabi.sketch_matrix(dist, dtype, seed, proj, n, 0, r0).double()
+        mm = m[r0:r0 + n].to(op).double()
+        want += S @ mm
+        bound += S.abs() @ mm.abs()
+    err = (got.double() - want).abs()
+    out_eps = 2.0**-22 if dtype == torch.float32 else 2.0**-7
+    assert bool((err <= out_eps * want.abs() + 2.0**-24 * rows**0.5 * 16 * bound).all()), float((err / bound).max())
+    assert float(want.abs().mean()) > 100.0                                 # (a sum over 2^21 rows, not a field of zeros)
+    # the far end of the buffer matters: zero the last rows and the result moves by exactly their contribution
+    tail = 300
+    m2 = m.clone()
+    m2[rows - tail:] = 0
+    S = cabi.sketch_matrix(dist, dtype, seed, proj, tail, 0, rows - tail).double()
+    moved = (got.double() - cabi.sketch(dist, m2, proj, seed).double())
+    assert torch.allclose(moved, S @ m[rows - tail:].to(op).double(), rtol=0, atol=float(want.abs().max()) * 2 * out_eps + 1e-2)
+
+
+def test_unsupported_sizes_are_refused_not_wrapped():
+    wide = torch.zeros(8, 8 * 2**20, dtype=torch.bfloat16, device=DEV)      # a K stage of this row stride spans > 2 GiB
+    with pytest.raises(cabi.FewbitHipError, match='leading dimension'):
+        cabi.sketch('rademacher', wide[:, :64], 4, 1)
+
+
 def test_estimator_is_unbiased_on_the_gpu_kernel():
     """E[(S G)^T (S X)] / proj = G^T X: mean over seeds of the kernel's own products converges to the exact product"""
     g = torch.Generator().manual_seed(0)

@@ -126,6 +126,7 @@ def main():
     ap.add_argument('--route', default='module', choices=('module', 'op', 'both'), help='see the module docstring')
     ap.add_argument('--table', action='store_true',
                     help="the four rows of the reference README's table: GELU {vanilla, 3-bit} x linear {vanilla, randomized}")
+    ap.add_argument('--row', type=int, default=None, choices=(0, 1, 2, 3), help='with --table: run only this row (profiling)')
     ap.add_argument('--linear-ratio', type=float, default=0.2, help='proj_dim_ratio of the randomized linear layers')
     ap.add_argument('--sketch-bf16', action='store_true', help='run the sketch GEMMs of fp32 layers in bf16')
     ap.add_argument('--matmul', default='gaussian', choices=('gaussian', 'rademacher'), help='kind of dense sketch of the randomized layers')
@@ -144,7 +145,9 @@ def main():
         fewbit_amd.linear.use_native_sketch(False)
     if args.table:
         rows = []
-        for gelu, linear in ((False, False), (True, False), (False, True), (True, True)):
+        for i, (gelu, linear) in enumerate(((False, False), (True, False), (False, True), (True, True))):
+            if args.row is not None and i != args.row:
+                continue
             model = build(dtype, dev)
             ng = swap_gelu(model, args.bits) if gelu else 0
             nl = swap_linear(model, args.linear_ratio, torch.bfloat16 if args.sketch_bf16 else None, args.matmul) if linear else 0
