@@ -15,7 +15,7 @@ __all__ = [
     'quantize_backward', 'bind_forward', 'bind_backward', 'bind_stepwise1_forward', 'bind_stepwise1_backward',
     'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError', 'describe_forward',
     'describe_backward', 'describe_stepwise1_forward', 'describe_stepwise1_backward', 'tune',
-    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves', 'tune_sketch_halves',
+    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'next_sketch_seed', 'mix_sketch_seed', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves', 'tune_sketch_halves',
     'philox4x32',
 ]
 
@@ -30,7 +30,7 @@ CONTINUOUS = ('celu', 'elu', 'gelu', 'hardswish', 'logsigmoid', 'mish', 'selu', 
 STEPWISE1 = ('hardshrink', 'hardsigmoid', 'hardtanh', 'leaky_relu', 'relu', 'relu6', 'softshrink', 'threshold')
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 SKETCH_DISTS = ('rademacher', 'gaussian')      # enum fewbit_sketch_dist
-ABI_VERSION = 2                                # FEWBIT_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 3                                # FEWBIT_HIP_ABI_VERSION this binding was written against
 
 # every symbol include/fewbit_hip.h declares
 SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwidth', 'fewbit_hip_state_nbytes',
@@ -38,7 +38,8 @@ SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwid
            'fewbit_hip_stepwise1_backward', 'fewbit_hip_pack_codes', 'fewbit_hip_unpack_codes',
            'fewbit_hip_describe_quantize_forward', 'fewbit_hip_describe_quantize_backward',
            'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune',
-           'fewbit_hip_sketch_workspace', 'fewbit_hip_sketch', 'fewbit_hip_sketch_matrix', 'fewbit_hip_sketch_describe',
+           'fewbit_hip_sketch_workspace', 'fewbit_hip_sketch', 'fewbit_hip_sketch_device_seed', 'fewbit_hip_sketch_next_seed',
+           'fewbit_hip_sketch_mix_seed', 'fewbit_hip_sketch_matrix', 'fewbit_hip_sketch_describe',
            'fewbit_hip_sketch_tune_slices', 'fewbit_hip_sketch_tune_waves', 'fewbit_hip_sketch_tune_halves', 'fewbit_hip_philox4x32')
 
 
@@ -97,6 +98,12 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_sketch_workspace.argtypes = [i32, i32, sz, sz, sz]
         L.fewbit_hip_sketch.restype = i32
         L.fewbit_hip_sketch.argtypes = [i32, i32, vp, sz, sz, sz, sz, u64, dbl, vp, vp, sz, vp]
+        L.fewbit_hip_sketch_device_seed.restype = i32
+        L.fewbit_hip_sketch_device_seed.argtypes = [i32, i32, vp, sz, sz, sz, sz, vp, dbl, vp, vp, sz, vp]
+        L.fewbit_hip_sketch_next_seed.restype = i32
+        L.fewbit_hip_sketch_next_seed.argtypes = [vp, u64, vp, vp]
+        L.fewbit_hip_sketch_mix_seed.restype = u64
+        L.fewbit_hip_sketch_mix_seed.argtypes = [u64, u64]
         L.fewbit_hip_sketch_matrix.restype = i32
         L.fewbit_hip_sketch_matrix.argtypes = [i32, i32, u64, sz, sz, sz, sz, vp, vp]
         L.fewbit_hip_sketch_describe.restype = i32
@@ -364,10 +371,11 @@ def sketch_workspace_bytes(dist: str, rows: int, features: int, proj: int, dtype
     return lib().fewbit_hip_sketch_workspace(SKETCH_DISTS.index(dist), DTYPES[dtype], rows, features, proj)
 
 
-def sketch(dist: str, m: torch.Tensor, proj: int, seed: int, scale: float = 1.0, out: Optional[torch.Tensor] = None,
+def sketch(dist: str, m: torch.Tensor, proj: int, seed, scale: float = 1.0, out: Optional[torch.Tensor] = None,
            workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
     """``scale * S @ m`` for the ``proj x rows`` random matrix S(seed) of kind ``dist`` ('rademacher' / 'gaussian'), which is
-    never materialised.  ``m``: 2-D, rows x features, unit stride along the features (any row stride)."""
+    never materialised.  ``m``: 2-D, rows x features, unit stride along the features (any row stride).  ``seed``: an int, or a
+    one-element int64 tensor on the device of ``m`` whose value is read when the kernel runs (``next_sketch_seed``)."""
     if m.device.type != 'cuda':
         raise FewbitHipError(f'm must live on the GPU (got {m.device})')
     if m.dim() != 2 or (m.shape[1] > 1 and m.stride(1) != 1):
@@ -385,12 +393,40 @@ def sketch(dist: str, m: torch.Tensor, proj: int, seed: int, scale: float = 1.0,
         if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
             workspace = torch.empty(need, dtype=torch.uint8, device=m.device)
         _same_device(m, out, *(() if workspace is None else (workspace, )))
-        _check(lib().fewbit_hip_sketch(SKETCH_DISTS.index(dist), DTYPES[m.dtype], m.data_ptr(), rows, features, ld, proj,
-                                       seed & 0xffffffffffffffff, scale, out.data_ptr(),
-                                       0 if workspace is None else workspace.data_ptr(),
-                                       0 if workspace is None else workspace.numel() * workspace.element_size(),
-                                       _stream(stream, m.device)))
+        tail = (scale, out.data_ptr(), 0 if workspace is None else workspace.data_ptr(),
+                0 if workspace is None else workspace.numel() * workspace.element_size(), _stream(stream, m.device))
+        if isinstance(seed, torch.Tensor):
+            _seed_word(seed, 'seed')
+            _same_device(m, seed)
+            _check(lib().fewbit_hip_sketch_device_seed(SKETCH_DISTS.index(dist), DTYPES[m.dtype], m.data_ptr(), rows, features, ld,
+                                                       proj, seed.data_ptr(), *tail))
+        else:
+            _check(lib().fewbit_hip_sketch(SKETCH_DISTS.index(dist), DTYPES[m.dtype], m.data_ptr(), rows, features, ld, proj,
+                                           seed & 0xffffffffffffffff, *tail))
     return out
+
+
+def _seed_word(t: torch.Tensor, what: str) -> None:
+    if t.device.type != 'cuda' or t.dtype != torch.int64 or t.numel() != 1:
+        raise FewbitHipError(f'{what} must be a one-element int64 tensor on the GPU')
+
+
+def next_sketch_seed(counter: torch.Tensor, base: int, out: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    """On the device, in stream order: ``out = mix_sketch_seed(base, counter); counter += 1``.  Recorded into a hipGraph this
+    gives every replay (and every call inside it) its own seed; pass ``out`` to ``sketch`` as the seed."""
+    _seed_word(counter, 'counter')
+    with _on(counter.device):
+        if out is None:
+            out = torch.empty(1, dtype=torch.int64, device=counter.device)
+        _seed_word(out, 'out')
+        _same_device(counter, out)
+        _check(lib().fewbit_hip_sketch_next_seed(counter.data_ptr(), base & 0xffffffffffffffff, out.data_ptr(), _stream(stream, counter.device)))
+    return out
+
+
+def mix_sketch_seed(base: int, count: int) -> int:
+    """host evaluation of the seed ``next_sketch_seed`` leaves for counter value ``count``"""
+    return int(lib().fewbit_hip_sketch_mix_seed(base & 0xffffffffffffffff, count & 0xffffffffffffffff))
 
 
 def sketch_matrix(dist: str, dtype: torch.dtype, seed: int, nrows: int, ncols: int, row0: int = 0, col0: int = 0,

@@ -297,8 +297,10 @@ template <int PITCH> __device__ __forceinline__ void store_block(const Block8x8 
 // `out` + z * proj * features (no scale); otherwise the scaled result in the dtype of M.
 template <int DIST, int DT, bool PARTIAL, bool RAGGED, int W, int NH>
 __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restrict__ m, size_t rows, size_t features, size_t ld, size_t proj,
-                                                           Key key, float scale, void *__restrict__ out, size_t kslice) {
+                                                           Key key, const Key *__restrict__ key_dev, float scale, void *__restrict__ out,
+                                                           size_t kslice) {
     typedef Tile<W, NH> T_;
+    if (key_dev != nullptr) key = *key_dev;          // the seed of a call inside a hipGraph lives in device memory (one scalar load)
     constexpr int BM = T_::BM, BK = T_::BK, BNT = T_::BNT, RG = T_::RG, kStageBytes = T_::kStageBytes, kSteps = T_::kSteps;
     constexpr int kPerBlock = T_::kStagesPerBlock, kABytes = T_::kABytes;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];        // 2 * kStageBytes of M, then 2 * kABytes of A fragments
@@ -553,8 +555,27 @@ template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(
     out[idx] = v;
 }
 
+// ---- seeds drawn on the device ----------------------------------------------------------------------------------------------
+// A launch recorded in a hipGraph replays its kernel ARGUMENTS: a seed passed by value would give every replay the same S.
+// There the seed comes from device memory instead: `next_seed_kernel` (also recorded) bumps a counter and derives the seed of
+// this call from it, so every replay -- and every call inside one replay -- draws a fresh matrix; the backward of the layer
+// reads the seed its forward left behind.  mix_seed = splitmix64's finaliser over base + (count + 1) * golden ratio.
+__host__ __device__ __forceinline__ uint64_t mix_seed(uint64_t base, uint64_t count) {
+    uint64_t x = base + (count + 1) * 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void next_seed_kernel(uint64_t *counter, uint64_t base, uint64_t *seed) {
+    const uint64_t count = *counter;
+    *counter = count + 1;
+    *seed = mix_seed(base, count);
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------------
 struct Plan { unsigned gx, gy, gz; size_t kslice; int waves, halves; };
+struct Seed { Key value; const Key *device; };       // `device` != nullptr: the key is read from there when the kernel runs
 
 int device_cus() {
     static std::atomic<int> cached[64];
@@ -641,7 +662,7 @@ Plan make_plan(int dist, int dtype, size_t rows, size_t features, size_t proj) {
 }
 
 template <int DIST, int DT, bool PARTIAL, int W, int NH = 1>
-int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Key key, float scale, void *out,
+int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out,
                   hipStream_t s) {
     const dim3 grid(p.gx, p.gy, p.gz), block(Tile<W, NH>::kThreads);
     constexpr size_t lds = Tile<W, NH>::kLdsBytes;
@@ -659,14 +680,14 @@ int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t
                 done.fetch_or(bit, std::memory_order_relaxed);
             }
         }
-        hipLaunchKernelGGL(kern, grid, block, lds, s, m, rows, features, ld, proj, key, scale, out, p.kslice);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, m, rows, features, ld, proj, key.value, key.device, scale, out, p.kslice);
         return FEWBIT_OK;
     };
     return ragged ? go(sketch_kernel<DIST, DT, PARTIAL, true, W, NH>) : go(sketch_kernel<DIST, DT, PARTIAL, false, W, NH>);
 }
 
 template <int DIST, int DT>
-int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, Key key, float scale, void *out, void *workspace,
+int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out, void *workspace,
            size_t workspace_bytes, hipStream_t s) {
     const Plan p = make_plan(DIST, DT, rows, features, proj);
     const bool ragged = (features % 8) != 0;
@@ -694,7 +715,7 @@ int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, 
 }
 
 template <int DIST>
-int launch_dtype(int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Key key, float scale, void *out,
+int launch_dtype(int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out,
                  void *workspace, size_t workspace_bytes, hipStream_t s) {
     switch (dtype) {
     case FEWBIT_F32: return launch<DIST, FEWBIT_F32>(m, rows, features, ld, proj, key, scale, out, workspace, workspace_bytes, s);
@@ -718,15 +739,14 @@ size_t fewbit_hip_sketch_workspace(int dist, int dtype, size_t rows, size_t feat
     return p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : 0;
 }
 
-int fewbit_hip_sketch(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, uint64_t seed, double scale,
-                      void *out, void *workspace, size_t workspace_bytes, void *stream) {
+static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, double scale,
+                        void *out, void *workspace, size_t workspace_bytes, void *stream) {
     if (dist != FEWBIT_SKETCH_RADEMACHER && dist != FEWBIT_SKETCH_GAUSSIAN) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: unknown distribution %d", dist);
     if (proj == 0 || features == 0) return FEWBIT_OK;
     if (out == nullptr || (m == nullptr && rows != 0)) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: null pointer");
     if (ld < features) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: leading dimension %zu < features %zu", ld, features);
     if (proj > 0xffffffffull || (rows >> 3) > 0xffffffffull) return fail(FEWBIT_ERR_UNSUPPORTED, "sketch: proj and rows/8 must fit 32 bits");
     if ((ld + 1) * 72 * 4 >= 0x80000000ull) return fail(FEWBIT_ERR_UNSUPPORTED, "sketch: leading dimension %zu too large (a K stage must span less than 2 GiB)", ld);
-    const Key key{static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (rows == 0) {                                  // empty sum: zeros
         const size_t es = dtype == FEWBIT_F32 ? 4 : 2;
@@ -736,6 +756,30 @@ int fewbit_hip_sketch(int dist, int dtype, const void *m, size_t rows, size_t fe
     if (dist == FEWBIT_SKETCH_RADEMACHER)
         return launch_dtype<FEWBIT_SKETCH_RADEMACHER>(dtype, m, rows, features, ld, proj, key, static_cast<float>(scale), out, workspace, workspace_bytes, s);
     return launch_dtype<FEWBIT_SKETCH_GAUSSIAN>(dtype, m, rows, features, ld, proj, key, static_cast<float>(scale), out, workspace, workspace_bytes, s);
+}
+
+int fewbit_hip_sketch(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, uint64_t seed, double scale,
+                      void *out, void *workspace, size_t workspace_bytes, void *stream) {
+    const Seed key{Key{static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)}, nullptr};
+    return sketch_entry(dist, dtype, m, rows, features, ld, proj, key, scale, out, workspace, workspace_bytes, stream);
+}
+
+int fewbit_hip_sketch_device_seed(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj,
+                                  const uint64_t *seed_device, double scale, void *out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (seed_device == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: null seed pointer");
+    static_assert(sizeof(Key) == sizeof(uint64_t), "a Key is the two halves of the 64-bit seed, low word first");
+    const Seed key{Key{0u, 0u}, reinterpret_cast<const Key *>(seed_device)};
+    return sketch_entry(dist, dtype, m, rows, features, ld, proj, key, scale, out, workspace, workspace_bytes, stream);
+}
+
+uint64_t fewbit_hip_sketch_mix_seed(uint64_t base, uint64_t count) { return mix_seed(base, count); }
+
+int fewbit_hip_sketch_next_seed(uint64_t *counter_device, uint64_t base, uint64_t *seed_device, void *stream) {
+    if (counter_device == nullptr || seed_device == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch_next_seed: null pointer");
+    hipLaunchKernelGGL(next_seed_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), counter_device, base, seed_device);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sketch_next_seed: %s", hipGetErrorString(e));
+    return FEWBIT_OK;
 }
 
 int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, size_t col0, size_t nrows, size_t ncols, float *out, void *stream) {

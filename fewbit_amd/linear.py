@@ -125,7 +125,35 @@ def _draw_seed(generator: Optional[torch.Generator]) -> int:
     return _mix64(generator.initial_seed(), offset)
 
 
-def _native_sketch(kind: str, mat: torch.Tensor, p: int, seed: int, scale: float) -> torch.Tensor:
+_REPLAY_COUNTERS = {}
+
+
+def _replay_counter(device: torch.device) -> torch.Tensor:
+    """One int64 word per device that the recorded seed kernels advance.  It must exist BEFORE a capture starts (a tensor
+    allocated while capturing belongs to the graph's pool and its zero-fill would be replayed too): every eager call of the
+    native path makes sure it does, so the customary warm-up run before `torch.cuda.graph(...)` is enough."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    counter = _REPLAY_COUNTERS.get(key)
+    if counter is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('fewbit.linear_grp: run the layer once on this device before capturing it into a graph '
+                               '(the per-device replay counter of the sketch seeds cannot be created during capture)')
+        counter = _REPLAY_COUNTERS[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    return counter
+
+
+def _sketch_seed(generator: Optional[torch.Generator], device: torch.device):
+    """Seed of one sketch: an int drawn on the host -- or, while the stream is being captured into a hipGraph, a device word
+    that a recorded kernel re-derives from (a host draw made at capture time, the replay counter) on every replay, so that a
+    replayed training step meets a fresh S each time instead of the one matrix whose seed was recorded."""
+    counter = _replay_counter(device)
+    if not torch.cuda.is_current_stream_capturing():
+        return _draw_seed(generator)
+    from . import cabi
+    return cabi.next_sketch_seed(counter, _draw_seed(generator))
+
+
+def _native_sketch(kind: str, mat: torch.Tensor, p: int, seed, scale: float) -> torch.Tensor:
     from . import cabi
     if mat.stride(1) != 1 or mat.stride(0) < mat.shape[1]:      # (e.g. the expanded gradient of a sum: strides (0, 0))
         mat = mat.contiguous()
@@ -191,7 +219,7 @@ class _LinearGRP(torch.autograd.Function):
         ctx.native_seed = None
         if _native_sketch_applies(kind, flat, sketch_dtype):
             # S lives nowhere: the projection and the seed are all that is kept
-            ctx.native_seed = _draw_seed(generator)
+            ctx.native_seed = _sketch_seed(generator, flat.device)
             sketch = _native_sketch(kind, flat.detach(), p, ctx.native_seed, 1.0 / p)
             ctx.save_for_backward(sketch, weight)
             ctx.p, ctx.kind = p, kind

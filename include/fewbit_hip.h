@@ -53,8 +53,9 @@ extern "C" {
 #endif
 
 /* 1: the quantized-activation path.  2: + fewbit_hip_describe_*, fewbit_hip_tune (added in round 3 without a bump) and the
- * random-projection entry points fewbit_hip_sketch* (round 4).  Bindings check it and refuse an older library by name. */
-#define FEWBIT_HIP_ABI_VERSION 2
+ * random-projection entry points fewbit_hip_sketch* (round 4).  3: + seeds in device memory (fewbit_hip_sketch_device_seed,
+ * fewbit_hip_sketch_next_seed, fewbit_hip_sketch_mix_seed).  Bindings check it and refuse an older library by name. */
+#define FEWBIT_HIP_ABI_VERSION 3
 
 typedef enum fewbit_status {
     FEWBIT_OK = 0,
@@ -178,6 +179,18 @@ typedef enum fewbit_sketch_dist { FEWBIT_SKETCH_RADEMACHER = 0, FEWBIT_SKETCH_GA
 size_t fewbit_hip_sketch_workspace(int dist, int dtype, size_t rows, size_t features, size_t proj);
 int fewbit_hip_sketch(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, uint64_t seed,
                       double scale, void *out, void *workspace, size_t workspace_bytes, void *stream);
+/* The same product with the seed read from DEVICE memory when the kernel runs.  A launch recorded in a hipGraph replays its
+ * arguments, so a seed passed by value would give every replay the same S (the reference cannot be captured at all: it reads
+ * the generator state back, fewbit/functional/linear.py:105); here the recorded pair
+ *     fewbit_hip_sketch_next_seed(counter, base, seed)      *seed = fewbit_hip_sketch_mix_seed(base, (*counter)++)
+ *     fewbit_hip_sketch_device_seed(..., seed, ...)
+ * draws a fresh matrix on every replay, and the layer's backward re-reads the `seed` word its forward left behind.
+ * `counter`, `seed_device`: 8-byte aligned device words owned by the caller. */
+int fewbit_hip_sketch_device_seed(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj,
+                                  const uint64_t *seed_device, double scale, void *out, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+int fewbit_hip_sketch_next_seed(uint64_t *counter_device, uint64_t base, uint64_t *seed_device, void *stream);
+uint64_t fewbit_hip_sketch_mix_seed(uint64_t base, uint64_t count);    /* host evaluation of the same function */
 /* S[row0 .. row0+nrows) x [col0 .. col0+ncols) itself as fp32 (rounded as the product kernel rounds its operand for
  * `dtype`) -- test seam and debugging aid; the product path never materialises S */
 int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, size_t col0, size_t nrows, size_t ncols, float *out,

@@ -237,3 +237,68 @@ def test_sketch_and_randomized_layer_capture_into_a_hip_graph():
     exact = torch.ones(512, 32, device=DEV).T @ x.detach()
     assert gw.shape == exact.shape and float(torch.linalg.norm(gw - exact) / torch.linalg.norm(exact)) < 4.0     # one draw: ~sqrt(rows/p) = 2
     assert float(gw.abs().max()) > 0
+
+
+def _splitmix(base, count):
+    M = 2**64 - 1
+    x = (base + (count + 1) * 0x9E3779B97F4A7C15) & M
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+    return x ^ (x >> 31)
+
+
+def test_seed_in_device_memory_is_the_same_sketch_as_the_seed_by_value():
+    counter = torch.tensor([41], dtype=torch.int64, device=DEV)
+    base = 0xfedcba9876543210
+    word = cabi.next_sketch_seed(counter, base)
+    assert int(counter) == 42
+    seed = int(word) & (2**64 - 1)
+    assert seed == cabi.mix_sketch_seed(base, 41) == _splitmix(base, 41)
+    assert cabi.mix_sketch_seed(0, 0) == _splitmix(0, 0) and cabi.mix_sketch_seed(2**64 - 1, 2**64 - 1) == _splitmix(2**64 - 1, 2**64 - 1)
+    for dist, dtype, shape, proj in (('rademacher', torch.bfloat16, (3000, 520), 300), ('gaussian', torch.float16, (1111, 1024), 129),
+                                     ('gaussian', torch.float32, (4096, 264), 64), ('rademacher', torch.float32, (9000, 768), 700)):
+        m = torch.randn(*shape, device=DEV).to(dtype)
+        assert torch.equal(cabi.sketch(dist, m, proj, word, 0.5), cabi.sketch(dist, m, proj, seed, 0.5)), (dist, dtype)
+    with pytest.raises(cabi.FewbitHipError):
+        cabi.sketch('rademacher', torch.ones(16, 8, device=DEV), 4, torch.zeros(1, dtype=torch.int64))            # a host word
+    with pytest.raises(cabi.FewbitHipError):
+        cabi.sketch('rademacher', torch.ones(16, 8, device=DEV), 4, torch.zeros(2, dtype=torch.int64, device=DEV))
+
+
+@pytest.mark.parametrize('kind', ('rademacher', 'gaussian'))
+def test_every_replay_of_a_captured_layer_step_draws_a_fresh_sketch(kind, monkeypatch):
+    """A seed recorded by value would replay ONE matrix for ever; the recorded seed kernel derives it from (the host draw made
+    at capture time, a device counter the replays advance): replay r of the graph equals the eager product with seed
+    mix(base, c0 + r), the backward inside the same replay meets the forward's matrix, and the replays differ."""
+    import fewbit
+    from fewbit_amd import linear
+    lin = fewbit.RandomizedLinear(64, 32, proj_dim=96, matmul=kind, bias=False, device=DEV)
+    x = torch.randn(512, 64, device=DEV, requires_grad=True)
+    wgt = torch.randn(512, 32, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                          # the warm-up every capture needs (creates the replay counter too)
+        torch.autograd.grad((lin(x) * wgt).sum(), lin.weight)
+    torch.cuda.current_stream().wait_stream(side)
+    base = 0x1234567
+    monkeypatch.setattr(linear, '_draw_seed', lambda generator: base)
+    counter = linear._replay_counter(torch.device(DEV))
+    c0 = int(counter)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gw, = torch.autograd.grad((lin(x) * wgt).sum(), lin.weight)
+    assert int(counter) == c0                              # recording runs nothing
+    seen = []
+    for r in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(counter) == c0 + r + 1
+        seed = cabi.mix_sketch_seed(base, c0 + r)
+        want = cabi.sketch(kind, wgt, 96, seed).T @ cabi.sketch(kind, x.detach(), 96, seed, 1.0 / 96)
+        assert torch.allclose(gw, want, rtol=1e-4, atol=1e-3), (kind, r, float((gw - want).abs().max()))
+        seen.append(gw.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    # outside a capture nothing changes: the seed is a host draw passed by value, the counter stays where it is
+    gw2, = torch.autograd.grad((lin(x) * wgt).sum(), lin.weight)
+    want = cabi.sketch(kind, wgt, 96, base).T @ cabi.sketch(kind, x.detach(), 96, base, 1.0 / 96)
+    assert torch.allclose(gw2, want, rtol=1e-4, atol=1e-3) and int(counter) == c0 + 3
