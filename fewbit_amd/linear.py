@@ -29,7 +29,11 @@ constructor / call signatures; the implementation is this repository's own:
   way into the matrix pipe (accumulation is fp32): a zero-mean relative perturbation of 2^-9 per element under an estimator
   whose own relative noise is ~ sqrt(rows / p).  ``use_native_sketch(False)`` (or ``FEWBIT_SKETCH_NATIVE=0``) selects
   the PyTorch formulation (randn / randint + matmul) instead; host tensors, float64 and the sampled transforms always
-  take it.
+  take it;
+* the native path can be captured into a hipGraph (``torch.cuda.graph``) after one eager warm-up call per device: while
+  the stream is capturing, the seed is a device word that a recorded one-thread kernel re-derives on every replay
+  (``_sketch_seed``), so a replayed training step draws a fresh ``S`` each time -- a seed recorded by value would repeat
+  one matrix for ever.  (The reference reads the generator state back in forward and cannot be captured.)
 
 The sampled transforms ('dct', 'dft') are PyTorch-level code (FFT-bound).  SURVEY section 8f, row 4.
 """
