@@ -530,6 +530,47 @@ template <int DT> __global__ __launch_bounds__(256) void sketch_reduce_kernel(co
     else static_cast<__bf16 *>(out)[i] = static_cast<__bf16>(s);
 }
 
+// the same sums four elements per thread (n % 4 == 0): the loads of up to 8 slices are issued before the first add, so a thread
+// has 8 x 16 bytes in flight instead of one dependent 4-byte load per slice (16384 x 768 bf16, p = 3276, 6 slices, rocprofv3: 15.2 -> 10.5 us)
+template <int DT> __global__ __launch_bounds__(256) void sketch_reduce4_kernel(const float *__restrict__ ws, size_t n4, int slices, float scale, void *__restrict__ out) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(ws) + i;
+    f32x4 s = src[0];
+    int z = 1;
+    for (; z + 8 <= slices; z += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[static_cast<size_t>(z + k) * n4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];                          // (slice order, as the scalar kernel)
+    }
+    if (z + 4 <= slices) {
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = src[static_cast<size_t>(z + k) * n4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += v[k];
+        z += 4;
+    }
+    {
+        f32x4 v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = z + k < slices ? src[static_cast<size_t>(z + k) * n4] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (z + k < slices) s += v[k];      // (no `+ 0`: -0.0 stays -0.0, as in the scalar kernel)
+    }
+    s *= scale;
+    if constexpr (DT == FEWBIT_F32) reinterpret_cast<f32x4 *>(out)[i] = s;
+    else {
+        typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+        u32x2 o;
+        o.x = Operand<DT>::pack(s.x, s.y);
+        o.y = Operand<DT>::pack(s.z, s.w);
+        reinterpret_cast<u32x2 *>(out)[i] = o;
+    }
+}
+
 // the matrix itself (test seam and debugging aid; the product path never calls it): out[i][r] = S[row0 + i][col0 + r] as fp32
 template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(Key key, size_t row0, size_t col0, size_t nrows, size_t ncols, int dtype, float *__restrict__ out) {
     const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -706,8 +747,12 @@ int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, 
                             : launch_kernel<DIST, DT, true, 4>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s);
         if (rc != FEWBIT_OK) return rc;
         const size_t n = proj * features;
-        hipLaunchKernelGGL((sketch_reduce_kernel<DT>), dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s,
-                           static_cast<const float *>(workspace), n, static_cast<int>(p.gz), scale, out);
+        if (n % 4 == 0 && (reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out)) % 16 == 0)
+            hipLaunchKernelGGL((sketch_reduce4_kernel<DT>), dim3(static_cast<unsigned>((n / 4 + 255) / 256)), dim3(256), 0, s,
+                               static_cast<const float *>(workspace), n / 4, static_cast<int>(p.gz), scale, out);
+        else
+            hipLaunchKernelGGL((sketch_reduce_kernel<DT>), dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s,
+                               static_cast<const float *>(workspace), n, static_cast<int>(p.gz), scale, out);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sketch: %s", hipGetErrorString(e));
