@@ -220,6 +220,21 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
     }
 }
 
+// y of the forward.  FEWBIT_INPLACE_STORE (measurement builds): what an IN PLACE call (y == x, the reference operator's own
+// contract) does with a store the out-of-place policy makes nontemporal -- 0: the same nontemporal store, 1: a plain store
+// (wave-uniform branch on the two kernel arguments), 2: plain stores always.
+#ifndef FEWBIT_INPLACE_STORE
+#define FEWBIT_INPLACE_STORE 0
+#endif
+template <int DT, bool NT> __device__ __forceinline__ void store_y(const void *x, void *y, size_t g, const float (&v)[8]) {
+    if constexpr (NT && FEWBIT_INPLACE_STORE == 1) {
+        if (x == y) GroupIO<DT>::template store<false>(y, g, v);
+        else GroupIO<DT>::template store<true>(y, g, v);
+    } else {
+        GroupIO<DT>::template store<(NT && FEWBIT_INPLACE_STORE != 2)>(y, g, v);
+    }
+}
+
 // occupancy each forward instantiation is compiled for: 8 waves/SIMD (<= 64 VGPRs) where the table and
 // the two prefetch buffers fit without spilling, 6 (<= 80) for 4-bit tables (15 border VGPRs), fp32
 // groups (8 VGPRs per buffer) and mish (ocml log1p+exp+tanh).  The launcher sizes the grid from the occupancy the runtime reports.
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) v
                 // state: plain store -- it is what backward reads, and a backward that follows closely finds it
                 // cached (4096x4096 bf16 step 26.5 -> 25.6 us); when backward runs much later it makes no difference.
                 if constexpr (kSplit) SplitF32::store<true>(y, g, s.lane, v);
-                else GroupIO<DT>::template store<kStreamY>(y, g, v);
+                else store_y<DT, kStreamY>(x, y, g, v);
                 store_state_quad<K, false>(state, g, s.lane, w);
             }
         });
@@ -459,7 +474,7 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
                     for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
                 }
                 const size_t g = (t * U + u) * kWave + s.lane;
-                GroupIO<DT>::template store<true>(y, g, v);
+                store_y<DT, true>(x, y, g, v);
 #if FEWBIT_STATE_STAGE
                 if (staged) {
                     // this tile's 192 state bytes -> slot (t - t0) % 4 of the wave's LDS strip (the same quad regroup as
