@@ -452,6 +452,9 @@ class TorchSync:
         self.dist, self.device = dist, device
         self.backend = os.environ.get('FEWBIT_BENCH_BACKEND', 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if os.environ['MASTER_ADDR'] in ('127.0.0.1', 'localhost', '::1'):
+            # one node: the loopback interface, whatever the container's hostname resolves to (or fails to)
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
         if self.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
