@@ -15,7 +15,7 @@ __all__ = [
     'quantize_backward', 'bind_forward', 'bind_backward', 'bind_stepwise1_forward', 'bind_stepwise1_backward',
     'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError', 'describe_forward',
     'describe_backward', 'describe_stepwise1_forward', 'describe_stepwise1_backward', 'tune',
-    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'next_sketch_seed', 'mix_sketch_seed', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves', 'tune_sketch_halves',
+    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'next_sketch_seed', 'mix_sketch_seed', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves', 'tune_sketch_halves', 'tune_sketch_convert',
     'philox4x32',
 ]
 
@@ -40,7 +40,7 @@ SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwid
            'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune',
            'fewbit_hip_sketch_workspace', 'fewbit_hip_sketch', 'fewbit_hip_sketch_device_seed', 'fewbit_hip_sketch_next_seed',
            'fewbit_hip_sketch_mix_seed', 'fewbit_hip_sketch_matrix', 'fewbit_hip_sketch_describe',
-           'fewbit_hip_sketch_tune_slices', 'fewbit_hip_sketch_tune_waves', 'fewbit_hip_sketch_tune_halves', 'fewbit_hip_philox4x32')
+           'fewbit_hip_sketch_tune_slices', 'fewbit_hip_sketch_tune_waves', 'fewbit_hip_sketch_tune_halves', 'fewbit_hip_sketch_tune_convert', 'fewbit_hip_philox4x32')
 
 
 class FewbitHipError(RuntimeError):
@@ -112,6 +112,8 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_sketch_tune_slices.argtypes = [ctypes.c_longlong]
         L.fewbit_hip_sketch_tune_waves.restype = i32
         L.fewbit_hip_sketch_tune_waves.argtypes = [ctypes.c_longlong]
+        L.fewbit_hip_sketch_tune_convert.restype = i32
+        L.fewbit_hip_sketch_tune_convert.argtypes = [ctypes.c_longlong]
         L.fewbit_hip_sketch_tune_halves.restype = i32
         L.fewbit_hip_sketch_tune_halves.argtypes = [ctypes.c_longlong]
         L.fewbit_hip_philox4x32.restype = None
@@ -457,6 +459,11 @@ def tune_sketch_waves(waves: int) -> None:
 def tune_sketch_halves(halves: int) -> None:
     """measurement hook: column halves per workgroup, 1 or 2 (the 128 x 512 tile); -1 = built-in policy"""
     _check(lib().fewbit_hip_sketch_tune_halves(int(halves)))
+
+
+def tune_sketch_convert(convert: int) -> None:
+    """measurement hook: round fp32 input to bf16 in one pass before the product (1), never (0), built-in policy (-1)"""
+    _check(lib().fewbit_hip_sketch_tune_convert(int(convert)))
 
 
 def philox4x32(counter, key):

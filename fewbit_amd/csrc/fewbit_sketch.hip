@@ -596,6 +596,35 @@ template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(
     out[idx] = v;
 }
 
+// ---- fp32 input, many row tiles: one conversion pass first ------------------------------------------------------------------
+// Every row tile of S re-reads M (from L2 / Infinity Cache).  For fp32 input that is twice the bytes of bf16 per re-read, twice
+// the staging registers and a conversion per element per re-read; from a few row tiles on it is cheaper to round M to bf16 ONCE
+// (a streaming pass: read 4 B, write 2 B per element, into the workspace) and run the bf16-input kernel on the copy, with the
+// result still written as fp32 from the fp32 sums (measured, 16384 rows: p = 3276: -10 % at 768 features, -9...-19 % at 3072;
+// p = 1638: -14 % / break-even; profiles/r04_sketch_preconvert.txt).  The products are the same numbers either way: both
+// round M to bf16 with the same round-to-nearest-even conversion.
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ m, size_t rows, size_t features, size_t ld, uint16_t *__restrict__ out) {
+    const size_t per_row = (features + 7) / 8;
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= rows * per_row) return;
+    const size_t r = i / per_row, f = (i % per_row) * 8;
+    const float *src = m + r * ld + f;
+    uint16_t *dst = out + r * features + f;
+    if (f + 8 <= features) {
+        typedef f32x4 __attribute__((aligned(4))) f32x4u;
+        const f32x4 a = *reinterpret_cast<const f32x4u *>(src), b = *reinterpret_cast<const f32x4u *>(src + 4);
+        u32x4 o;
+        o[0] = Operand<FEWBIT_BF16>::pack(a[0], a[1]);
+        o[1] = Operand<FEWBIT_BF16>::pack(a[2], a[3]);
+        o[2] = Operand<FEWBIT_BF16>::pack(b[0], b[1]);
+        o[3] = Operand<FEWBIT_BF16>::pack(b[2], b[3]);
+        typedef u32x4 __attribute__((aligned(2))) u32x4u;
+        *reinterpret_cast<u32x4u *>(dst) = o;
+    } else {
+        for (size_t e = 0; f + e < features; ++e) dst[e] = static_cast<uint16_t>(Operand<FEWBIT_BF16>::pack(src[e], 0.0f) & 0xffffu);
+    }
+}
+
 // ---- seeds drawn on the device ----------------------------------------------------------------------------------------------
 // A launch recorded in a hipGraph replays its kernel ARGUMENTS: a seed passed by value would give every replay the same S.
 // There the seed comes from device memory instead: `next_seed_kernel` (also recorded) bumps a counter and derives the seed of
@@ -728,17 +757,17 @@ int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t
 }
 
 template <int DIST, int DT>
-int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out, void *workspace,
+int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out, int out_dtype, void *workspace,
            size_t workspace_bytes, hipStream_t s) {
     const Plan p = make_plan(DIST, DT, rows, features, proj);
     const bool ragged = (features % 8) != 0;
     int rc;
-    if (p.gz == 1) {
+    if (p.gz == 1 && out_dtype == DT) {
         rc = p.halves == 2 ? launch_kernel<DIST, DT, false, 8, 2>(p, ragged, m, rows, features, ld, proj, key, scale, out, s)
              : p.waves == 8 ? launch_kernel<DIST, DT, false, 8>(p, ragged, m, rows, features, ld, proj, key, scale, out, s)
                             : launch_kernel<DIST, DT, false, 4>(p, ragged, m, rows, features, ld, proj, key, scale, out, s);
         if (rc != FEWBIT_OK) return rc;
-    } else {
+    } else {                                         // fp32 partial sums, then one pass: sum, scale, round to the result's dtype
         const size_t need = static_cast<size_t>(p.gz) * proj * features * sizeof(float);
         if (workspace == nullptr || workspace_bytes < need)
             return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", need, workspace_bytes);
@@ -747,12 +776,16 @@ int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, 
                             : launch_kernel<DIST, DT, true, 4>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s);
         if (rc != FEWBIT_OK) return rc;
         const size_t n = proj * features;
-        if (n % 4 == 0 && (reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out)) % 16 == 0)
-            hipLaunchKernelGGL((sketch_reduce4_kernel<DT>), dim3(static_cast<unsigned>((n / 4 + 255) / 256)), dim3(256), 0, s,
-                               static_cast<const float *>(workspace), n / 4, static_cast<int>(p.gz), scale, out);
-        else
-            hipLaunchKernelGGL((sketch_reduce_kernel<DT>), dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s,
-                               static_cast<const float *>(workspace), n, static_cast<int>(p.gz), scale, out);
+        const float *ws = static_cast<const float *>(workspace);
+        const int z = static_cast<int>(p.gz);
+        const bool vec = n % 4 == 0 && (reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
+        auto reduce = [&](auto tag) {
+            constexpr int ODT = decltype(tag)::value;
+            if (vec) hipLaunchKernelGGL((sketch_reduce4_kernel<ODT>), dim3(static_cast<unsigned>((n / 4 + 255) / 256)), dim3(256), 0, s, ws, n / 4, z, scale, out);
+            else hipLaunchKernelGGL((sketch_reduce_kernel<ODT>), dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, ws, n, z, scale, out);
+        };
+        if (out_dtype == FEWBIT_F32) reduce(std::integral_constant<int, FEWBIT_F32>{});
+        else reduce(std::integral_constant<int, DT>{});
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sketch: %s", hipGetErrorString(e));
@@ -760,15 +793,31 @@ int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, 
 }
 
 template <int DIST>
-int launch_dtype(int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out,
+int launch_dtype(int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out, int out_dtype,
                  void *workspace, size_t workspace_bytes, hipStream_t s) {
     switch (dtype) {
-    case FEWBIT_F32: return launch<DIST, FEWBIT_F32>(m, rows, features, ld, proj, key, scale, out, workspace, workspace_bytes, s);
-    case FEWBIT_F16: return launch<DIST, FEWBIT_F16>(m, rows, features, ld, proj, key, scale, out, workspace, workspace_bytes, s);
-    case FEWBIT_BF16: return launch<DIST, FEWBIT_BF16>(m, rows, features, ld, proj, key, scale, out, workspace, workspace_bytes, s);
+    case FEWBIT_F32: return launch<DIST, FEWBIT_F32>(m, rows, features, ld, proj, key, scale, out, out_dtype, workspace, workspace_bytes, s);
+    case FEWBIT_F16: return launch<DIST, FEWBIT_F16>(m, rows, features, ld, proj, key, scale, out, out_dtype, workspace, workspace_bytes, s);
+    case FEWBIT_BF16: return launch<DIST, FEWBIT_BF16>(m, rows, features, ld, proj, key, scale, out, out_dtype, workspace, workspace_bytes, s);
     default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: unknown dtype %d", dtype);
     }
 }
+
+// fp32 input: convert first?  From 6 row tiles of 256 on (p > 1280) -- below that M is read too few times for the extra pass
+// (read 4 + write 2 + read 2 bytes per element) to pay.  tune: 0 never, 1 always, -1 this policy.
+FEWBIT_HIDDEN std::atomic<long long> g_forced_convert{-1};
+bool converts_first(int dtype, size_t rows, size_t proj) {
+    if (dtype != FEWBIT_F32 || rows == 0) return false;
+    const long long forced = g_forced_convert.load(std::memory_order_relaxed);
+    if (forced >= 0) return forced != 0;
+    return proj > 1280;
+}
+constexpr size_t kWorkspaceAlign = 256;
+size_t partial_bytes(int dist, int dtype, int out_dtype, size_t rows, size_t features, size_t proj) {
+    const Plan p = make_plan(dist, dtype, rows, features, proj);
+    return (p.gz > 1 || out_dtype != dtype) ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : 0;
+}
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace sketch
 }  // namespace fewbit_hip
@@ -780,8 +829,9 @@ extern "C" {
 
 size_t fewbit_hip_sketch_workspace(int dist, int dtype, size_t rows, size_t features, size_t proj) {
     if (rows == 0 || features == 0 || proj == 0) return 0;
-    const Plan p = make_plan(dist, dtype, rows, features, proj);
-    return p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : 0;
+    if (converts_first(dtype, rows, proj))           // fp32 partial sums of the bf16-input kernel, then the bf16 copy of M
+        return round_up(partial_bytes(dist, FEWBIT_BF16, FEWBIT_F32, rows, features, proj), kWorkspaceAlign) + rows * features * sizeof(uint16_t);
+    return partial_bytes(dist, dtype, dtype, rows, features, proj);
 }
 
 static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, double scale,
@@ -798,9 +848,23 @@ static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t 
         if (hipMemsetAsync(out, 0, proj * features * es, s) != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sketch: memset failed");
         return FEWBIT_OK;
     }
+    int in_dtype = dtype;
+    if (converts_first(dtype, rows, proj)) {
+        const size_t head = round_up(partial_bytes(dist, FEWBIT_BF16, FEWBIT_F32, rows, features, proj), kWorkspaceAlign);
+        const size_t need = head + rows * features * sizeof(uint16_t);
+        if (workspace == nullptr || workspace_bytes < need)
+            return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", need, workspace_bytes);
+        uint16_t *copy = reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(workspace) + head);
+        const size_t pieces = rows * ((features + 7) / 8);
+        hipLaunchKernelGGL(to_bf16_kernel, dim3(static_cast<unsigned>((pieces + 255) / 256)), dim3(256), 0, s, static_cast<const float *>(m), rows, features, ld, copy);
+        m = copy;
+        ld = features;
+        in_dtype = FEWBIT_BF16;
+        workspace_bytes = head;
+    }
     if (dist == FEWBIT_SKETCH_RADEMACHER)
-        return launch_dtype<FEWBIT_SKETCH_RADEMACHER>(dtype, m, rows, features, ld, proj, key, static_cast<float>(scale), out, workspace, workspace_bytes, s);
-    return launch_dtype<FEWBIT_SKETCH_GAUSSIAN>(dtype, m, rows, features, ld, proj, key, static_cast<float>(scale), out, workspace, workspace_bytes, s);
+        return launch_dtype<FEWBIT_SKETCH_RADEMACHER>(in_dtype, m, rows, features, ld, proj, key, static_cast<float>(scale), out, dtype, workspace, workspace_bytes, s);
+    return launch_dtype<FEWBIT_SKETCH_GAUSSIAN>(in_dtype, m, rows, features, ld, proj, key, static_cast<float>(scale), out, dtype, workspace, workspace_bytes, s);
 }
 
 int fewbit_hip_sketch(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, uint64_t seed, double scale,
@@ -844,12 +908,13 @@ int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, si
 
 int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features, size_t proj, char *buf, size_t len) {
     if (buf == nullptr || len == 0) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch_describe: no buffer");
-    const Plan p = make_plan(dist, dtype, rows, features, proj);
+    const bool converted = converts_first(dtype, rows, proj);
+    const Plan p = make_plan(dist, converted ? FEWBIT_BF16 : dtype, rows, features, proj);
     snprintf(buf, len, "{\"kernel\": \"sketch_kernel (%dx%d tile, K stage %d, v_mfma_f32_32x32x16)\", \"grid\": [%u, %u, %u], \"threads\": %d, "
-                       "\"k_slice\": %zu, \"lds_bytes\": %d, \"workspace_bytes\": %zu}",
+                       "\"k_slice\": %zu, \"lds_bytes\": %d, \"workspace_bytes\": %zu, \"converted_to_bf16_first\": %s}",
              32 * p.waves / p.halves, 256 * p.halves, 16 * p.waves / p.halves, p.gx, p.gy, p.gz, 64 * p.waves, p.kslice,
-             p.halves == 2 ? Tile<8, 2>::kLdsBytes : 2 * 16 * p.waves * BN * 2,
-             p.gz > 1 ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : static_cast<size_t>(0));
+             p.halves == 2 ? Tile<8, 2>::kLdsBytes : 2 * 16 * p.waves * BN * 2, fewbit_hip_sketch_workspace(dist, dtype, rows, features, proj),
+             converted ? "true" : "false");
     return FEWBIT_OK;
 }
 
@@ -867,6 +932,12 @@ int fewbit_hip_sketch_debug_trace(unsigned long long *host, size_t count) {
 
 int fewbit_hip_sketch_tune_slices(long long slices) {
     g_forced_slices.store(slices, std::memory_order_relaxed);
+    return FEWBIT_OK;
+}
+
+int fewbit_hip_sketch_tune_convert(long long convert) {
+    if (convert < -1 || convert > 1) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: convert is 0 (never), 1 (always) or -1 (policy), got %lld", convert);
+    g_forced_convert.store(convert, std::memory_order_relaxed);
     return FEWBIT_OK;
 }
 

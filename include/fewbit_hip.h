@@ -169,7 +169,8 @@ int fewbit_hip_unpack_codes(const uint8_t *state, int32_t *codes, size_t n, int 
  *        matrix cores (definition: fewbit_amd/csrc/fewbit_sketch.hip header; host model: tests/sketch_reference.py).
  *        Forward and backward pass the same seed and get the same S.
  *   m    rows x features, row-major with leading dimension `ld` (elements), dtype F32 / F16 / BF16; fp32 is rounded to bf16
- *        while it is staged (the products run on the bf16 matrix pipe, accumulation is fp32)
+ *        (while it is staged, or for many row tiles in one pass beforehand) -- the products run on the bf16 matrix pipe,
+ *        accumulation is fp32
  *   out  proj x features, contiguous, the dtype of m
  *   workspace  fewbit_hip_sketch_workspace(dist, dtype, rows, features, proj) bytes of device memory (0 when the rows are not sliced);
  *        contents are scratch.  The result is deterministic: the same arguments give the same bits.
@@ -204,6 +205,10 @@ int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features
 int fewbit_hip_sketch_tune_slices(long long slices);
 int fewbit_hip_sketch_tune_waves(long long waves);
 int fewbit_hip_sketch_tune_halves(long long halves);
+/* fp32 input with many row tiles (p > 1280) is rounded to bf16 ONCE into the workspace and multiplied by the bf16-input kernel
+ * (the result stays fp32, from the fp32 sums; the numbers are the ones the in-kernel conversion gives): 0 never, 1 always,
+ * -1 that policy.  fewbit_hip_sketch_workspace already counts the copy. */
+int fewbit_hip_sketch_tune_convert(long long convert);
 /* Philox4x32-10 on the HOST (the generator behind S; known-answer tests run it without a GPU) */
 void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -177,6 +177,7 @@ def test_seeded_fuzz_of_shapes_dtypes_strides_and_tiles():
     the slicing are drawn per case; every product must equal the host model's"""
     import random
     rnd = random.Random(20260402)
+    rnd_convert = random.Random(7)                       # (its own stream: the cases above keep their sequence)
     edges_r = (1, 7, 8, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 3000)
     edges_f = (1, 8, 9, 40, 255, 256, 257, 264, 511, 512, 520, 768, 1032)
     edges_p = (1, 31, 32, 33, 127, 128, 129, 255, 256, 257, 300)
@@ -189,6 +190,7 @@ def test_seeded_fuzz_of_shapes_dtypes_strides_and_tiles():
             cabi.tune_sketch_waves(rnd.choice((-1, 4, 8)))
             cabi.tune_sketch_halves(rnd.choice((-1, 1, 2)))
             cabi.tune_sketch_slices(rnd.choice((-1, 1, 2, 3)))
+            cabi.tune_sketch_convert(rnd_convert.choice((-1, 0, 1)))         # fp32 input: one conversion pass first, or not
             ld = features + rnd.choice((0, 0, 8, 3)) if features > 1 else None
             _product_case(dist, dtype, rows, features, proj, seed=rnd.getrandbits(64), ld=ld if ld != features else None,
                           scale=rnd.choice((1.0, 1.0 / proj, -0.5)))
@@ -196,6 +198,37 @@ def test_seeded_fuzz_of_shapes_dtypes_strides_and_tiles():
         cabi.tune_sketch_waves(-1)
         cabi.tune_sketch_halves(-1)
         cabi.tune_sketch_slices(-1)
+        cabi.tune_sketch_convert(-1)
+
+
+def test_fp32_input_converted_to_bf16_first_gives_the_same_products():
+    """p > 1280 (six row tiles re-reading M): fp32 input is rounded to bf16 once, into the workspace, and the bf16-input kernel
+    runs on the copy; the result is still fp32 from the fp32 sums.  Same rounding of M either way -> the same products, up to
+    the association of the fp32 sums where the two paths slice the rows differently."""
+    assert cabi.describe_sketch('rademacher', 16384, 768, 3276, torch.float32)['converted_to_bf16_first'] is True
+    assert cabi.describe_sketch('gaussian', 16384, 768, 1280, torch.float32)['converted_to_bf16_first'] is False
+    assert cabi.describe_sketch('rademacher', 16384, 768, 3276, torch.bfloat16)['converted_to_bf16_first'] is False
+    try:
+        for dist in ('rademacher', 'gaussian'):
+            for rows, features, proj, ld in ((3000, 770, 200, None), (4096, 512, 1400, None), (512, 100, 64, 136), (2048, 1024, 1300, 1032), (1000, 37, 5, None)):
+                g = torch.Generator().manual_seed(rows)
+                m = torch.randn(rows, ld or features, generator=g).to(DEV)[:, :features]
+                got = {}
+                for convert in (0, 1):
+                    cabi.tune_sketch_convert(convert)
+                    plan = cabi.describe_sketch(dist, rows, features, proj, torch.float32)
+                    assert plan['converted_to_bf16_first'] is bool(convert)
+                    assert plan['workspace_bytes'] == cabi.sketch_workspace_bytes(dist, rows, features, proj, torch.float32)
+                    if convert:
+                        assert plan['workspace_bytes'] >= rows * features * 2 + proj * features * 4
+                    got[convert] = cabi.sketch(dist, m, proj, 99, 0.25)
+                    assert got[convert].dtype == torch.float32
+                    assert torch.equal(got[convert], cabi.sketch(dist, m, proj, 99, 0.25))           # deterministic
+                bound = 0.25 * (cabi.sketch_matrix(dist, torch.float32, 99, proj, rows).abs() @ m.abs())
+                assert bool(((got[0] - got[1]).abs() <= 2.0**-20 * bound + 1e-30).all()), (dist, rows, features, proj)
+                _product_case(dist, torch.float32, rows, features, proj, seed=5, ld=ld)                # (convert = 1 still set)
+    finally:
+        cabi.tune_sketch_convert(-1)
 
 
 def test_sketch_and_randomized_layer_capture_into_a_hip_graph():
