@@ -352,6 +352,14 @@ def measure_sketch(device):
         us = timed(lambda: cabi.sketch(dist, m, proj, 1234, 1.0 / proj, out=o, workspace=ws))
         out[dist] = {'us': round(us, 1), 'plan': cabi.describe_sketch(dist, rows, features, proj), 'roofline': {'bound': 'mfma', 'achieved': round(flops / us / 1e6, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
                                                        'frac': round(flops / us / 1e6 / 2500.0, 4)}}
+    # fp32 input (the reference's own dtype): M is rounded to bf16 once, into the workspace, then the same kernel; fp32 result
+    m32 = m.float()
+    ws32 = torch.empty(max(max(cabi.sketch_workspace_bytes(d, rows, features, proj, torch.float32) for d in cabi.SKETCH_DISTS), 1), dtype=torch.uint8, device=device)
+    o32 = torch.empty(proj, features, dtype=torch.float32, device=device)
+    out['fp32_input'] = {dist: {'us': round(timed(lambda: cabi.sketch(dist, m32, proj, 1234, 1.0 / proj, out=o32, workspace=ws32)), 1),
+                                'converted_to_bf16_first': cabi.describe_sketch(dist, rows, features, proj, torch.float32)['converted_to_bf16_first']}
+                         for dist in ('rademacher', 'gaussian')}
+    del m32, ws32, o32
     S = torch.randn(proj, rows, device=device, dtype=torch.bfloat16)
     out['torch'] = {'randn_plus_matmul_us': round(timed(lambda: torch.randn(proj, rows, device=device, dtype=torch.bfloat16) @ m), 1),
                     'randint_plus_matmul_us': round(timed(lambda: (torch.randint(0, 2, (proj, rows), device=device, dtype=torch.int8).to(torch.bfloat16) * 2 - 1) @ m), 1),
