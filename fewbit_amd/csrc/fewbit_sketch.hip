@@ -84,6 +84,10 @@ template <int W, int NH = 1> struct Tile {
     static constexpr int kChunksPerRow = BNT / 8;              // 16-byte chunks per octet of rows in the LDS image
 };
 constexpr int kPhiloxRounds = 10;
+#ifndef FEWBIT_GAUSSIAN_ROUNDS
+#define FEWBIT_GAUSSIAN_ROUNDS 10
+#endif
+constexpr int kGaussianRounds = FEWBIT_GAUSSIAN_ROUNDS;
 #ifndef FEWBIT_SKETCH_ABLATE
 #define FEWBIT_SKETCH_ABLATE 0      // measurement builds only (results are WRONG): 1 no staging of M after the first stage, 2 no barrier in
 #endif                              // the K loop, 4 constant A operand (no generator), 8 B fragments read once (no LDS reads in the loop)
@@ -109,10 +113,11 @@ __device__ unsigned long long g_sketch_trace[8 * 512 * 12];      // slots 0..2 a
 // ---- Philox4x32-10 -----------------------------------------------------------------------------------------------------
 struct Key { uint32_t k0, k1; };
 
+template <int ROUNDS = kPhiloxRounds>
 __host__ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, Key key, uint32_t (&out)[4]) {
     uint32_t k0 = key.k0, k1 = key.k1;
 #pragma unroll
-    for (int r = 0; r < kPhiloxRounds; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0, p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
         const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0, n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
         c1 = static_cast<uint32_t>(p1);
@@ -173,7 +178,7 @@ __device__ __forceinline__ void box_muller(uint32_t w, float &z0, float &z1) {
 
 template <int DT> __device__ __forceinline__ u32x4 gaussian_fragment(uint32_t row, uint32_t octet, Key key) {
     uint32_t w[4];
-    philox4x32(row, octet, 0u, 1u, key, w);
+    philox4x32<kGaussianRounds>(row, octet, 0u, 1u, key, w);
     u32x4 a;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -585,7 +590,7 @@ template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(
         v = ((w[s >> 2] >> (((j & 1) ? 31 : 15) - (4 * (s & 3) + (j >> 1)))) & 1u) ? -1.0f : 1.0f;
     } else {
         uint32_t w[4];
-        philox4x32(static_cast<uint32_t>(i), static_cast<uint32_t>(r >> 3), 0u, 1u, key, w);
+        philox4x32<kGaussianRounds>(static_cast<uint32_t>(i), static_cast<uint32_t>(r >> 3), 0u, 1u, key, w);
         float z0, z1;
         box_muller(w[j >> 1], z0, z1);
         v = (j & 1) ? z1 : z0;
