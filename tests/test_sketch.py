@@ -25,6 +25,34 @@ def test_philox_known_answers_library_and_model():
         assert cabi.philox4x32(tuple(int(c[k][n]) for k in range(4)), (0x12345678, 0x9abcdef0)) == tuple(int(g[n]) for g in got)
 
 
+def test_model_round_loop_against_the_seven_round_vectors_too():
+    """Random123 kat_vectors, philox4x32 with 7 rounds: a second published fixed point for the model's round function and key
+    schedule (the kernels use 10 rounds; DESIGN.md 3.1 records the 7-round experiment)"""
+    for ctr, key, want in (((0, 0, 0, 0), (0, 0), (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
+                           ((0xffffffff, ) * 4, (0xffffffff, ) * 2, (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
+                           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a))):
+        got = ref.philox4x32(*[np.array([c]) for c in ctr], *key, rounds=7)
+        assert tuple(int(g[0]) for g in got) == want
+
+
+def test_seed_derivation_of_captured_launches_on_the_host():
+    """fewbit_hip_sketch_mix_seed (what the recorded seed kernel computes from its counter): splitmix64's finaliser"""
+    M = 2**64 - 1
+
+    def splitmix(base, count):
+        x = (base + (count + 1) * 0x9E3779B97F4A7C15) & M
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+        return x ^ (x >> 31)
+
+    rng = np.random.default_rng(1)
+    for base, count in [(0, 0), (M, M), (1, 0), (0, 1)] + [(int(a), int(b)) for a, b in rng.integers(0, 2**63, size=(50, 2))]:
+        assert cabi.mix_sketch_seed(base, count) == splitmix(base, count)
+    # splitmix64's own first output for state 0 (Vigna's reference implementation): 0xe220a8397b1dcdaf
+    assert cabi.mix_sketch_seed(0, 0) == 0xe220a8397b1dcdaf
+    assert len({cabi.mix_sketch_seed(5, c) for c in range(1000)}) == 1000
+
+
 def test_model_matrices_have_the_right_moments_and_are_functions_of_the_seed():
     S = ref.rademacher(7, 96, 2048)
     assert set(S.unique().tolist()) == {-1.0, 1.0}
