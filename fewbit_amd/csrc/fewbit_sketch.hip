@@ -182,9 +182,13 @@ template <int DT> __device__ __forceinline__ u32x4 gaussian_fragment(uint32_t ro
     u32x4 a;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float z0, z1;
-        box_muller(w[q], z0, z1);
-        a[q] = Operand<DT>::pack(z0, z1);
+        if constexpr ((FEWBIT_SKETCH_ABLATE & 16) != 0) {      // (measurement only: no Box-Muller, the raw bits as operands)
+            a[q] = (w[q] & 0x007f007fu) | Operand<DT>::kOnes;
+        } else {
+            float z0, z1;
+            box_muller(w[q], z0, z1);
+            a[q] = Operand<DT>::pack(z0, z1);
+        }
     }
     return a;
 }
