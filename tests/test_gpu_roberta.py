@@ -36,8 +36,21 @@ def _step_times(model, ids, labels, steps):
     return times
 
 
+@pytest.fixture
+def shipped_routes():
+    """the operator library's autograd routes as shipped (all on), whatever FEWBIT_NO_* says in the environment of the run:
+    the raw-operator assertions below (no CopySlices, the same saved bytes as the module route) describe that configuration"""
+    import fewbit_amd
+    prev = {}
+    if fewbit_amd.native_loaded() and fewbit_amd.autograd_internals():
+        prev = {k: fewbit_amd.autograd_route(k, True) for k in ('direct_node', 'base_dirty', 'fresh_view')}
+    yield
+    for k, v in prev.items():
+        fewbit_amd.autograd_route(k, v)
+
+
 @pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16))
-def test_roberta_base_all_gelu_fewbit(dtype):
+def test_roberta_base_all_gelu_fewbit(dtype, shipped_routes):
     pytest.importorskip('transformers')
     import fewbit
     import fewbit_amd
