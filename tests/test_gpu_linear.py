@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+@pytest.fixture(autouse=True)
+def native_sketch_on():
+    """these tests are about the gfx950 sketch kernel: select it whatever FEWBIT_SKETCH_NATIVE says in the environment"""
+    from fewbit_amd import linear
+    prev = linear.use_native_sketch(True)
+    yield
+    linear.use_native_sketch(prev)
+
+
 @pytest.fixture(scope='module')
 def lref():
     with np.load(GOLDEN / 'linear_ref.npz') as z:

@@ -11,6 +11,15 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+@pytest.fixture(autouse=True)
+def native_sketch_on():
+    """these tests are about the gfx950 sketch kernel: select it whatever FEWBIT_SKETCH_NATIVE says in the environment"""
+    from fewbit_amd import linear
+    prev = linear.use_native_sketch(True)
+    yield
+    linear.use_native_sketch(prev)
+
+
 @pytest.mark.parametrize('seed', (0, 1, 0x1234567890abcdef, 2**64 - 1))
 def test_rademacher_matrix_is_the_models_bit_for_bit(seed):
     for (nr, nc, r0, c0) in ((70, 1000, 0, 0), (33, 515, 1000, 250), (4, 64, 2**31, 2**33 + 8)):
