@@ -122,5 +122,31 @@ int main() {
     }
     std::printf("  sketch %zu x %zu . %zu x %zu (Rademacher, seed %llx): mismatches %zu\n", proj, rows, rows, feats,
                 static_cast<unsigned long long>(sk_seed), bad_sketch);
-    return (bad_code || bad_gx || bad_y || bad_sketch) ? 1 : 0;
+    // ---- the same product with its seed in DEVICE memory (what a launch recorded in a hipGraph uses): the seed kernel derives
+    //      seed = mix(base, counter++) on the device; the host evaluates the same function and must get the same product ----
+    uint64_t *dwords;                                   // [0] the counter, [1] the seed of this call
+    const uint64_t base = 42, counter0 = 6;
+    HIP_OK(hipMalloc(&dwords, 16));
+    HIP_OK(hipMemcpyAsync(dwords, &counter0, 8, hipMemcpyHostToDevice, stream));
+    std::vector<float> out_dev(out.size()), out_val(out.size());
+    rc = fewbit_hip_sketch_next_seed(dwords, base, dwords + 1, stream);
+    if (rc == FEWBIT_OK)
+        rc = fewbit_hip_sketch_device_seed(FEWBIT_SKETCH_GAUSSIAN, FEWBIT_F32, dm, rows, feats, feats, proj, dwords + 1, 0.5, dout, dws, ws_bytes, stream);
+    if (rc != FEWBIT_OK) {
+        std::fprintf(stderr, "device-seed sketch error %d: %s\n", rc, fewbit_hip_last_error());
+        return 3;
+    }
+    HIP_OK(hipMemcpyAsync(out_dev.data(), dout, out.size() * 4, hipMemcpyDeviceToHost, stream));
+    uint64_t counter1 = 0;
+    HIP_OK(hipMemcpyAsync(&counter1, dwords, 8, hipMemcpyDeviceToHost, stream));
+    rc = fewbit_hip_sketch(FEWBIT_SKETCH_GAUSSIAN, FEWBIT_F32, dm, rows, feats, feats, proj, fewbit_hip_sketch_mix_seed(base, counter0), 0.5, dout, dws,
+                           ws_bytes, stream);
+    if (rc != FEWBIT_OK) return 3;
+    HIP_OK(hipMemcpyAsync(out_val.data(), dout, out.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    size_t bad_seed = counter1 != counter0 + 1;
+    for (size_t i = 0; i < out.size(); ++i) bad_seed += out_dev[i] != out_val[i];
+    std::printf("  seed in device memory (counter %llu -> %llu): differences from the seed by value %zu\n",
+                static_cast<unsigned long long>(counter0), static_cast<unsigned long long>(counter1), bad_seed);
+    return (bad_code || bad_gx || bad_y || bad_sketch || bad_seed) ? 1 : 0;
 }

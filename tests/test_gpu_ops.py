@@ -525,6 +525,7 @@ def test_torch_free_host_program_on_the_c_abi():
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'mismatches: codes 0, gradients 0, forward 0' in out.stdout
     assert '(Rademacher, seed 123456789abcdef): mismatches 0' in out.stdout      # the random-projection kernel, S rebuilt on the host
+    assert 'seed in device memory (counter 6 -> 7): differences from the seed by value 0' in out.stdout
 
 
 def test_inference_mode_and_no_grad_run_the_kernels():
