@@ -125,6 +125,36 @@ def test_layer_through_the_native_sketch_equals_the_host_model_of_the_same_strea
     assert torch.allclose(xd.grad.cpu().float(), (gy.to(DEV) @ w.to(DEV)).cpu().float(), rtol=1e-2 if dtype != torch.float32 else 1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('kind', ('rademacher', 'gaussian'))
+def test_sketch_dtype_keeps_a_16_bit_projection_of_an_fp32_layer(kind, monkeypatch):
+    """sketch_dtype=torch.bfloat16 on an fp32 layer (extension; fewbit_amd/linear.py docstring): the projection is computed from
+    and KEPT in bf16 -- half the saved bytes -- and backward's small GEMM runs in bf16; the weight gradient (fp32 again) equals
+    the all-fp32 route's for the same seed up to those roundings, and the host model's."""
+    import sketch_reference as ref
+    import fewbit_amd.linear as L
+    seed = 0xabcdef12345
+    monkeypatch.setattr(L, '_draw_seed', lambda generator: seed)
+    g = torch.Generator().manual_seed(3)
+    rows, fin, fout, p = 600, 72, 40, 96
+    x, w, gy = torch.randn(rows, fin, generator=g), torch.randn(fout, fin, generator=g) * 0.2, torch.randn(rows, fout, generator=g)
+    grads, saved = {}, {}
+    for name, sd in (('fp32', None), ('bf16', torch.bfloat16)):
+        xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+        seen = []
+        with torch.autograd.graph.saved_tensors_hooks(lambda t: (seen.append((tuple(t.shape), t.dtype)), t)[1], lambda t: t):
+            y = fewbit.functional.linear_grp(xd, wd, None, proj_dim=p, matmul=kind, sketch_dtype=sd)
+        y.backward(gy.to(DEV))
+        grads[name], saved[name] = wd.grad.cpu().double(), seen
+        assert wd.grad.dtype == torch.float32 and y.dtype == torch.float32
+    assert ((p, fin), torch.float32) in saved['fp32'] and ((p, fin), torch.bfloat16) in saved['bf16'], saved
+    scale = float(grads['fp32'].abs().max())
+    assert float((grads['fp32'] - grads['bf16']).abs().max()) <= 2e-2 * scale                 # two bf16 roundings of the projections
+    S = ref.matrix(kind, seed, p, rows, torch.bfloat16).double()
+    xs, gs = x.to(torch.bfloat16).double(), gy.to(torch.bfloat16).double()
+    want = (S @ gs).to(torch.bfloat16).double().T @ (S @ xs / p).to(torch.bfloat16).double()
+    assert float((grads['bf16'] - want).abs().max()) <= 2e-2 * scale
+
+
 def test_native_sketch_replays_from_generators_and_can_be_switched_off():
     import fewbit_amd.linear as L
     x = torch.randn(512, 64, device=DEV, requires_grad=True)
