@@ -329,16 +329,12 @@ def measure_op_level(cfg, device, reps=200):
 
 def measure_sketch(device):
     """the random-projection product of the randomized linear layers (fewbit_hip_sketch, S generated in registers
-    -> MFMA) at RoBERTa-base's widest layer (16384 tokens x 3072 features, proj_dim_ratio 0.1), bf16, against what it replaces
-    (S drawn into HBM + torch.matmul).  Roofline class MFMA: 2*p*rows*features flops against the 2.5 PFLOP/s dense bf16 peak."""
+    -> MFMA) where the reference quotes it: proj_dim_ratio 0.2 of 16384 tokens (README "Randomized Linear (20 %)", p = 3276) at
+    both layer widths of RoBERTa-base (3072 and 768 features), bf16, both distributions, each with its roofline (class MFMA:
+    2*p*rows*features flops against the 2.5 PFLOP/s dense bf16 peak) and beside what it replaces (S drawn into HBM + torch.matmul,
+    timed in the same process).  `wins_vs_torch` makes a regression visible in the line.  p = 1638 (ratio 0.1) stays as an extra."""
     from fewbit_amd import cabi
-    rows, features, proj = 16384, 3072, 1638
-    m = torch.randn(rows, features, device=device).to(torch.bfloat16)
-    flops = 2.0 * proj * rows * features
-    out = {'workload': f'out = S . M, S {proj} x {rows} (never materialised), M {rows} x {features} bf16', 'flops': flops,
-           'S_bytes_not_materialised': proj * rows * 2}
-    ws = torch.empty(max(max(cabi.sketch_workspace_bytes(d, rows, features, proj) for d in cabi.SKETCH_DISTS), 1), dtype=torch.uint8, device=device)
-    o = torch.empty(proj, features, dtype=torch.bfloat16, device=device)
+    rows = 16384
 
     def timed(f, reps=20):
         for _ in range(5):
@@ -348,23 +344,37 @@ def measure_sketch(device):
             best.append(event_time_us([f], reps, preroll=1))
         return sorted(best)[1]
 
-    for dist in ('rademacher', 'gaussian'):
-        us = timed(lambda: cabi.sketch(dist, m, proj, 1234, 1.0 / proj, out=o, workspace=ws))
-        out[dist] = {'us': round(us, 1), 'plan': cabi.describe_sketch(dist, rows, features, proj), 'roofline': {'bound': 'mfma', 'achieved': round(flops / us / 1e6, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
-                                                       'frac': round(flops / us / 1e6 / 2500.0, 4)}}
-    # fp32 input (the reference's own dtype): M is rounded to bf16 once, into the workspace, then the same kernel; fp32 result
-    m32 = m.float()
-    ws32 = torch.empty(max(max(cabi.sketch_workspace_bytes(d, rows, features, proj, torch.float32) for d in cabi.SKETCH_DISTS), 1), dtype=torch.uint8, device=device)
-    o32 = torch.empty(proj, features, dtype=torch.float32, device=device)
-    out['fp32_input'] = {dist: {'us': round(timed(lambda: cabi.sketch(dist, m32, proj, 1234, 1.0 / proj, out=o32, workspace=ws32)), 1),
-                                'converted_to_bf16_first': cabi.describe_sketch(dist, rows, features, proj, torch.float32)['converted_to_bf16_first']}
-                         for dist in ('rademacher', 'gaussian')}
-    del m32, ws32, o32
-    S = torch.randn(proj, rows, device=device, dtype=torch.bfloat16)
-    out['torch'] = {'randn_plus_matmul_us': round(timed(lambda: torch.randn(proj, rows, device=device, dtype=torch.bfloat16) @ m), 1),
-                    'randint_plus_matmul_us': round(timed(lambda: (torch.randint(0, 2, (proj, rows), device=device, dtype=torch.int8).to(torch.bfloat16) * 2 - 1) @ m), 1),
-                    'matmul_alone_us': round(timed(lambda: S @ m), 1)}
-    out['evidence'] = 'profiles/r04_sketch_bench.json, profiles/r04_sketch_rocprof_*.txt, DESIGN.md 3.1 / 5.1'
+    def one(features, proj, fp32_too):
+        m = torch.randn(rows, features, device=device).to(torch.bfloat16)
+        flops = 2.0 * proj * rows * features
+        rec = {'workload': f'out = S . M, S {proj} x {rows} (never materialised), M {rows} x {features} bf16', 'flops': flops,
+               'S_bytes_not_materialised': proj * rows * 2}
+        ws = torch.empty(max(max(cabi.sketch_workspace_bytes(d, rows, features, proj) for d in cabi.SKETCH_DISTS), 1), dtype=torch.uint8, device=device)
+        o = torch.empty(proj, features, dtype=torch.bfloat16, device=device)
+        S = torch.randn(proj, rows, device=device, dtype=torch.bfloat16)
+        rec['torch'] = {'randn_plus_matmul_us': round(timed(lambda: torch.randn(proj, rows, device=device, dtype=torch.bfloat16) @ m), 1),
+                        'randint_plus_matmul_us': round(timed(lambda: (torch.randint(0, 2, (proj, rows), device=device, dtype=torch.int8).to(torch.bfloat16) * 2 - 1) @ m), 1),
+                        'matmul_alone_us': round(timed(lambda: S @ m), 1)}
+        del S
+        for dist, pair in (('rademacher', 'randint_plus_matmul_us'), ('gaussian', 'randn_plus_matmul_us')):
+            us = timed(lambda: cabi.sketch(dist, m, proj, 1234, 1.0 / proj, out=o, workspace=ws))
+            rec[dist] = {'us': round(us, 1), 'torch_us': rec['torch'][pair], 'wins_vs_torch': bool(us <= rec['torch'][pair]),
+                         'plan': cabi.describe_sketch(dist, rows, features, proj),
+                         'roofline': {'bound': 'mfma', 'achieved': round(flops / us / 1e6, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(flops / us / 1e6 / 2500.0, 4)}}
+        if fp32_too:    # fp32 input (the reference's own dtype): M is rounded to bf16 once, into the workspace, then the same kernel; fp32 result
+            m32 = m.float()
+            ws32 = torch.empty(max(max(cabi.sketch_workspace_bytes(d, rows, features, proj, torch.float32) for d in cabi.SKETCH_DISTS), 1), dtype=torch.uint8, device=device)
+            o32 = torch.empty(proj, features, dtype=torch.float32, device=device)
+            rec['fp32_input'] = {dist: {'us': round(timed(lambda: cabi.sketch(dist, m32, proj, 1234, 1.0 / proj, out=o32, workspace=ws32)), 1),
+                                        'converted_to_bf16_first': cabi.describe_sketch(dist, rows, features, proj, torch.float32)['converted_to_bf16_first']}
+                                 for dist in ('rademacher', 'gaussian')}
+        return rec
+
+    out = {'note': 'proj_dim_ratio 0.2 (p = 3276 of 16384 rows) is the ratio of the reference README and tools/roberta_bench.py; 0.1 is an extra',
+           'ratio_0.2': {'16384x3072': one(3072, 3276, True), '16384x768': one(768, 3276, False)},
+           'ratio_0.1': {'16384x3072': one(3072, 1638, False)}}
+    out['wins_vs_torch'] = all(out['ratio_0.2'][shape][dist]['wins_vs_torch'] for shape in out['ratio_0.2'] for dist in ('rademacher', 'gaussian'))
+    out['evidence'] = 'profiles/r05_sketch_bench.json, profiles/r05_sketch_rocprof_*.txt, DESIGN.md 3.1 / 5.1'
     return out
 
 
@@ -806,6 +816,9 @@ def add_extras(line, args, device):
             if 'error' not in live:                      # this run's own counters replace the recorded figure
                 line['roofline']['traffic_recorded'] = line['roofline']['traffic']
                 line['roofline']['traffic'], line['roofline']['traffic_source'] = live['hbm_bytes_per_launch'], live['source']
+                line['roofline']['traffic_live_error'] = None
+            else:                                        # visible in the line, not only on stderr: `traffic` is then the recorded figure
+                line['roofline']['traffic_live_error'] = live['error']
     if not args.no_cpu_baseline:
         reps_all, reps_one = CPU_SAMPLES[args.config]
         line['cpu_baseline'] = _guarded('cpu_baseline', lambda: cpu_baseline(args.config, cfg, reps_all))

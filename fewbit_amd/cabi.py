@@ -15,7 +15,7 @@ __all__ = [
     'quantize_backward', 'bind_forward', 'bind_backward', 'bind_stepwise1_forward', 'bind_stepwise1_backward',
     'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError', 'describe_forward',
     'describe_backward', 'describe_stepwise1_forward', 'describe_stepwise1_backward', 'tune',
-    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'next_sketch_seed', 'mix_sketch_seed', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves', 'tune_sketch_halves', 'tune_sketch_convert',
+    'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'next_sketch_seed', 'mix_sketch_seed', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves', 'tune_sketch_halves', 'tune_sketch_convert', 'tune_sketch_partials', 'tune_sketch_materialise', 'xoshiro128pp',
     'philox4x32',
 ]
 
@@ -30,7 +30,7 @@ CONTINUOUS = ('celu', 'elu', 'gelu', 'hardswish', 'logsigmoid', 'mish', 'selu', 
 STEPWISE1 = ('hardshrink', 'hardsigmoid', 'hardtanh', 'leaky_relu', 'relu', 'relu6', 'softshrink', 'threshold')
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 SKETCH_DISTS = ('rademacher', 'gaussian')      # enum fewbit_sketch_dist
-ABI_VERSION = 3                                # FEWBIT_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 4                                # FEWBIT_HIP_ABI_VERSION this binding was written against
 
 # every symbol include/fewbit_hip.h declares
 SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwidth', 'fewbit_hip_state_nbytes',
@@ -40,7 +40,8 @@ SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwid
            'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune',
            'fewbit_hip_sketch_workspace', 'fewbit_hip_sketch', 'fewbit_hip_sketch_device_seed', 'fewbit_hip_sketch_next_seed',
            'fewbit_hip_sketch_mix_seed', 'fewbit_hip_sketch_matrix', 'fewbit_hip_sketch_describe',
-           'fewbit_hip_sketch_tune_slices', 'fewbit_hip_sketch_tune_waves', 'fewbit_hip_sketch_tune_halves', 'fewbit_hip_sketch_tune_convert', 'fewbit_hip_philox4x32')
+           'fewbit_hip_sketch_tune_slices', 'fewbit_hip_sketch_tune_waves', 'fewbit_hip_sketch_tune_halves', 'fewbit_hip_sketch_tune_convert', 'fewbit_hip_sketch_tune_partials', 'fewbit_hip_sketch_tune_materialise',
+           'fewbit_hip_philox4x32', 'fewbit_hip_xoshiro128pp')
 
 
 class FewbitHipError(RuntimeError):
@@ -116,8 +117,14 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_sketch_tune_convert.argtypes = [ctypes.c_longlong]
         L.fewbit_hip_sketch_tune_halves.restype = i32
         L.fewbit_hip_sketch_tune_halves.argtypes = [ctypes.c_longlong]
+        L.fewbit_hip_sketch_tune_partials.restype = i32
+        L.fewbit_hip_sketch_tune_partials.argtypes = [ctypes.c_longlong]
+        L.fewbit_hip_sketch_tune_materialise.restype = i32
+        L.fewbit_hip_sketch_tune_materialise.argtypes = [ctypes.c_longlong]
         L.fewbit_hip_philox4x32.restype = None
         L.fewbit_hip_philox4x32.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
+        L.fewbit_hip_xoshiro128pp.restype = None
+        L.fewbit_hip_xoshiro128pp.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), sz]
         _lib = L
     return _lib
 
@@ -464,6 +471,25 @@ def tune_sketch_halves(halves: int) -> None:
 def tune_sketch_convert(convert: int) -> None:
     """measurement hook: round fp32 input to bf16 in one pass before the product (1), never (0), built-in policy (-1)"""
     _check(lib().fewbit_hip_sketch_tune_convert(int(convert)))
+
+
+def tune_sketch_partials(bf16_partials: int) -> None:
+    """measurement hook: partial sums of sliced bf16 products in bf16 (1 / -1, the policy) or always in fp32 (0)"""
+    _check(lib().fewbit_hip_sketch_tune_partials(int(bf16_partials)))
+
+
+def tune_sketch_materialise(materialise: int) -> None:
+    """measurement hook: Gaussian S written to the workspace once as MFMA fragments and read back by the product kernel (1),
+    always regenerated inside the product kernel (0), built-in policy (-1)"""
+    _check(lib().fewbit_hip_sketch_tune_materialise(int(materialise)))
+
+
+def xoshiro128pp(state, n: int):
+    """n outputs of xoshiro128++ from `state` (4 words) on the host, as the kernels evaluate it; returns (outputs, new state)"""
+    st = (ctypes.c_uint32 * 4)(*state)
+    o = (ctypes.c_uint32 * max(n, 1))()
+    lib().fewbit_hip_xoshiro128pp(st, o, n)
+    return tuple(o)[:n], tuple(st)
 
 
 def philox4x32(counter, key):

@@ -83,11 +83,17 @@ template <int W, int NH = 1> struct Tile {
     static constexpr int kStagesPerBlock = 256 / BK;           // stages per 256-row Rademacher block
     static constexpr int kChunksPerRow = BNT / 8;              // 16-byte chunks per octet of rows in the LDS image
 };
+// internal "distribution" of the product kernel: the A fragments were written to memory beforehand (sketch_fragments_kernel)
+constexpr int kFromMemory = 2;
+constexpr int kFragAhead = 4;               // MFMA steps a fragment load runs ahead of its use (registers: 4 x 4 dwords)
 constexpr int kPhiloxRounds = 10;
 #ifndef FEWBIT_GAUSSIAN_ROUNDS
 #define FEWBIT_GAUSSIAN_ROUNDS 10
 #endif
 constexpr int kGaussianRounds = FEWBIT_GAUSSIAN_ROUNDS;
+#ifndef FEWBIT_GAUSSIAN_GEN
+#define FEWBIT_GAUSSIAN_GEN 2       // 2: xoshiro128++ streams seeded by Philox (the definition of S); 1: one Philox call per fragment (the
+#endif                              // round-4 definition, kept as a measurement build only -- the host model no longer follows it)
 #ifndef FEWBIT_SKETCH_ABLATE
 #define FEWBIT_SKETCH_ABLATE 0      // measurement builds only (results are WRONG): 1 no staging of M after the first stage, 2 no barrier in
 #endif                              // the K loop, 4 constant A operand (no generator), 8 B fragments read once (no LDS reads in the loop)
@@ -130,6 +136,21 @@ __host__ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, ui
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// ---- xoshiro128++ 1.0 (Blackman & Vigna, "Scrambled linear pseudorandom number generators", 2019; public-domain reference
+// xoshiro128plusplus.c) -- 9 one-cycle VALU instructions per 32 bits, against ~85 issue slots for the 128 bits of a Philox call
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+__host__ __device__ __forceinline__ uint32_t xoshiro128pp(uint32_t (&s)[4]) {
+    const uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
+    const uint32_t t = s[1] << 9;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl32(s[3], 11);
+    return result;
+}
+
 // operand type of the matrix pipe: bf16 for bf16 AND fp32 inputs (fp32 is rounded to bf16 while it is staged), fp16 for fp16
 template <int DT> struct Operand {
     typedef bf16x8 frag;
@@ -167,29 +188,33 @@ template <int DT> __device__ __forceinline__ u32x4 rademacher_fragment(const uin
     return a;
 }
 
-// Gaussian: 8 normals from one Philox call (4 words -> 4 Box-Muller pairs)
+// Gaussian: one 32-bit word -> one Box-Muller pair (u1 = (x + 0.5) / 65536 is ONE exact v_fma_f32)
 __device__ __forceinline__ void box_muller(uint32_t w, float &z0, float &z1) {
-    const float u1 = (static_cast<float>(w & 0xffffu) + 0.5f) * (1.0f / 65536.0f);
+    const float u1 = __builtin_fmaf(static_cast<float>(w & 0xffffu), 1.0f / 65536.0f, 0.5f / 65536.0f);
     const float u2 = static_cast<float>(w >> 16) * (1.0f / 65536.0f);
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // -2 ln u = -2 ln2 * log2 u
     z0 = rad * __builtin_amdgcn_cosf(u2);                                                             // v_cos_f32 takes turns
     z1 = rad * __builtin_amdgcn_sinf(u2);
 }
 
+// one 32-bit word -> two normals, packed as one operand dword (even element low)
+template <int DT> __device__ __forceinline__ uint32_t gaussian_pair(uint32_t w) {
+    if constexpr ((FEWBIT_SKETCH_ABLATE & 16) != 0) {          // (measurement only: no Box-Muller, the raw bits as operands)
+        return (w & 0x007f007fu) | Operand<DT>::kOnes;
+    } else {
+        float z0, z1;
+        box_muller(w, z0, z1);
+        return Operand<DT>::pack(z0, z1);
+    }
+}
+
+// the round-4 definition (FEWBIT_GAUSSIAN_GEN == 1, measurement builds): one Philox call per fragment
 template <int DT> __device__ __forceinline__ u32x4 gaussian_fragment(uint32_t row, uint32_t octet, Key key) {
     uint32_t w[4];
     philox4x32<kGaussianRounds>(row, octet, 0u, 1u, key, w);
     u32x4 a;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if constexpr ((FEWBIT_SKETCH_ABLATE & 16) != 0) {      // (measurement only: no Box-Muller, the raw bits as operands)
-            a[q] = (w[q] & 0x007f007fu) | Operand<DT>::kOnes;
-        } else {
-            float z0, z1;
-            box_muller(w[q], z0, z1);
-            a[q] = Operand<DT>::pack(z0, z1);
-        }
-    }
+    for (int q = 0; q < 4; ++q) a[q] = gaussian_pair<DT>(w[q]);
     return a;
 }
 
@@ -223,19 +248,21 @@ template <int DT> __device__ __forceinline__ RawPiece<DT> load_raw(const uint8_t
     return r;
 }
 
-// interior stage: `base` = first row of the stage (wave-uniform), off[j] = byte offset of this thread's piece of row j
-template <int DT> __device__ __forceinline__ void fetch_fast(RawBlock<DT> &b, const uint8_t *base, const uint32_t (&off)[8]) {
+// interior stage: `base` = first row of the stage, `row_bytes` = one row of M (both wave-uniform: the row advance stays in
+// scalar registers and the loads take the scalar-base form), off0 = byte offset of this thread's piece of the stage's row 0
+template <int DT> __device__ __forceinline__ void fetch_fast(RawBlock<DT> &b, const uint8_t *base, size_t row_bytes, uint32_t off0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) b.row[j] = load_raw<DT>(base + off[j]);
+    for (int j = 0; j < 8; ++j) b.row[j] = load_raw<DT>(base + j * row_bytes + off0);
 }
 
 // last stage of a slice: rows >= rows_left are clamped to the last valid one (and zeroed by finish_block)
-template <int DT> __device__ __forceinline__ void fetch_clamped(RawBlock<DT> &b, const uint8_t *base, const uint32_t (&off)[8], int row0, int rows_left) {
+template <int DT> __device__ __forceinline__ void fetch_clamped(RawBlock<DT> &b, const uint8_t *base, size_t row_bytes, uint32_t off0, int row0, int rows_left) {
+    const uint32_t rb = static_cast<uint32_t>(row_bytes);      // (a stage spans less than 2 GiB: checked by the host)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int last = rows_left - 1 - row0;                 // index (within this thread's octet) of the last valid row; may be < 0
         const int jc = j <= last ? j : (last > 0 ? last : 0);
-        const uint32_t o = last >= 0 ? off[0] + static_cast<uint32_t>(jc) * (off[1] - off[0]) : off[0] - static_cast<uint32_t>(row0) * (off[1] - off[0]);
+        const uint32_t o = last >= 0 ? off0 + static_cast<uint32_t>(jc) * rb : off0 - static_cast<uint32_t>(row0) * rb;
         b.row[j] = load_raw<DT>(base + o);
     }
 }
@@ -302,13 +329,14 @@ template <int PITCH> __device__ __forceinline__ void store_block(const Block8x8 
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
-// grid: x = column tiles (256 features), y = row tiles of S (128), z = K slices.  PARTIAL: write fp32 partial sums to
+// grid: x = column tiles (256 features), y = row tiles of S (128), z = K slices.  PARTIAL (1: fp32, 2: bf16): write partial sums to
 // `out` + z * proj * features (no scale); otherwise the scaled result in the dtype of M.
-template <int DIST, int DT, bool PARTIAL, bool RAGGED, int W, int NH>
+template <int DIST, int DT, int PARTIAL, bool RAGGED, int W, int NH>
 __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restrict__ m, size_t rows, size_t features, size_t ld, size_t proj,
                                                            Key key, const Key *__restrict__ key_dev, float scale, void *__restrict__ out,
-                                                           size_t kslice) {
+                                                           size_t kslice, const void *__restrict__ frags, size_t frag_steps) {
     typedef Tile<W, NH> T_;
+    static_assert(DIST != kFromMemory || NH == 1, "fragments from memory: the one-half tiles only");
     if (key_dev != nullptr) key = *key_dev;          // the seed of a call inside a hipGraph lives in device memory (one scalar load)
     constexpr int BM = T_::BM, BK = T_::BK, BNT = T_::BNT, RG = T_::RG, kStageBytes = T_::kStageBytes, kSteps = T_::kSteps;
     constexpr int kPerBlock = T_::kStagesPerBlock, kABytes = T_::kABytes;
@@ -336,9 +364,8 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     // this thread's piece of row j of a stage: byte offset from the stage's first row (column 0 for a chunk outside the matrix)
     constexpr int ES = elem_size<DT>();
     const size_t col = n0 + 8 * sfc < features ? n0 + 8 * sfc : 0;
-    uint32_t off[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) off[j] = static_cast<uint32_t>(((8 * so + j) * ld + col) * ES);
+    const uint32_t off0 = static_cast<uint32_t>((8 * so * ld + col) * ES);
+    const size_t row_bytes = ld * ES;
     const uint8_t *stage_base = static_cast<const uint8_t *>(m) + k_begin * ld * ES;
     const size_t stage_bytes = static_cast<size_t>(BK) * ld * ES;
 
@@ -349,8 +376,8 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
         if constexpr (RAGGED) {
             if (mode != 2) fetch_guarded<DT>(raw, m, ld, k_begin + st * BK + 8 * so, k_end, n0 + 8 * sfc, features);
         } else {
-            if (mode == 0) fetch_fast<DT>(raw, stage_base + st * stage_bytes, off);
-            else if (mode == 1) fetch_clamped<DT>(raw, stage_base + st * stage_bytes, off, 8 * so, static_cast<int>(klen - st * BK));
+            if (mode == 0) fetch_fast<DT>(raw, stage_base + st * stage_bytes, row_bytes, off0);
+            else if (mode == 1) fetch_clamped<DT>(raw, stage_base + st * stage_bytes, row_bytes, off0, 8 * so, static_cast<int>(klen - st * BK));
         }
     };
     auto stage_to_lds = [&](size_t st, int mode, uint8_t *buf) __attribute__((always_inline)) {
@@ -372,16 +399,56 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     uint32_t signs[4] = {0u, 0u, 0u, 0u};
     // A fragment of step `ks` of stage `st` for this lane's row of S (Rademacher: `signs` must hold the Philox words of the
     // 256-row block that contains the stage)
+    // Gaussian: the xoshiro128++ streams of this lane's 256-row block -- stream t feeds operand dwords 2t and 2t + 1 of every
+    // step, two words per step, in step order.  One column half (NH == 1): the wave runs both streams; two halves: wave (g, hf)
+    // runs stream hf only and its partner the other one (each writes its 8 bytes of every fragment, publish_fragments)
+    constexpr bool kStreams = DIST == FEWBIT_SKETCH_GAUSSIAN && FEWBIT_GAUSSIAN_GEN == 2;
+    uint32_t gs[NH > 1 ? 1 : 2][4];
     auto refresh_signs = [&](size_t st) __attribute__((always_inline)) {
         if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) {
             // one Philox call covers this lane's 16 MFMA steps = 256 rows = 4 or 2 stages (k_begin is a multiple of 256)
             if ((st & (kPerBlock - 1)) == 0 && !(FEWBIT_SKETCH_ABLATE & 4))
                 philox4x32(srow, static_cast<uint32_t>(2 * ((k_begin + st * BK) >> 8) + h), 0u, 0u, key, signs);
+        } else if constexpr (kStreams) {
+            if ((st & (kPerBlock - 1)) == 0 && !(FEWBIT_SKETCH_ABLATE & 4)) {
+                const uint32_t blk = static_cast<uint32_t>(2 * ((k_begin + st * BK) >> 8) + h);
+                if constexpr (NH > 1) {
+                    philox4x32<kGaussianRounds>(srow, blk, static_cast<uint32_t>(hf), 2u, key, gs[0]);
+                } else {
+                    philox4x32<kGaussianRounds>(srow, blk, 0u, 2u, key, gs[0]);
+                    philox4x32<kGaussianRounds>(srow, blk, 1u, 2u, key, gs[1]);
+                }
+            }
         }
     };
+    // fragments from memory (kFromMemory): fragment (row block rb, step g) is 64 lanes x 16 bytes at ((rb * frag_steps + g) * 64
+    // + lane) * 16 -- a wave walks 1 KiB per step through consecutive addresses; the load of step g + kFragAhead goes out when
+    // step g's fragment is taken from its register (the buffer ends in kFragAhead steps of padding)
+    const uint8_t *afrag = nullptr;
+    u32x4 apre[DIST == kFromMemory ? kFragAhead : 1];
+    if constexpr (DIST == kFromMemory) {
+        static_assert(kSteps % kFragAhead == 0, "the register ring is indexed by the step within a stage");
+        afrag = static_cast<const uint8_t *>(frags) + (((m0 / 32 + rg) * frag_steps + (k_begin >> 4)) * 64 + lane) * 16;
+#pragma unroll
+        for (int d = 0; d < kFragAhead; ++d) apre[d] = *reinterpret_cast<const u32x4 *>(afrag + static_cast<size_t>(d) * 1024);
+    }
+    // (Gaussian streams and fragments from memory: called ONCE per step and in step order -- every call consumes the next words)
     auto make_fragment = [&](size_t st, int ks) __attribute__((always_inline)) -> u32x4 {
-        if constexpr ((FEWBIT_SKETCH_ABLATE & 4) != 0) return u32x4{srow, srow, srow, srow};
+        if constexpr (DIST == kFromMemory) {
+            const u32x4 a = apre[ks % kFragAhead];
+            apre[ks % kFragAhead] = *reinterpret_cast<const u32x4 *>(afrag + (st * kSteps + ks + kFragAhead) * 1024);
+            return a;
+        }
+        else if constexpr ((FEWBIT_SKETCH_ABLATE & 4) != 0) return u32x4{srow, srow, srow, srow};
         else if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) return rademacher_fragment<DT>(signs, static_cast<int>((st & (kPerBlock - 1)) * kSteps + ks));
+        else if constexpr (kStreams && NH == 1) {
+            u32x4 a;
+            a[0] = gaussian_pair<DT>(xoshiro128pp(gs[0]));
+            a[1] = gaussian_pair<DT>(xoshiro128pp(gs[0]));
+            a[2] = gaussian_pair<DT>(xoshiro128pp(gs[NH > 1 ? 0 : 1]));
+            a[3] = gaussian_pair<DT>(xoshiro128pp(gs[NH > 1 ? 0 : 1]));
+            return a;
+        }
         else return gaussian_fragment<DT>(srow, static_cast<uint32_t>(((k_begin + st * BK) >> 3) + 2 * ks + h), key);
     };
     // NH = 2: this wave's share of the A fragments of stage `st` (steps [hf * kSteps / 2, (hf + 1) * kSteps / 2)) -> the LDS
@@ -393,11 +460,23 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
                 if (st >= nstages) return;             // block-uniform (the interior loop never gets here)
             }
             refresh_signs(st);
+            if constexpr (kStreams && (FEWBIT_SKETCH_ABLATE & 4) == 0) {
+                // this wave's stream = dwords 2 hf, 2 hf + 1 of EVERY step of the stage (8 of the fragment's 16 bytes)
+                typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #pragma unroll
-            for (int j = 0; j < kSteps / NH; ++j) {
-                const int ks = hf * (kSteps / NH) + j;
-                const u32x4 a = make_fragment(st, ks);
-                *reinterpret_cast<u32x4 *>(abuf + (st & 1) * kABytes + ((rg * kSteps + ks) * 64 + lane) * 16) = a;
+                for (int ks = 0; ks < kSteps; ++ks) {
+                    u32x2 a;
+                    a[0] = gaussian_pair<DT>(xoshiro128pp(gs[0]));
+                    a[1] = gaussian_pair<DT>(xoshiro128pp(gs[0]));
+                    *reinterpret_cast<u32x2 *>(abuf + (st & 1) * kABytes + ((rg * kSteps + ks) * 64 + lane) * 16 + 8 * hf) = a;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < kSteps / NH; ++j) {
+                    const int ks = hf * (kSteps / NH) + j;
+                    const u32x4 a = make_fragment(st, ks);
+                    *reinterpret_cast<u32x4 *>(abuf + (st & 1) * kABytes + ((rg * kSteps + ks) * 64 + lane) * 16) = a;
+                }
             }
         }
     };
@@ -455,7 +534,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
                     bq[t] = *reinterpret_cast<const u32x4 *>(frag + (static_cast<size_t>(2 * (ks + 1)) * BNT + 32 * t) * 16);
                 if constexpr (FAST) {
                     if (ks == first) store_feature<BNT>(blk, nxt, so, sfc, t);
-                    if (ks == first + 1) raw.row[t] = load_raw<DT>(next_base + off[t]);
+                    if (ks == first + 1) raw.row[t] = load_raw<DT>(next_base + t * row_bytes + off0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -494,7 +573,18 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
         float v[8];
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = acc[t][r];
-        if constexpr (PARTIAL) {
+        if constexpr (PARTIAL == 2) {                 // bf16 partial sums (bf16 results only: half the bytes of the slices' round trip)
+            uint16_t *p = static_cast<uint16_t *>(out) + (static_cast<size_t>(blockIdx.z) * proj + i) * features + f;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = Operand<FEWBIT_BF16>::pack(v[2 * e], v[2 * e + 1]);
+            if (f + 8 <= features) {
+                typedef u32x4 __attribute__((aligned(2))) u32x4u;
+                *reinterpret_cast<u32x4u *>(p) = o;
+            } else {
+                for (int e = 0; e < 8; ++e) if (f + e < features) p[e] = static_cast<uint16_t>(o[e >> 1] >> (16 * (e & 1)));
+            }
+        } else if constexpr (PARTIAL == 1) {
             float *p = static_cast<float *>(out) + (static_cast<size_t>(blockIdx.z) * proj + i) * features + f;
             if (f + 8 <= features) {
                 typedef f32x4 __attribute__((aligned(4))) f32x4u;
@@ -580,6 +670,48 @@ template <int DT> __global__ __launch_bounds__(256) void sketch_reduce4_kernel(c
     }
 }
 
+// bf16 partial sums -> bf16 result: the same fixed order, sums in fp32, one scale, one rounding.  8 elements (16 bytes) per thread
+// and slice when n % 8 == 0 (VEC), else one element
+template <bool VEC> __global__ __launch_bounds__(256) void sketch_reduce_bf16_kernel(const uint16_t *__restrict__ ws, size_t n, int slices, float scale, uint16_t *__restrict__ out) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    auto up = [](uint32_t hw) { return __builtin_bit_cast(float, hw << 16); };
+    if constexpr (VEC) {
+        const size_t n8 = n / 8;
+        if (i >= n8) return;
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(ws) + i;
+        float s[8];
+        {
+            const u32x4 v = src[0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[2 * e] = up(v[e] & 0xffffu); s[2 * e + 1] = up(v[e] >> 16); }
+        }
+        int z = 1;
+        for (; z + 4 <= slices; z += 4) {
+            u32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = src[static_cast<size_t>(z + k) * n8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[2 * e] += up(v[k][e] & 0xffffu); s[2 * e + 1] += up(v[k][e] >> 16); }
+        }
+        for (; z < slices; ++z) {
+            const u32x4 v = src[static_cast<size_t>(z) * n8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[2 * e] += up(v[e] & 0xffffu); s[2 * e + 1] += up(v[e] >> 16); }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = Operand<FEWBIT_BF16>::pack(s[2 * e] * scale, s[2 * e + 1] * scale);
+        reinterpret_cast<u32x4 *>(out)[i] = o;
+    } else {
+        if (i >= n) return;
+        float s = up(ws[i]);
+        for (int z = 1; z < slices; ++z) s += up(ws[static_cast<size_t>(z) * n + i]);
+        out[i] = static_cast<uint16_t>(Operand<FEWBIT_BF16>::pack(s * scale, 0.0f) & 0xffffu);
+    }
+}
+
 // the matrix itself (test seam and debugging aid; the product path never calls it): out[i][r] = S[row0 + i][col0 + r] as fp32
 template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(Key key, size_t row0, size_t col0, size_t nrows, size_t ncols, int dtype, float *__restrict__ out) {
     const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -593,10 +725,20 @@ template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(
         philox4x32(static_cast<uint32_t>(i), static_cast<uint32_t>(2 * (r >> 8) + h), 0u, 0u, key, w);
         v = ((w[s >> 2] >> (((j & 1) ? 31 : 15) - (4 * (s & 3) + (j >> 1)))) & 1u) ? -1.0f : 1.0f;
     } else {
+        float z0, z1;
+#if FEWBIT_GAUSSIAN_GEN == 2
+        // element j of step s of block r / 256 for octet parity h: word 2 s + (q & 1) of stream q / 2, q = j / 2
+        const int s = static_cast<int>((r & 255) >> 4), h = static_cast<int>((r >> 3) & 1), q = j >> 1;
+        uint32_t st[4];
+        philox4x32<kGaussianRounds>(static_cast<uint32_t>(i), static_cast<uint32_t>(2 * (r >> 8) + h), static_cast<uint32_t>(q >> 1), 2u, key, st);
+        uint32_t w = 0;
+        for (int k = 0; k <= 2 * s + (q & 1); ++k) w = xoshiro128pp(st);
+        box_muller(w, z0, z1);
+#else
         uint32_t w[4];
         philox4x32<kGaussianRounds>(static_cast<uint32_t>(i), static_cast<uint32_t>(r >> 3), 0u, 1u, key, w);
-        float z0, z1;
         box_muller(w[j >> 1], z0, z1);
+#endif
         v = (j & 1) ? z1 : z0;
         // rounded as the product kernel rounds its operand
         if (dtype == FEWBIT_F16) v = static_cast<float>(static_cast<_Float16>(v));
@@ -634,6 +776,45 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ 
     }
 }
 
+// ---- S written to memory once, in MFMA fragment order (the Gaussian sketch of layers wider than one column tile) --------------
+// In the fused kernel every column tile of the grid regenerates the rows of S it multiplies: features / 256 times the generator's
+// work, on the SIMD whose matrix pipe it shares -- measured (scratch/gen_bench.hip, profiles/r05_gen_bench.txt) a Gaussian fragment
+// costs as many issue cycles as the 8 MFMAs it feeds, and VALU work beside an MFMA stream is not free beyond ~4 instructions per
+// MFMA.  So for the Gaussian sketch of a layer wider than one tile, S is generated ONCE by this VALU-only kernel (every element
+// once: ~11 us of VALU time for 3276 x 16384, in practice the ~20 us its 107 MB take to write) into the workspace, as the
+// 16-byte-per-lane A fragments the product kernel's waves consume -- [32-row block of S][MFMA step][lane] -- and the product
+// kernel (kFromMemory) reads them with one coalesced 1 KiB load per wave and step, kFragAhead steps ahead.  The same S as the
+// fused kernel's (same streams, same Box-Muller, same rounding): which path ran is not visible in the result beyond the
+// association of the slices' fp32 sums.  One wave = one 32-row block of S x one 256-row block of M = 16 fragments (16 KiB).
+template <int DIST, int DT>
+__global__ __launch_bounds__(256) void sketch_fragments_kernel(Key key, const Key *__restrict__ key_dev, size_t nblocks, u32x4 *__restrict__ out) {
+    if (key_dev != nullptr) key = *key_dev;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    const size_t b = static_cast<size_t>(blockIdx.x) * 4 + wave, rb = blockIdx.y;
+    if (b >= nblocks) return;
+    const uint32_t srow = static_cast<uint32_t>(32 * rb + c), blk = static_cast<uint32_t>(2 * b + h);
+    u32x4 *dst = out + ((rb * nblocks + b) * 16) * 64 + lane;
+    if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) {
+        uint32_t signs[4];
+        philox4x32(srow, blk, 0u, 0u, key, signs);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) dst[st * 64] = rademacher_fragment<DT>(signs, st);
+    } else {
+        uint32_t g0[4], g1[4];
+        philox4x32<kGaussianRounds>(srow, blk, 0u, 2u, key, g0);
+        philox4x32<kGaussianRounds>(srow, blk, 1u, 2u, key, g1);
+#pragma unroll 4
+        for (int st = 0; st < 16; ++st) {
+            u32x4 a;
+            a[0] = gaussian_pair<DT>(xoshiro128pp(g0));
+            a[1] = gaussian_pair<DT>(xoshiro128pp(g0));
+            a[2] = gaussian_pair<DT>(xoshiro128pp(g1));
+            a[3] = gaussian_pair<DT>(xoshiro128pp(g1));
+            dst[st * 64] = a;
+        }
+    }
+}
+
 // ---- seeds drawn on the device ----------------------------------------------------------------------------------------------
 // A launch recorded in a hipGraph replays its kernel ARGUMENTS: a seed passed by value would give every replay the same S.
 // There the seed comes from device memory instead: `next_seed_kernel` (also recorded) bumps a counter and derives the seed of
@@ -647,14 +828,15 @@ __host__ __device__ __forceinline__ uint64_t mix_seed(uint64_t base, uint64_t co
 }
 
 __global__ void next_seed_kernel(uint64_t *counter, uint64_t base, uint64_t *seed) {
-    const uint64_t count = *counter;
-    *counter = count + 1;
+    // (an atomic bump: one counter per device serves every captured graph, and two graphs may replay on two streams at once)
+    const uint64_t count = atomicAdd(reinterpret_cast<unsigned long long *>(counter), 1ull);
     *seed = mix_seed(base, count);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 struct Plan { unsigned gx, gy, gz; size_t kslice; int waves, halves; };
 struct Seed { Key value; const Key *device; };       // `device` != nullptr: the key is read from there when the kernel runs
+struct Frags { const void *data; size_t steps; };    // A fragments in memory (kFromMemory): `steps` MFMA steps per 32-row block of S
 
 int device_cus() {
     static std::atomic<int> cached[64];
@@ -740,14 +922,17 @@ Plan make_plan(int dist, int dtype, size_t rows, size_t features, size_t proj) {
     return p;
 }
 
-template <int DIST, int DT, bool PARTIAL, int W, int NH = 1>
+template <int DIST, int DT, int PARTIAL, int W, int NH = 1>
 int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out,
-                  hipStream_t s) {
+                  Frags frags, hipStream_t s) {
     const dim3 grid(p.gx, p.gy, p.gz), block(Tile<W, NH>::kThreads);
     constexpr size_t lds = Tile<W, NH>::kLdsBytes;
     auto go = [&](auto kern) -> int {
         if (lds > 65536) {                           // (more than the default limit of a workgroup: opt in once per kernel and device)
-            static std::atomic<unsigned long long> done{0};
+            // (one flag word per KERNEL: the ragged and the plain variant have the same function type, hence share this lambda's
+            // instantiation -- they are told apart by index)
+            static std::atomic<unsigned long long> done_flags[2];
+            std::atomic<unsigned long long> &done = done_flags[ragged ? 1 : 0];
             int dev = 0;
             (void)hipGetDevice(&dev);
             const unsigned long long bit = 1ull << (dev & 63);
@@ -759,34 +944,65 @@ int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t
                 done.fetch_or(bit, std::memory_order_relaxed);
             }
         }
-        hipLaunchKernelGGL(kern, grid, block, lds, s, m, rows, features, ld, proj, key.value, key.device, scale, out, p.kslice);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, m, rows, features, ld, proj, key.value, key.device, scale, out, p.kslice, frags.data, frags.steps);
         return FEWBIT_OK;
     };
     return ragged ? go(sketch_kernel<DIST, DT, PARTIAL, true, W, NH>) : go(sketch_kernel<DIST, DT, PARTIAL, false, W, NH>);
 }
 
+// bf16 partial sums: when the result is bf16 anyway and the rows are sliced, the slices' round trip through memory (written by
+// the product kernel, read back by the reduce kernel -- 2 x gz x proj x features x 4 bytes, the K-independent part of a 768-wide
+// product's time) is made in bf16: each slice's sum is rounded once, the slices are added in fp32 in the same fixed order.  The
+// error of the result grows from one bf16 rounding to about sqrt(2) of one (gz roundings of sums sqrt(gz) times smaller).
+// tune: 0 never, 1 whenever the result is bf16, -1 this policy.
+FEWBIT_HIDDEN std::atomic<long long> g_forced_partial16{-1};
+bool partial16(int dtype, int out_dtype, unsigned gz) {
+    if (dtype != FEWBIT_BF16 || out_dtype != FEWBIT_BF16 || gz <= 1) return false;
+    return g_forced_partial16.load(std::memory_order_relaxed) != 0;
+}
+
+template <int DIST, int DT, int PARTIAL>
+int launch_tile(const Plan &p, bool ragged, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out,
+                Frags frags, hipStream_t s) {
+    if constexpr (DIST != kFromMemory) {
+        if (p.halves == 2) return launch_kernel<DIST, DT, PARTIAL, 8, 2>(p, ragged, m, rows, features, ld, proj, key, scale, out, frags, s);
+    }
+    return p.waves == 8 ? launch_kernel<DIST, DT, PARTIAL, 8>(p, ragged, m, rows, features, ld, proj, key, scale, out, frags, s)
+                        : launch_kernel<DIST, DT, PARTIAL, 4>(p, ragged, m, rows, features, ld, proj, key, scale, out, frags, s);
+}
+
 template <int DIST, int DT>
 int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out, int out_dtype, void *workspace,
-           size_t workspace_bytes, hipStream_t s) {
-    const Plan p = make_plan(DIST, DT, rows, features, proj);
+           size_t workspace_bytes, Frags frags, hipStream_t s) {
+    const Plan p = make_plan(DIST == kFromMemory ? static_cast<int>(FEWBIT_SKETCH_RADEMACHER) : DIST, DT, rows, features, proj);   // (from memory: the one-half tiles)
     const bool ragged = (features % 8) != 0;
     int rc;
     if (p.gz == 1 && out_dtype == DT) {
-        rc = p.halves == 2 ? launch_kernel<DIST, DT, false, 8, 2>(p, ragged, m, rows, features, ld, proj, key, scale, out, s)
-             : p.waves == 8 ? launch_kernel<DIST, DT, false, 8>(p, ragged, m, rows, features, ld, proj, key, scale, out, s)
-                            : launch_kernel<DIST, DT, false, 4>(p, ragged, m, rows, features, ld, proj, key, scale, out, s);
+        rc = launch_tile<DIST, DT, 0>(p, ragged, m, rows, features, ld, proj, key, scale, out, frags, s);
         if (rc != FEWBIT_OK) return rc;
-    } else {                                         // fp32 partial sums, then one pass: sum, scale, round to the result's dtype
-        const size_t need = static_cast<size_t>(p.gz) * proj * features * sizeof(float);
+    } else {                                         // partial sums, then one pass: sum, scale, round to the result's dtype
+        const bool p16 = partial16(DT, out_dtype, p.gz);
+        const size_t n = proj * features;
+        const size_t need = static_cast<size_t>(p.gz) * n * (p16 ? sizeof(uint16_t) : sizeof(float));
         if (workspace == nullptr || workspace_bytes < need)
             return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", need, workspace_bytes);
-        rc = p.halves == 2 ? launch_kernel<DIST, DT, true, 8, 2>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s)
-             : p.waves == 8 ? launch_kernel<DIST, DT, true, 8>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s)
-                            : launch_kernel<DIST, DT, true, 4>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, s);
-        if (rc != FEWBIT_OK) return rc;
-        const size_t n = proj * features;
-        const float *ws = static_cast<const float *>(workspace);
         const int z = static_cast<int>(p.gz);
+        if constexpr (DT == FEWBIT_BF16) {
+            if (p16) {
+                rc = launch_tile<DIST, DT, 2>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, frags, s);
+                if (rc != FEWBIT_OK) return rc;
+                const uint16_t *ws = static_cast<const uint16_t *>(workspace);
+                const bool vec = n % 8 == 0 && (reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
+                if (vec) hipLaunchKernelGGL((sketch_reduce_bf16_kernel<true>), dim3(static_cast<unsigned>((n / 8 + 255) / 256)), dim3(256), 0, s, ws, n, z, scale, static_cast<uint16_t *>(out));
+                else hipLaunchKernelGGL((sketch_reduce_bf16_kernel<false>), dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, ws, n, z, scale, static_cast<uint16_t *>(out));
+                const hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sketch: %s", hipGetErrorString(e));
+                return FEWBIT_OK;
+            }
+        }
+        rc = launch_tile<DIST, DT, 1>(p, ragged, m, rows, features, ld, proj, key, scale, workspace, frags, s);
+        if (rc != FEWBIT_OK) return rc;
+        const float *ws = static_cast<const float *>(workspace);
         const bool vec = n % 4 == 0 && (reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
         auto reduce = [&](auto tag) {
             constexpr int ODT = decltype(tag)::value;
@@ -803,11 +1019,13 @@ int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, 
 
 template <int DIST>
 int launch_dtype(int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out, int out_dtype,
-                 void *workspace, size_t workspace_bytes, hipStream_t s) {
+                 void *workspace, size_t workspace_bytes, Frags frags, hipStream_t s) {
     switch (dtype) {
-    case FEWBIT_F32: return launch<DIST, FEWBIT_F32>(m, rows, features, ld, proj, key, scale, out, out_dtype, workspace, workspace_bytes, s);
-    case FEWBIT_F16: return launch<DIST, FEWBIT_F16>(m, rows, features, ld, proj, key, scale, out, out_dtype, workspace, workspace_bytes, s);
-    case FEWBIT_BF16: return launch<DIST, FEWBIT_BF16>(m, rows, features, ld, proj, key, scale, out, out_dtype, workspace, workspace_bytes, s);
+    case FEWBIT_F32:
+        if constexpr (DIST == kFromMemory) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: fragments from memory need a 16-bit operand");
+        else return launch<DIST, FEWBIT_F32>(m, rows, features, ld, proj, key, scale, out, out_dtype, workspace, workspace_bytes, frags, s);
+    case FEWBIT_F16: return launch<DIST, FEWBIT_F16>(m, rows, features, ld, proj, key, scale, out, out_dtype, workspace, workspace_bytes, frags, s);
+    case FEWBIT_BF16: return launch<DIST, FEWBIT_BF16>(m, rows, features, ld, proj, key, scale, out, out_dtype, workspace, workspace_bytes, frags, s);
     default: return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: unknown dtype %d", dtype);
     }
 }
@@ -822,11 +1040,40 @@ bool converts_first(int dtype, size_t rows, size_t proj) {
     return proj > 1280;
 }
 constexpr size_t kWorkspaceAlign = 256;
-size_t partial_bytes(int dist, int dtype, int out_dtype, size_t rows, size_t features, size_t proj) {
-    const Plan p = make_plan(dist, dtype, rows, features, proj);
-    return (p.gz > 1 || out_dtype != dtype) ? static_cast<size_t>(p.gz) * proj * features * sizeof(float) : 0;
-}
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// S in memory first?  The Gaussian sketch (a fragment costs ~100 issue slots; Rademacher's 8 are not worth a byte of traffic) on
+// the 16-bit pipe, when at least two column tiles would otherwise regenerate it and its fragments (bf16, rows of S padded to
+// 256, rows of M to 256) stay under 1 GiB.  tune: 0 never, 1 whenever possible, -1 this policy.
+FEWBIT_HIDDEN std::atomic<long long> g_forced_materialise{-1};
+size_t fragment_blocks(size_t rows) { return (rows + 255) / 256; }                  // 256-row blocks of M = 16 MFMA steps each
+size_t fragment_row_blocks(size_t proj) { return (proj + 255) / 256 * 8; }          // 32-row blocks of S, padded to whole 256-row tiles
+size_t fragment_bytes(size_t rows, size_t proj) { return (fragment_row_blocks(proj) * fragment_blocks(rows) * 16 + kFragAhead) * 1024; }
+bool materialises(int dist, int operand_dtype, size_t rows, size_t features, size_t proj) {
+    if (dist != FEWBIT_SKETCH_GAUSSIAN || operand_dtype == FEWBIT_F32 || rows == 0) return false;
+    const long long forced = g_forced_materialise.load(std::memory_order_relaxed);
+    if (forced == 0 || fragment_row_blocks(proj) > 65535) return false;
+    if (forced == 1) return true;
+    return features > BN && fragment_bytes(rows, proj) <= (1ull << 30);
+}
+
+// the workspace of one call: [partial sums][bf16 copy of an fp32 M][A fragments of S], each part aligned to kWorkspaceAlign
+struct Layout { int operand_dtype, plan_dist; bool converted, materialised; size_t partial_bytes, copy_off, copy_bytes, frag_off, frag_bytes, total; };
+Layout layout(int dist, int dtype, size_t rows, size_t features, size_t proj) {
+    Layout L{};
+    L.converted = converts_first(dtype, rows, proj);
+    L.operand_dtype = L.converted ? static_cast<int>(FEWBIT_BF16) : dtype;
+    L.materialised = materialises(dist, L.operand_dtype, rows, features, proj);
+    L.plan_dist = L.materialised ? static_cast<int>(FEWBIT_SKETCH_RADEMACHER) : dist;      // (fragments from memory: the one-half tiles' plan)
+    const Plan p = make_plan(L.plan_dist, L.operand_dtype, rows, features, proj);
+    L.partial_bytes = (p.gz > 1 || dtype != L.operand_dtype)
+                          ? static_cast<size_t>(p.gz) * proj * features * (partial16(L.operand_dtype, dtype, p.gz) ? sizeof(uint16_t) : sizeof(float)) : 0;
+    size_t end = L.partial_bytes;
+    if (L.converted) { L.copy_off = round_up(end, kWorkspaceAlign); L.copy_bytes = rows * features * sizeof(uint16_t); end = L.copy_off + L.copy_bytes; }
+    if (L.materialised) { L.frag_off = round_up(end, kWorkspaceAlign); L.frag_bytes = fragment_bytes(rows, proj); end = L.frag_off + L.frag_bytes; }
+    L.total = end;
+    return L;
+}
 
 }  // namespace sketch
 }  // namespace fewbit_hip
@@ -838,9 +1085,7 @@ extern "C" {
 
 size_t fewbit_hip_sketch_workspace(int dist, int dtype, size_t rows, size_t features, size_t proj) {
     if (rows == 0 || features == 0 || proj == 0) return 0;
-    if (converts_first(dtype, rows, proj))           // fp32 partial sums of the bf16-input kernel, then the bf16 copy of M
-        return round_up(partial_bytes(dist, FEWBIT_BF16, FEWBIT_F32, rows, features, proj), kWorkspaceAlign) + rows * features * sizeof(uint16_t);
-    return partial_bytes(dist, dtype, dtype, rows, features, proj);
+    return layout(dist, dtype, rows, features, proj).total;
 }
 
 static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, double scale,
@@ -857,23 +1102,30 @@ static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t 
         if (hipMemsetAsync(out, 0, proj * features * es, s) != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sketch: memset failed");
         return FEWBIT_OK;
     }
-    int in_dtype = dtype;
-    if (converts_first(dtype, rows, proj)) {
-        const size_t head = round_up(partial_bytes(dist, FEWBIT_BF16, FEWBIT_F32, rows, features, proj), kWorkspaceAlign);
-        const size_t need = head + rows * features * sizeof(uint16_t);
-        if (workspace == nullptr || workspace_bytes < need)
-            return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", need, workspace_bytes);
-        uint16_t *copy = reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(workspace) + head);
+    const Layout L = layout(dist, dtype, rows, features, proj);
+    if (L.total != 0 && (workspace == nullptr || workspace_bytes < L.total))
+        return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", L.total, workspace_bytes);
+    uint8_t *ws = static_cast<uint8_t *>(workspace);
+    if (L.converted) {                                // fp32 input, many row tiles: rounded to bf16 once
+        uint16_t *copy = reinterpret_cast<uint16_t *>(ws + L.copy_off);
         const size_t pieces = rows * ((features + 7) / 8);
         hipLaunchKernelGGL(to_bf16_kernel, dim3(static_cast<unsigned>((pieces + 255) / 256)), dim3(256), 0, s, static_cast<const float *>(m), rows, features, ld, copy);
         m = copy;
         ld = features;
-        in_dtype = FEWBIT_BF16;
-        workspace_bytes = head;
+    }
+    const float fscale = static_cast<float>(scale);
+    if (L.materialised) {                             // S once, as A fragments; then the product kernel that reads them
+        const size_t nblocks = fragment_blocks(rows);
+        const dim3 grid(static_cast<unsigned>((nblocks + 3) / 4), static_cast<unsigned>(fragment_row_blocks(proj)));
+        u32x4 *frag = reinterpret_cast<u32x4 *>(ws + L.frag_off);
+        if (L.operand_dtype == FEWBIT_F16) hipLaunchKernelGGL((sketch_fragments_kernel<FEWBIT_SKETCH_GAUSSIAN, FEWBIT_F16>), grid, dim3(256), 0, s, key.value, key.device, nblocks, frag);
+        else hipLaunchKernelGGL((sketch_fragments_kernel<FEWBIT_SKETCH_GAUSSIAN, FEWBIT_BF16>), grid, dim3(256), 0, s, key.value, key.device, nblocks, frag);
+        // (the kFragAhead steps of padding behind the last fragment are read, never used: any bytes will do)
+        return launch_dtype<kFromMemory>(L.operand_dtype, m, rows, features, ld, proj, key, fscale, out, dtype, workspace, L.partial_bytes, Frags{frag, nblocks * 16}, s);
     }
     if (dist == FEWBIT_SKETCH_RADEMACHER)
-        return launch_dtype<FEWBIT_SKETCH_RADEMACHER>(in_dtype, m, rows, features, ld, proj, key, static_cast<float>(scale), out, dtype, workspace, workspace_bytes, s);
-    return launch_dtype<FEWBIT_SKETCH_GAUSSIAN>(in_dtype, m, rows, features, ld, proj, key, static_cast<float>(scale), out, dtype, workspace, workspace_bytes, s);
+        return launch_dtype<FEWBIT_SKETCH_RADEMACHER>(L.operand_dtype, m, rows, features, ld, proj, key, fscale, out, dtype, workspace, L.partial_bytes, Frags{nullptr, 0}, s);
+    return launch_dtype<FEWBIT_SKETCH_GAUSSIAN>(L.operand_dtype, m, rows, features, ld, proj, key, fscale, out, dtype, workspace, L.partial_bytes, Frags{nullptr, 0}, s);
 }
 
 int fewbit_hip_sketch(int dist, int dtype, const void *m, size_t rows, size_t features, size_t ld, size_t proj, uint64_t seed, double scale,
@@ -917,13 +1169,15 @@ int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, si
 
 int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features, size_t proj, char *buf, size_t len) {
     if (buf == nullptr || len == 0) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch_describe: no buffer");
-    const bool converted = converts_first(dtype, rows, proj);
-    const Plan p = make_plan(dist, converted ? FEWBIT_BF16 : dtype, rows, features, proj);
-    snprintf(buf, len, "{\"kernel\": \"sketch_kernel (%dx%d tile, K stage %d, v_mfma_f32_32x32x16)\", \"grid\": [%u, %u, %u], \"threads\": %d, "
-                       "\"k_slice\": %zu, \"lds_bytes\": %d, \"workspace_bytes\": %zu, \"converted_to_bf16_first\": %s}",
-             32 * p.waves / p.halves, 256 * p.halves, 16 * p.waves / p.halves, p.gx, p.gy, p.gz, 64 * p.waves, p.kslice,
-             p.halves == 2 ? Tile<8, 2>::kLdsBytes : 2 * 16 * p.waves * BN * 2, fewbit_hip_sketch_workspace(dist, dtype, rows, features, proj),
-             converted ? "true" : "false");
+    const Layout L = layout(dist, dtype, rows, features, proj);
+    const Plan p = make_plan(L.plan_dist, L.operand_dtype, rows, features, proj);
+    const char *partials = (p.gz > 1 || L.operand_dtype != dtype) ? (partial16(L.operand_dtype, dtype, p.gz) ? "\"bf16\"" : "\"fp32\"") : "null";
+    snprintf(buf, len, "{\"kernel\": \"sketch_kernel (%dx%d tile, K stage %d, v_mfma_f32_32x32x16%s)\", \"grid\": [%u, %u, %u], \"threads\": %d, "
+                       "\"k_slice\": %zu, \"lds_bytes\": %d, \"workspace_bytes\": %zu, \"converted_to_bf16_first\": %s, \"partial_sums\": %s, "
+                       "\"s_fragment_bytes\": %zu}",
+             32 * p.waves / p.halves, 256 * p.halves, 16 * p.waves / p.halves, L.materialised ? ", A fragments of S from memory" : "", p.gx, p.gy, p.gz,
+             64 * p.waves, p.kslice, p.halves == 2 ? Tile<8, 2>::kLdsBytes : 2 * 16 * p.waves * BN * 2, rows == 0 ? 0 : L.total,
+             L.converted ? "true" : "false", partials, L.frag_bytes);
     return FEWBIT_OK;
 }
 
@@ -931,6 +1185,12 @@ void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uin
     uint32_t o[4];
     philox4x32(counter[0], counter[1], counter[2], counter[3], Key{key[0], key[1]}, o);
     for (int i = 0; i < 4; ++i) out[i] = o[i];
+}
+
+void fewbit_hip_xoshiro128pp(uint32_t state[4], uint32_t *out, size_t n) {
+    uint32_t s[4] = {state[0], state[1], state[2], state[3]};
+    for (size_t i = 0; i < n; ++i) out[i] = xoshiro128pp(s);
+    for (int i = 0; i < 4; ++i) state[i] = s[i];
 }
 
 #ifdef FEWBIT_SKETCH_TRACE
@@ -941,6 +1201,18 @@ int fewbit_hip_sketch_debug_trace(unsigned long long *host, size_t count) {
 
 int fewbit_hip_sketch_tune_slices(long long slices) {
     g_forced_slices.store(slices, std::memory_order_relaxed);
+    return FEWBIT_OK;
+}
+
+int fewbit_hip_sketch_tune_partials(long long bf16_partials) {
+    if (bf16_partials < -1 || bf16_partials > 1) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: bf16 partial sums are 0 (never), 1 / -1 (for bf16 results), got %lld", bf16_partials);
+    g_forced_partial16.store(bf16_partials, std::memory_order_relaxed);
+    return FEWBIT_OK;
+}
+
+int fewbit_hip_sketch_tune_materialise(long long materialise) {
+    if (materialise < -1 || materialise > 1) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: materialise is 0 (never), 1 (whenever possible) or -1 (policy), got %lld", materialise);
+    g_forced_materialise.store(materialise, std::memory_order_relaxed);
     return FEWBIT_OK;
 }
 

@@ -468,6 +468,7 @@ struct PackedBackwardNode : public torch::autograd::Node {
     bool host = false;
 
     variable_list apply(variable_list &&grads) override {
+        std::lock_guard<std::mutex> lock(mutex_);      // (as ATen's generated nodes: apply and release_variables exclude each other)
         variable_list out(1);
         const Tensor st = state.unpack();              // raises autograd's own "backward through the graph a second time"
         const Tensor &g = grads[0];
@@ -495,6 +496,9 @@ struct PackedBackwardNode : public torch::autograd::Node {
 template <typename Launch>
 Tensor forward_direct(const Tensor &self, bool inplace, bool host, int step_fn, double p0, const Tensor &levels, Launch &&launch) {
     if (inplace) torch::autograd::check_inplace(self, /*requires_grad=*/true);
+    // forward-mode AD: the packed state holds what BACKWARD needs, there is no jvp -- say so (the torch::autograd::Function route
+    // raises for a tangent too) instead of dropping the tangent silently
+    TORCH_CHECK(!self._fw_grad(/*level=*/0).defined(), "fewbit: forward-mode AD (a tangent on the input) is not implemented for the packed-state operators");
     std::shared_ptr<PackedBackwardNode> node(new PackedBackwardNode(), torch::autograd::deleteNode);
     node->host = host;
     node->step_fn = step_fn;

@@ -108,9 +108,12 @@ def use_native_sketch(on: Optional[bool] = None) -> bool:
 
 
 def _native_sketch_applies(kind: str, mat: torch.Tensor, sketch_dtype) -> bool:
+    """The kernel multiplies on the 16-bit matrix pipe (fp32 input is rounded to bf16, sums are fp32).  ``sketch_dtype=None``
+    (the default) and the 16-bit dtypes take it; an EXPLICIT ``sketch_dtype=torch.float32`` / ``float64`` asks for products of
+    that precision and gets the PyTorch formulation (S drawn into memory, library GEMM in that dtype) instead."""
     return (_NATIVE_SKETCH and _INJECTED is None and kind in ('gaussian', 'rademacher') and mat.device.type == 'cuda'
             and mat.dtype in (torch.float32, torch.float16, torch.bfloat16) and mat.dim() == 2 and mat.shape[0] > 0
-            and sketch_dtype in (None, torch.bfloat16, torch.float16, mat.dtype))
+            and sketch_dtype in (None, torch.bfloat16, torch.float16))
 
 
 def _mix64(a: int, b: int) -> int:
@@ -156,7 +159,13 @@ def _sketch_seed(generator: Optional[torch.Generator], device: torch.device):
     if not torch.cuda.is_current_stream_capturing():
         return _draw_seed(generator)
     from . import cabi
-    return cabi.next_sketch_seed(counter, _draw_seed(generator))
+    # (while capturing, a DEVICE generator is not touched: reading or moving its offset belongs to the graph machinery of
+    # torch.cuda -- the base of the recorded seed kernel comes from the host's default generator instead; a host generator is
+    # used as given.  The counter is one word per device shared by every captured graph: graphs replayed one after the other
+    # see consecutive counts (reproducible), graphs replayed CONCURRENTLY on several streams still get distinct counts -- the
+    # bump is an atomic add -- but which graph gets which is then up to the hardware.)
+    host_gen = generator if generator is None or generator.device.type == 'cpu' else None
+    return cabi.next_sketch_seed(counter, _draw_seed(host_gen))
 
 
 def _native_sketch(kind: str, mat: torch.Tensor, p: int, seed, scale: float) -> torch.Tensor:

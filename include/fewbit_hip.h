@@ -55,7 +55,7 @@ extern "C" {
 /* 1: the quantized-activation path.  2: + fewbit_hip_describe_*, fewbit_hip_tune (added in round 3 without a bump) and the
  * random-projection entry points fewbit_hip_sketch* (round 4).  3: + seeds in device memory (fewbit_hip_sketch_device_seed,
  * fewbit_hip_sketch_next_seed, fewbit_hip_sketch_mix_seed).  Bindings check it and refuse an older library by name. */
-#define FEWBIT_HIP_ABI_VERSION 3
+#define FEWBIT_HIP_ABI_VERSION 4
 
 typedef enum fewbit_status {
     FEWBIT_OK = 0,
@@ -209,8 +209,20 @@ int fewbit_hip_sketch_tune_halves(long long halves);
  * (the result stays fp32, from the fp32 sums; the numbers are the ones the in-kernel conversion gives): 0 never, 1 always,
  * -1 that policy.  fewbit_hip_sketch_workspace already counts the copy. */
 int fewbit_hip_sketch_tune_convert(long long convert);
+/* bf16 results with sliced rows: the slices' partial sums make their round trip through the workspace in bf16 instead of fp32
+ * (half the bytes; each slice's sum is rounded once, the slices are added in fp32 in a fixed order): 0 never, 1 or -1 that
+ * policy.  fewbit_hip_sketch_workspace follows the setting. */
+int fewbit_hip_sketch_tune_partials(long long bf16_partials);
+/* Gaussian sketch of a layer wider than one 256-feature tile: S is generated ONCE, by a VALU-only kernel, into the workspace as the
+ * bf16 / fp16 A fragments of the matrix pipe, and the product kernel reads them back (instead of every column tile regenerating
+ * its rows of S beside its MFMAs): 0 never (always the fused kernel), 1 whenever possible, -1 the policy (features > 256 and the
+ * fragments <= 1 GiB).  The same S either way.  fewbit_hip_sketch_workspace follows the setting. */
+int fewbit_hip_sketch_tune_materialise(long long materialise);
 /* Philox4x32-10 on the HOST (the generator behind S; known-answer tests run it without a GPU) */
 void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+/* xoshiro128++ 1.0 on the HOST (Blackman & Vigna; the stream generator of the Gaussian sketch, seeded by a Philox call per
+ * 256-row block): advances `state` by n steps and writes the n outputs */
+void fewbit_hip_xoshiro128pp(uint32_t state[4], uint32_t *out, size_t n);
 
 #ifdef __cplusplus
 }

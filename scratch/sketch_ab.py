@@ -1,5 +1,5 @@
 """A/B of builds / tile heights of the random-projection kernel in ONE process, interleaved round by round:
-   python scratch/sketch_ab.py dist rows features proj name=lib[@waves=W,slices=Z] ..."""
+   python scratch/sketch_ab.py dist rows features proj name=lib[@waves=W,slices=Z,halves=H,partials=P,mem=M] ..."""
 import ctypes, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); os.chdir(ROOT)
 import torch
@@ -8,7 +8,7 @@ dist, rows, features, proj = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), in
 dtype = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f16': torch.float16}[os.environ.get('DT', 'bf16')]
 m = torch.randn(rows, features, device='cuda').to(dtype)
 o = torch.empty(proj, features, dtype=dtype, device='cuda')
-ws = torch.empty(proj * features * 4 * 16, dtype=torch.uint8, device='cuda')
+ws = torch.empty(proj * features * 4 * 16 + (proj + 256) * (rows + 512) * 2 + (rows * features * 2 if dtype == torch.float32 else 0) + 65536, dtype=torch.uint8, device='cuda')
 vp, sz, i32, dbl, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_double, ctypes.c_uint64
 arms = {}
 for a in sys.argv[5:]:
@@ -17,11 +17,15 @@ for a in sys.argv[5:]:
     lib = ctypes.CDLL(os.path.abspath(path))
     lib.fewbit_hip_sketch.argtypes = [i32, i32, vp, sz, sz, sz, sz, u64, dbl, vp, vp, sz, vp]
     lib.fewbit_hip_sketch_tune_slices.argtypes = [ctypes.c_longlong]; lib.fewbit_hip_sketch_tune_waves.argtypes = [ctypes.c_longlong]; lib.fewbit_hip_sketch_tune_halves.argtypes = [ctypes.c_longlong]
+    if hasattr(lib, 'fewbit_hip_sketch_tune_partials'): lib.fewbit_hip_sketch_tune_partials.argtypes = [ctypes.c_longlong]
+    if hasattr(lib, 'fewbit_hip_sketch_tune_materialise'): lib.fewbit_hip_sketch_tune_materialise.argtypes = [ctypes.c_longlong]
     arms[name] = (lib, dict(kv.split('=') for kv in own.split(',') if kv))
 stream = torch.cuda.current_stream().cuda_stream
 def run(name, reps):
     lib, st = arms[name]
     lib.fewbit_hip_sketch_tune_slices(int(st.get('slices', -1))); lib.fewbit_hip_sketch_tune_waves(int(st.get('waves', -1))); lib.fewbit_hip_sketch_tune_halves(int(st.get('halves', -1)))
+    if hasattr(lib, 'fewbit_hip_sketch_tune_partials'): lib.fewbit_hip_sketch_tune_partials(int(st.get('partials', -1)))
+    if hasattr(lib, 'fewbit_hip_sketch_tune_materialise'): lib.fewbit_hip_sketch_tune_materialise(int(st.get('mem', -1)))
     args = (cabi.SKETCH_DISTS.index(dist), cabi.DTYPES[dtype], m.data_ptr(), rows, features, features, proj, 1234, 1.0 / proj, o.data_ptr(), ws.data_ptr(), ws.numel(), stream)
     for _ in range(2): assert lib.fewbit_hip_sketch(*args) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -4,7 +4,10 @@ evaluated with numpy -- a pure function of (seed, row, column).  Test infrastruc
     philox4x32(c0..c3, k0, k1)      Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
                                     SC'11), vectorised over arrays of counters
     rademacher(seed, rows, cols)    +-1 matrix S[rows x cols]
-    gaussian(seed, rows, cols, dt)  N(0,1) by Box-Muller on 16-bit uniforms, rounded to the operand dtype `dt`
+    xoshiro128pp(state)             xoshiro128++ 1.0 (Blackman & Vigna 2019, reference xoshiro128plusplus.c), vectorised
+    gaussian(seed, rows, cols, dt)  N(0,1) by Box-Muller on 16-bit uniforms, rounded to the operand dtype `dt`; the 32-bit words
+                                    come from two xoshiro128++ streams per (row, 256-column block, octet parity), each seeded
+                                    by one Philox call
 """
 import numpy as np
 import torch
@@ -42,13 +45,45 @@ def rademacher(seed: int, nrows: int, ncols: int, row0: int = 0, col0: int = 0) 
     return torch.from_numpy(np.where(bit == 1, -1.0, 1.0).astype(np.float32))
 
 
+def xoshiro128pp(state):
+    """one step for arrays of states (a list of four uint64 arrays holding 32-bit values): returns (output, new state)"""
+    s0, s1, s2, s3 = state
+
+    def rotl(x, k):
+        return ((x << np.uint64(k)) | (x >> np.uint64(32 - k))) & M32
+
+    result = (rotl((s0 + s3) & M32, 7) + s0) & M32
+    t = (s1 << np.uint64(9)) & M32
+    s2 = s2 ^ s0
+    s3 = s3 ^ s1
+    s1 = s1 ^ s2
+    s0 = s0 ^ s3
+    s2 = s2 ^ t
+    s3 = rotl(s3, 11)
+    return result, [s0, s1, s2, s3]
+
+
+def gaussian_words(seed: int, i, r):
+    """the 32-bit word behind S[i][r] (arrays, broadcast against each other): with b = r // 256, s = (r % 256) // 16,
+    h = (r // 8) % 2, q = (r % 8) // 2: output number 2 s + q % 2 of the xoshiro128++ stream whose state is
+    philox(i, 2 b + h, q // 2, 2) -- stream q // 2 feeds operand dwords 2 (q // 2) and 2 (q // 2) + 1 of every MFMA step of the block"""
+    i, r = np.broadcast_arrays(np.asarray(i, dtype=np.uint64), np.asarray(r, dtype=np.uint64))
+    s, h, q = (r % 256) // 16, (r // 8) % 2, (r % 8) // 2
+    state = list(philox4x32(i, 2 * (r // 256) + h, q // 2, 2, *_key(seed)))
+    n = (2 * s + q % 2).astype(np.int64)
+    word = np.zeros(i.shape, dtype=np.uint64)
+    for k in range(int(n.max()) + 1 if n.size else 0):
+        out, state = xoshiro128pp(state)
+        word = np.where(n == k, out, word)
+    return word
+
+
 def gaussian(seed: int, nrows: int, ncols: int, dtype: torch.dtype = torch.bfloat16, row0: int = 0, col0: int = 0,
              rounded: bool = True) -> torch.Tensor:
     i = (row0 + np.arange(nrows, dtype=np.uint64))[:, None]
     r = (col0 + np.arange(ncols, dtype=np.uint64))[None, :]
     j = r % 8
-    words = philox4x32(i, r // 8, 0, 1, *_key(seed))
-    w = np.choose((j // 2).astype(np.int64) + np.zeros(i.shape, dtype=np.int64), words)
+    w = gaussian_words(seed, i, r)
     u1 = ((w & np.uint64(0xffff)).astype(np.float64) + 0.5) / 65536.0
     u2 = (w >> np.uint64(16)).astype(np.float64) / 65536.0
     rad = np.sqrt(-2.0 * np.log(u1))

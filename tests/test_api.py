@@ -33,7 +33,7 @@ def test_native_libraries_load_and_export_the_abi():
     # pure host helpers of the ABI may be called without a GPU
     L = cabi.lib()
     header_version = int(re.search(r"#define FEWBIT_HIP_ABI_VERSION (\d+)", header).group(1))
-    assert L.fewbit_hip_abi_version() == header_version == cabi.ABI_VERSION == 3
+    assert L.fewbit_hip_abi_version() == header_version == cabi.ABI_VERSION == 4
     assert [L.fewbit_hip_bitwidth(v) for v in (2, 3, 4, 5, 8, 9, 16, 256)] == [1, 2, 2, 3, 3, 4, 4, 8]
     assert L.fewbit_hip_state_nbytes(16777216, 3) == 6291456 and L.fewbit_hip_state_nbytes(9, 3) == 6
     assert fewbit_amd.native_loaded(), fewbit_amd.native_error()

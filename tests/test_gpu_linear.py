@@ -155,6 +155,23 @@ def test_sketch_dtype_keeps_a_16_bit_projection_of_an_fp32_layer(kind, monkeypat
     assert float((grads['bf16'] - want).abs().max()) <= 2e-2 * scale
 
 
+def test_an_explicit_fp32_sketch_dtype_opts_out_of_the_16_bit_kernel(monkeypatch):
+    """sketch_dtype=None (default) and the 16-bit dtypes run on the gfx950 kernel, whose operands are 16-bit; an explicit
+    sketch_dtype=torch.float32 asks for fp32 products and gets the PyTorch formulation (the reference's arithmetic)"""
+    import fewbit_amd.linear as L
+    calls = []
+    native = L._native_sketch
+    monkeypatch.setattr(L, '_native_sketch', lambda *a, **k: (calls.append(a[0]), native(*a, **k))[1])
+    x = torch.randn(300, 48, device=DEV, requires_grad=True)
+    w = torch.randn(24, 48, device=DEV, requires_grad=True)
+    for sd, expect in ((None, 2), (torch.bfloat16, 2), (torch.float32, 0), (torch.float64, 0)):
+        calls.clear()
+        fewbit.functional.linear_grp(x, w, None, proj_dim=64, matmul='gaussian', sketch_dtype=sd).sum().backward()
+        assert len(calls) == expect, (sd, calls)                  # forward + backward sketches
+        assert w.grad is not None and w.grad.dtype == torch.float32
+        w.grad = None
+
+
 def test_native_sketch_replays_from_generators_and_can_be_switched_off():
     import fewbit_amd.linear as L
     x = torch.randn(512, 64, device=DEV, requires_grad=True)

@@ -57,23 +57,74 @@ def _product_case(dist, dtype, rows, features, proj, seed, ld=None, scale=1.0):
     # fp32 accumulation of exact products (+ for Gaussian one operand step on a few entries), then one rounding to `dtype`
     out_eps = {torch.float32: 2.0**-22, torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}[dtype]
     slack = (2.0**-8 if dist == 'gaussian' else 0.0) * bound / max(rows, 1)**0.5 * 8
+    plan = cabi.describe_sketch(dist, rows, features, proj, dtype)
+    if plan['partial_sums'] == 'bf16':           # every slice's sum makes its way to the reduce kernel rounded to bf16: at most 2^-8 of it each
+        assert dtype == torch.bfloat16 and plan['grid'][2] > 1
+        ks = plan['k_slice']
+        slack = slack + abs(scale) * 2.0**-8 * sum((S[:, z:z + ks] @ mm[z:z + ks]).abs() for z in range(0, rows, ks)) * 1.01
     floor = 2.0**-24 if dtype == torch.float16 else 1e-30          # fp16 results below 6e-5 are subnormal: steps of 2^-24
     assert bool((err <= out_eps * want.abs() + 1e-5 * bound + slack + floor).all()), (dist, dtype, rows, features, proj, float((err / (bound + 1e-30)).max()))
     return got
 
 
-@pytest.mark.parametrize('halves', (1, 2))
+@pytest.mark.parametrize('path', ('fused', 'fused_halves', 'memory'))
 @pytest.mark.parametrize('dist', ('rademacher', 'gaussian'))
 @pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16, torch.float16))
-def test_product_equals_the_model_matrix_times_m(dist, dtype, halves):
-    """`halves` = 2: the 128 x 512 tile, whose wave pairs hand each other their A fragments through LDS"""
-    cabi.tune_sketch_halves(halves)
+def test_product_equals_the_model_matrix_times_m(dist, dtype, path):
+    """`fused`: S generated inside the product kernel; `fused_halves`: the same on the 128 x 512 tile, whose wave pairs hand each
+    other their A fragments through LDS; `memory`: (Gaussian) S written to the workspace once as MFMA fragments and read back by
+    the product kernel -- the same S, the same products"""
+    cabi.tune_sketch_halves(2 if path == 'fused_halves' else 1)
+    cabi.tune_sketch_materialise(1 if path == 'memory' else 0)
     try:
         for rows, features, proj in ((64, 256, 128), (100, 37, 5), (1000, 264, 130), (257, 8, 1), (4096, 512, 256), (3000, 770, 200), (2048, 1024, 300)):
+            plan = cabi.describe_sketch(dist, rows, features, proj, dtype)
+            from_memory = path == 'memory' and dist == 'gaussian' and (dtype != torch.float32 or plan['converted_to_bf16_first'])
+            assert (plan['s_fragment_bytes'] > 0) == from_memory == ('from memory' in plan['kernel']), plan
+            if from_memory:
+                assert plan['s_fragment_bytes'] == (-(-proj // 256) * 8 * -(-rows // 256) * 16 + 4) * 1024 and plan['workspace_bytes'] >= plan['s_fragment_bytes']
             _product_case(dist, dtype, rows, features, proj, seed=rows + 17)
         _product_case(dist, dtype, 512, 100, 64, seed=3, ld=136, scale=0.125)         # a strided view, a scale
     finally:
         cabi.tune_sketch_halves(-1)
+        cabi.tune_sketch_materialise(-1)
+
+
+def test_gaussian_fragments_from_memory_are_the_fused_kernels_matrix():
+    """the policy (Gaussian, 16-bit operand, more than one column tile): S once into the workspace, product kernel reads it -- bit
+    for bit the fused kernel's result when both slice the rows alike, deterministic, also for fp32 input that is rounded to bf16
+    first and for a device-resident seed"""
+    assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 3072, 3276)['kernel']
+    assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 768, 3276)['kernel']
+    assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 768, 3276, torch.float32)['kernel']            # (converted to bf16 first)
+    assert 'from memory' not in cabi.describe_sketch('gaussian', 16384, 768, 1000, torch.float32)['kernel']        # (fp32 operand staged in the kernel)
+    assert 'from memory' not in cabi.describe_sketch('gaussian', 16384, 256, 3276)['kernel']                       # one column tile: nothing to share
+    assert 'from memory' not in cabi.describe_sketch('rademacher', 16384, 3072, 3276)['kernel']
+    assert cabi.describe_sketch('gaussian', 2**21, 768, 2**10)['s_fragment_bytes'] == 0                             # 4 GiB of fragments: the fused kernel
+    g = torch.Generator().manual_seed(9)
+    try:
+        for dtype, rows, features, proj, z in ((torch.bfloat16, 5000, 776, 300, 2), (torch.float16, 2049, 520, 257, 1), (torch.float32, 3000, 384, 1400, 3)):
+            m = torch.randn(rows, features, generator=g).to(dtype).to(DEV)
+            cabi.tune_sketch_slices(z)
+            cabi.tune_sketch_halves(1)
+            got = {}
+            for mat in (0, 1):
+                cabi.tune_sketch_materialise(mat)
+                cabi.tune_sketch_waves(8)                    # the same tile and slicing for both: the same fp32 sums in the same order
+                assert ('from memory' in cabi.describe_sketch('gaussian', rows, features, proj, dtype)['kernel']) == bool(mat)
+                got[mat] = cabi.sketch('gaussian', m, proj, 77, 0.5)
+                assert torch.equal(got[mat], cabi.sketch('gaussian', m, proj, 77, 0.5))
+            assert torch.equal(got[0], got[1]), (dtype, float((got[0].float() - got[1].float()).abs().max()))
+            cabi.tune_sketch_waves(4)
+            assert torch.allclose(cabi.sketch('gaussian', m, proj, 77, 0.5).float(), got[1].float(), rtol=2e-2, atol=0.5)
+            word = torch.tensor([77], dtype=torch.int64, device=DEV)
+            cabi.tune_sketch_waves(8)
+            assert torch.equal(cabi.sketch('gaussian', m, proj, word, 0.5), got[1])
+    finally:
+        cabi.tune_sketch_slices(-1)
+        cabi.tune_sketch_halves(-1)
+        cabi.tune_sketch_waves(-1)
+        cabi.tune_sketch_materialise(-1)
 
 
 def test_row_slices_are_deterministic_and_agree():
@@ -99,6 +150,7 @@ def test_row_slices_are_deterministic_and_agree():
                 outs[(dist, w)] = cabi.sketch(dist, m, 200, 42)
         cabi.tune_sketch_waves(-1)
         cabi.tune_sketch_halves(2)                       # the 128 x 512 tile (A fragments shared through LDS), both sketches
+        cabi.tune_sketch_materialise(0)
         for dist in ('rademacher', 'gaussian'):
             assert '128x512' in cabi.describe_sketch(dist, 8192, 384, 200)['kernel']
             outs[(dist, 'wide')] = cabi.sketch(dist, m, 200, 42)
@@ -109,10 +161,53 @@ def test_row_slices_are_deterministic_and_agree():
         cabi.tune_sketch_slices(-1)
         cabi.tune_sketch_waves(-1)
         cabi.tune_sketch_halves(-1)
+        cabi.tune_sketch_materialise(-1)
     plan = cabi.describe_sketch('rademacher', 16384, 3072, 1638)
     assert plan['threads'] in (256, 512) and plan['grid'][0] == 12 and plan['grid'][1] == -(-1638 // (plan['threads'] // 2)) and plan['grid'][2] >= 1
-    plan = cabi.describe_sketch('gaussian', 16384, 3072, 1638)
-    assert '128x512' in plan['kernel'] and plan['grid'][:2] == [6, 13] and plan['lds_bytes'] == 163840
+    plan = cabi.describe_sketch('gaussian', 16384, 3072, 1638)                       # the policy: S from memory, the Rademacher plan's tile
+    assert 'from memory' in plan['kernel'] and plan['grid'][0] == 12 and plan['s_fragment_bytes'] == (7 * 8 * 64 * 16 + 4) * 1024
+    try:
+        cabi.tune_sketch_materialise(0)                                              # the fused kernel: the 128 x 512 tile for wide 16-bit layers
+        plan = cabi.describe_sketch('gaussian', 16384, 3072, 1638)
+        assert '128x512' in plan['kernel'] and plan['grid'][:2] == [6, 13] and plan['lds_bytes'] == 163840 and plan['s_fragment_bytes'] == 0
+    finally:
+        cabi.tune_sketch_materialise(-1)
+
+
+def test_bf16_partial_sums_of_sliced_bf16_products():
+    """bf16 result + sliced rows: the slices' sums cross the workspace in bf16 (half the bytes), are added in fp32 in slice order,
+    deterministic; against fp32 partial sums the result moves by at most the roundings of the slices' sums"""
+    m = torch.randn(8192, 392, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).to(DEV)
+    try:
+        for dist in ('rademacher', 'gaussian'):
+            for z in (2, 4, 7):
+                cabi.tune_sketch_slices(z)
+                got = {}
+                for p16 in (0, 1):
+                    cabi.tune_sketch_partials(p16)
+                    plan = cabi.describe_sketch(dist, 8192, 392, 200)
+                    assert plan['partial_sums'] == ('bf16' if p16 else 'fp32') and plan['grid'][2] == z
+                    assert plan['workspace_bytes'] == z * 200 * 392 * (2 if p16 else 4) == cabi.sketch_workspace_bytes(dist, 8192, 392, 200)
+                    got[p16] = cabi.sketch(dist, m, 200, 11, 0.5)
+                    assert torch.equal(got[p16], cabi.sketch(dist, m, 200, 11, 0.5))
+                ks = plan['k_slice']
+                S = cabi.sketch_matrix(dist, torch.bfloat16, 11, 200, 8192).double()
+                parts = sum((S[:, k:k + ks] @ m[k:k + ks].double()).abs() for k in range(0, 8192, ks))
+                want = 0.5 * (S @ m.double())
+                err = (got[1].double() - want).abs()
+                assert bool((err <= 2.0**-8 * want.abs() + 0.5 * 2.0**-8 * parts * 1.01 + 1e-3).all()), (dist, z, float(err.max()))
+                assert not torch.equal(got[0], got[1]) and float((got[0].float() - got[1].float()).abs().max()) < 0.5 * float(parts.max()) * 2.0**-7
+            # a ragged feature count takes the element-wise reduce kernel, an fp16 / fp32 result keeps fp32 partial sums
+            cabi.tune_sketch_partials(-1)
+            cabi.tune_sketch_slices(3)
+            _product_case(dist, torch.bfloat16, 3000, 389, 130, seed=4)
+            assert cabi.describe_sketch(dist, 8192, 392, 200, torch.float16)['partial_sums'] == 'fp32'
+            assert cabi.describe_sketch(dist, 8192, 392, 200, torch.float32)['partial_sums'] == 'fp32'
+        cabi.tune_sketch_slices(1)
+        assert cabi.describe_sketch('rademacher', 8192, 392, 200)['partial_sums'] is None
+    finally:
+        cabi.tune_sketch_slices(-1)
+        cabi.tune_sketch_partials(-1)
 
 
 def test_empty_and_degenerate_shapes():
@@ -187,6 +282,8 @@ def test_seeded_fuzz_of_shapes_dtypes_strides_and_tiles():
     import random
     rnd = random.Random(20260402)
     rnd_convert = random.Random(7)                       # (its own stream: the cases above keep their sequence)
+    rnd_partials = random.Random(8)
+    rnd_memory = random.Random(9)
     edges_r = (1, 7, 8, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 3000)
     edges_f = (1, 8, 9, 40, 255, 256, 257, 264, 511, 512, 520, 768, 1032)
     edges_p = (1, 31, 32, 33, 127, 128, 129, 255, 256, 257, 300)
@@ -200,6 +297,8 @@ def test_seeded_fuzz_of_shapes_dtypes_strides_and_tiles():
             cabi.tune_sketch_halves(rnd.choice((-1, 1, 2)))
             cabi.tune_sketch_slices(rnd.choice((-1, 1, 2, 3)))
             cabi.tune_sketch_convert(rnd_convert.choice((-1, 0, 1)))         # fp32 input: one conversion pass first, or not
+            cabi.tune_sketch_partials(rnd_partials.choice((-1, 0, 1)))       # bf16 result, sliced rows: bf16 or fp32 partial sums
+            cabi.tune_sketch_materialise(rnd_memory.choice((-1, 0, 1)))      # Gaussian: S from memory, or generated in the product kernel
             ld = features + rnd.choice((0, 0, 8, 3)) if features > 1 else None
             _product_case(dist, dtype, rows, features, proj, seed=rnd.getrandbits(64), ld=ld if ld != features else None,
                           scale=rnd.choice((1.0, 1.0 / proj, -0.5)))
@@ -208,6 +307,8 @@ def test_seeded_fuzz_of_shapes_dtypes_strides_and_tiles():
         cabi.tune_sketch_halves(-1)
         cabi.tune_sketch_slices(-1)
         cabi.tune_sketch_convert(-1)
+        cabi.tune_sketch_partials(-1)
+        cabi.tune_sketch_materialise(-1)
 
 
 def test_fp32_input_converted_to_bf16_first_gives_the_same_products():
@@ -240,7 +341,7 @@ def test_fp32_input_converted_to_bf16_first_gives_the_same_products():
         cabi.tune_sketch_convert(-1)
 
 
-def test_sketch_and_randomized_layer_capture_into_a_hip_graph():
+def test_sketch_and_randomized_layer_capture_into_a_hip_graph(monkeypatch):
     """no call of the path synchronises or reads back from the device: the kernel (and a whole randomized layer step with its seed
     drawn on the host) can be captured once and replayed on new data"""
     import fewbit
@@ -269,6 +370,10 @@ def test_sketch_and_randomized_layer_capture_into_a_hip_graph():
         for _ in range(2):
             gw, = torch.autograd.grad(lin(x).sum(), lin.weight)
     torch.cuda.current_stream().wait_stream(side)
+    from fewbit_amd import linear
+    base = 0x5eed5eed
+    monkeypatch.setattr(linear, '_draw_seed', lambda generator: base)
+    c0 = int(linear._replay_counter(torch.device(DEV)))
     g2 = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g2):
         gw, = torch.autograd.grad(lin(x).sum(), lin.weight)
@@ -276,9 +381,12 @@ def test_sketch_and_randomized_layer_capture_into_a_hip_graph():
         x.copy_(torch.randn(512, 64, device=DEV))
     g2.replay()
     torch.cuda.synchronize()
+    # the replayed step IS the eager estimate for the seed the recorded seed kernel derived (bias and all): p = 128 of 512 rows
+    seed = cabi.mix_sketch_seed(base, c0)
+    want = cabi.sketch('rademacher', torch.ones(512, 32, device=DEV), 128, seed).T @ cabi.sketch('rademacher', x.detach(), 128, seed, 1.0 / 128)
+    assert gw.shape == want.shape and torch.allclose(gw, want, rtol=1e-4, atol=1e-3), float((gw - want).abs().max())
     exact = torch.ones(512, 32, device=DEV).T @ x.detach()
-    assert gw.shape == exact.shape and float(torch.linalg.norm(gw - exact) / torch.linalg.norm(exact)) < 4.0     # one draw: ~sqrt(rows/p) = 2
-    assert float(gw.abs().max()) > 0
+    assert float(torch.linalg.norm(gw - exact) / torch.linalg.norm(exact)) < 4.0          # (and an estimate of the exact product: one draw ~ sqrt(rows / p) = 2)
 
 
 def _splitmix(base, count):

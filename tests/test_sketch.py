@@ -1,5 +1,5 @@
-"""The generator behind the random-projection kernel, without a GPU: Philox4x32-10 of the library (host entry point of the
-C-ABI) and of the numpy model against the published known-answer vectors, and the statistics of the model's matrices."""
+"""The generator behind the random-projection kernel, without a GPU: Philox4x32-10 and xoshiro128++ of the library (host entry
+points of the C-ABI) and of the numpy model against published known-answer vectors, and the statistics of the model's matrices."""
 import numpy as np
 import torch
 
@@ -35,6 +35,37 @@ def test_model_round_loop_against_the_seven_round_vectors_too():
         assert tuple(int(g[0]) for g in got) == want
 
 
+def test_xoshiro128pp_known_answers_library_and_model():
+    """xoshiro128++ 1.0: the outputs of Blackman & Vigna's reference xoshiro128plusplus.c from the state {1, 2, 3, 4} (the vector
+    the rand_xoshiro crate's tests carry); the first two are checkable by hand: rotl(1 + 4, 7) + 1 = 641, then the state is
+    {7, 0, 1026, 12288} and rotl(7 + 12288, 7) + 7 = 1573767"""
+    want = [641, 1573767, 3222811527, 3517856514, 836907274, 4247214768, 3867114732, 1355841295, 495546011, 621204420]
+    out, state = cabi.xoshiro128pp((1, 2, 3, 4), 10)
+    assert list(out) == want
+    more, _ = cabi.xoshiro128pp(state, 5)                                  # the state handed back continues the stream
+    assert list(cabi.xoshiro128pp((1, 2, 3, 4), 15)[0]) == want + list(more)
+    st = [np.array([v, v + 10], dtype=np.uint64) for v in (1, 2, 3, 4)]
+    got = []
+    for _ in range(10):
+        w, st = ref.xoshiro128pp(st)
+        got.append(int(w[0]))
+    assert got == want
+    assert int(w[1]) == cabi.xoshiro128pp((11, 12, 13, 14), 10)[0][-1]     # the model on arrays == the library lane by lane
+
+
+def test_gaussian_words_are_the_streams_the_kernel_header_defines():
+    """S[i][r] for the Gaussian sketch: word 2 s + q % 2 of stream q // 2 of (row i, block r // 256, octet parity (r // 8) % 2),
+    the stream seeded by philox(i, 2 (r // 256) + h, q // 2, 2) -- spelled out with the library's host generators"""
+    seed = 0x0123456789abcdef
+    key = (seed & 0xffffffff, seed >> 32)
+    for i, r in ((0, 0), (5, 7), (5, 8), (77, 255), (77, 256), (3, 1000), (2**31 + 1, 2**33 + 8 * 37 + 5)):
+        s, h, q = (r % 256) // 16, (r // 8) % 2, (r % 8) // 2
+        state = cabi.philox4x32((i & 0xffffffff, (2 * (r // 256) + h) & 0xffffffff, q // 2, 2), key)
+        n = 2 * s + q % 2
+        want = cabi.xoshiro128pp(state, n + 1)[0][n]
+        assert int(ref.gaussian_words(seed, np.array([[i]]), np.array([[r]]))[0, 0]) == want, (i, r)
+
+
 def test_seed_derivation_of_captured_launches_on_the_host():
     """fewbit_hip_sketch_mix_seed (what the recorded seed kernel computes from its counter): splitmix64's finaliser"""
     M = 2**64 - 1
@@ -63,6 +94,10 @@ def test_model_matrices_have_the_right_moments_and_are_functions_of_the_seed():
     kurt = float((G**4).mean() / G.var()**2)
     assert abs(kurt - 3.0) < 0.1
     assert abs(float((G[:, 0::2] * G[:, 1::2]).mean())) < 0.01                                   # the two halves of a Box-Muller pair
+    # consecutive words of a stream (elements 0,1 against 2,3 of an octet), the two streams (0..3 against 4..7), consecutive
+    # steps of a block (columns r and r + 16) and the two octet parities (r and r + 8): uncorrelated, also in their squares
+    for a, b in ((G[:, 0::8], G[:, 2::8]), (G[:, 1::8], G[:, 5::8]), (G[:, :-16], G[:, 16:]), (G[:, :-8], G[:, 8:]), (G[:-1], G[1:])):
+        assert abs(float((a * b).mean())) < 0.012 and abs(float((a * a * b * b).mean()) - 1.0) < 0.04
     # windows of the same matrix agree with the whole; another seed gives another matrix
     assert torch.equal(ref.rademacher(7, 10, 300, row0=5, col0=250), ref.rademacher(7, 96, 2048)[5:15, 250:550])
     assert torch.equal(ref.gaussian(7, 10, 300, row0=5, col0=250), ref.gaussian(7, 96, 2048)[5:15, 250:550])
