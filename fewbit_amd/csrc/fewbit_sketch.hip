@@ -85,7 +85,13 @@ template <int W, int NH = 1> struct Tile {
 };
 // internal "distribution" of the product kernel: the A fragments were written to memory beforehand (sketch_fragments_kernel)
 constexpr int kFromMemory = 2;
-constexpr int kFragAhead = 4;               // MFMA steps a fragment load runs ahead of its use (registers: 4 x 4 dwords)
+#ifndef FEWBIT_FRAG_AHEAD
+#define FEWBIT_FRAG_AHEAD 4
+#endif
+constexpr int kFragAhead = FEWBIT_FRAG_AHEAD;  // MFMA steps a fragment load runs ahead of its use (registers: 4 dwords per step)
+#ifndef FEWBIT_SKETCH_XCD
+#define FEWBIT_SKETCH_XCD 1                  // workgroup -> tile order that keeps a tile's neighbours on one XCD (0: the grid's own order)
+#endif
 constexpr int kPhiloxRounds = 10;
 #ifndef FEWBIT_GAUSSIAN_ROUNDS
 #define FEWBIT_GAUSSIAN_ROUNDS 10
@@ -344,8 +350,28 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int rg = NH > 1 ? wave % RG : wave, hf = NH > 1 ? wave / RG : 0;    // row group of S, column half of the tile
-    const size_t n0 = static_cast<size_t>(blockIdx.x) * BNT, m0 = static_cast<size_t>(blockIdx.y) * BM;
-    const size_t k_begin = static_cast<size_t>(blockIdx.z) * kslice;
+    // Which tile this workgroup takes.  The dispatcher is observed to put workgroup b (x fastest) on XCD b % 8, each XCD with its own
+    // 4 MiB L2 (MI355X_MICROARCH.md): in the grid's own order the 32 workgroups an XCD runs at a time are scattered over all column
+    // tiles and some 20 row tiles, and every one of them pulls its stage of M (and its fragments of S) into that L2 separately.
+    // Here XCD i walks a contiguous range of a tile list ordered slice-major, then in groups of 8 row tiles x all column tiles,
+    // row tile fastest: its 32 concurrent workgroups cover ~4 column tiles x 8 row tiles of ONE slice, (4 + 8) instead of ~(12 + 20)
+    // operand streams per stage.  A bijection of the grid (T1 in cdna_hip_programming.md); speed only, placement is no contract.
+    // Used by the kernel that reads S from memory (two operand streams per workgroup: 16384 x 3072, p = 3276: 330.5 -> 324.9 us,
+    // 768 wide 115.1 -> 109.6); the kernels that generate S themselves measured 1.5-3 % SLOWER with it (Rademacher 280.7 ->
+    // 285.5 / 82.9 -> 84.4 us) and keep the grid's own order (profiles/r05_sketch_xcd_prefetch_ab.txt).
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if constexpr (FEWBIT_SKETCH_XCD != 0 && DIST == kFromMemory) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+        const unsigned orig = bx + gx * (by + gy * bz), xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+        const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+        constexpr unsigned GY = 8;
+        const unsigned t = v % (gx * gy), grp = t / (GY * gx), first = grp * GY, gh = gy - first < GY ? gy - first : GY, u = t - grp * GY * gx;
+        bz = v / (gx * gy);
+        by = first + u % gh;
+        bx = u / gh;
+    }
+    const size_t n0 = static_cast<size_t>(bx) * BNT, m0 = static_cast<size_t>(by) * BM;
+    const size_t k_begin = static_cast<size_t>(bz) * kslice;
     const size_t k_end = k_begin + kslice < rows ? k_begin + kslice : rows;
     const uint32_t srow = static_cast<uint32_t>(m0 + 32 * rg + c);            // this lane's row of S
 
@@ -425,18 +451,19 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     // + lane) * 16 -- a wave walks 1 KiB per step through consecutive addresses; the load of step g + kFragAhead goes out when
     // step g's fragment is taken from its register (the buffer ends in kFragAhead steps of padding)
     const uint8_t *afrag = nullptr;
-    u32x4 apre[DIST == kFromMemory ? kFragAhead : 1];
+    constexpr int kAhead = kFragAhead < kSteps ? kFragAhead : kSteps;      // (at most one stage ahead)
+    u32x4 apre[DIST == kFromMemory ? kAhead : 1];
     if constexpr (DIST == kFromMemory) {
-        static_assert(kSteps % kFragAhead == 0, "the register ring is indexed by the step within a stage");
+        static_assert(kSteps % kAhead == 0, "the register ring is indexed by the step within a stage");
         afrag = static_cast<const uint8_t *>(frags) + (((m0 / 32 + rg) * frag_steps + (k_begin >> 4)) * 64 + lane) * 16;
 #pragma unroll
-        for (int d = 0; d < kFragAhead; ++d) apre[d] = *reinterpret_cast<const u32x4 *>(afrag + static_cast<size_t>(d) * 1024);
+        for (int d = 0; d < kAhead; ++d) apre[d] = *reinterpret_cast<const u32x4 *>(afrag + static_cast<size_t>(d) * 1024);
     }
     // (Gaussian streams and fragments from memory: called ONCE per step and in step order -- every call consumes the next words)
     auto make_fragment = [&](size_t st, int ks) __attribute__((always_inline)) -> u32x4 {
         if constexpr (DIST == kFromMemory) {
-            const u32x4 a = apre[ks % kFragAhead];
-            apre[ks % kFragAhead] = *reinterpret_cast<const u32x4 *>(afrag + (st * kSteps + ks + kFragAhead) * 1024);
+            const u32x4 a = apre[ks % kAhead];
+            apre[ks % kAhead] = *reinterpret_cast<const u32x4 *>(afrag + (st * kSteps + ks + kAhead) * 1024);
             return a;
         }
         else if constexpr ((FEWBIT_SKETCH_ABLATE & 4) != 0) return u32x4{srow, srow, srow, srow};
@@ -574,7 +601,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = acc[t][r];
         if constexpr (PARTIAL == 2) {                 // bf16 partial sums (bf16 results only: half the bytes of the slices' round trip)
-            uint16_t *p = static_cast<uint16_t *>(out) + (static_cast<size_t>(blockIdx.z) * proj + i) * features + f;
+            uint16_t *p = static_cast<uint16_t *>(out) + (static_cast<size_t>(bz) * proj + i) * features + f;
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = Operand<FEWBIT_BF16>::pack(v[2 * e], v[2 * e + 1]);
@@ -585,7 +612,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
                 for (int e = 0; e < 8; ++e) if (f + e < features) p[e] = static_cast<uint16_t>(o[e >> 1] >> (16 * (e & 1)));
             }
         } else if constexpr (PARTIAL == 1) {
-            float *p = static_cast<float *>(out) + (static_cast<size_t>(blockIdx.z) * proj + i) * features + f;
+            float *p = static_cast<float *>(out) + (static_cast<size_t>(bz) * proj + i) * features + f;
             if (f + 8 <= features) {
                 typedef f32x4 __attribute__((aligned(4))) f32x4u;
                 *reinterpret_cast<f32x4u *>(p) = f32x4{v[0], v[1], v[2], v[3]};
@@ -872,7 +899,7 @@ double plan_slices(size_t tiles, size_t slots, size_t rows, long long forced, si
     return best_cost;
 }
 
-Plan make_plan(int dist, int dtype, size_t rows, size_t features, size_t proj) {
+Plan make_plan(int dist, int dtype, size_t rows, size_t features, size_t proj, bool one_half = false) {
     const long long forced_z = g_forced_slices.load(std::memory_order_relaxed), forced_w = g_forced_waves.load(std::memory_order_relaxed);
     const long long forced_h = g_forced_halves.load(std::memory_order_relaxed);
     const size_t cus = static_cast<size_t>(device_cus());
@@ -884,6 +911,7 @@ Plan make_plan(int dist, int dtype, size_t rows, size_t features, size_t proj) {
     bool wide = dist == FEWBIT_SKETCH_GAUSSIAN && dtype != FEWBIT_F32 && features >= 1024 && (features % (2 * BN) == 0 || features >= 2048);
     if (forced_h == 1) wide = false;
     if (forced_h == 2) wide = true;
+    if (one_half) wide = false;                      // (fragments from memory: the product kernel has the one-half tiles only)
     if (wide) {
         p.waves = 8;
         p.halves = 2;
@@ -974,7 +1002,7 @@ int launch_tile(const Plan &p, bool ragged, const void *m, size_t rows, size_t f
 template <int DIST, int DT>
 int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, Seed key, float scale, void *out, int out_dtype, void *workspace,
            size_t workspace_bytes, Frags frags, hipStream_t s) {
-    const Plan p = make_plan(DIST == kFromMemory ? static_cast<int>(FEWBIT_SKETCH_RADEMACHER) : DIST, DT, rows, features, proj);   // (from memory: the one-half tiles)
+    const Plan p = make_plan(DIST == kFromMemory ? static_cast<int>(FEWBIT_SKETCH_RADEMACHER) : DIST, DT, rows, features, proj, DIST == kFromMemory);
     const bool ragged = (features % 8) != 0;
     int rc;
     if (p.gz == 1 && out_dtype == DT) {
@@ -1065,7 +1093,7 @@ Layout layout(int dist, int dtype, size_t rows, size_t features, size_t proj) {
     L.operand_dtype = L.converted ? static_cast<int>(FEWBIT_BF16) : dtype;
     L.materialised = materialises(dist, L.operand_dtype, rows, features, proj);
     L.plan_dist = L.materialised ? static_cast<int>(FEWBIT_SKETCH_RADEMACHER) : dist;      // (fragments from memory: the one-half tiles' plan)
-    const Plan p = make_plan(L.plan_dist, L.operand_dtype, rows, features, proj);
+    const Plan p = make_plan(L.plan_dist, L.operand_dtype, rows, features, proj, L.materialised);
     L.partial_bytes = (p.gz > 1 || dtype != L.operand_dtype)
                           ? static_cast<size_t>(p.gz) * proj * features * (partial16(L.operand_dtype, dtype, p.gz) ? sizeof(uint16_t) : sizeof(float)) : 0;
     size_t end = L.partial_bytes;
@@ -1170,7 +1198,7 @@ int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, si
 int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features, size_t proj, char *buf, size_t len) {
     if (buf == nullptr || len == 0) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch_describe: no buffer");
     const Layout L = layout(dist, dtype, rows, features, proj);
-    const Plan p = make_plan(L.plan_dist, L.operand_dtype, rows, features, proj);
+    const Plan p = make_plan(L.plan_dist, L.operand_dtype, rows, features, proj, L.materialised);
     const char *partials = (p.gz > 1 || L.operand_dtype != dtype) ? (partial16(L.operand_dtype, dtype, p.gz) ? "\"bf16\"" : "\"fp32\"") : "null";
     snprintf(buf, len, "{\"kernel\": \"sketch_kernel (%dx%d tile, K stage %d, v_mfma_f32_32x32x16%s)\", \"grid\": [%u, %u, %u], \"threads\": %d, "
                        "\"k_slice\": %zu, \"lds_bytes\": %d, \"workspace_bytes\": %zu, \"converted_to_bf16_first\": %s, \"partial_sums\": %s, "

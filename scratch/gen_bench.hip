@@ -1,7 +1,7 @@
 // micro-benchmark behind the Gaussian sketch's generator budget (round 5): how many VALU instructions of which class fit beside
 // a v_mfma_f32_32x32x16_bf16 stream on one SIMD, with one and with two waves per SIMD, and what whole generator candidates cost
 // when they are placed (a) as one clump in front of a step's 8 MFMAs (what the product kernel does) or (b) woven between them.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scratch/gen_bench scratch/gen_bench.hip && scratch/gen_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scratch/bin/gen_bench scratch/gen_bench.hip && scratch/bin/gen_bench
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

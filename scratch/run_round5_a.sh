@@ -2,7 +2,7 @@
 # round 5, call a: generator micro-benchmark; sketch tests on the new Gaussian definition + bf16 partial sums; A/B against the round-4 generator
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 300 scratch/gen_bench > gpurun_out/r05a_gen_bench.txt 2>&1; tail -5 gpurun_out/r05a_gen_bench.txt
+timeout 300 scratch/bin/gen_bench > gpurun_out/r05a_gen_bench.txt 2>&1; tail -5 gpurun_out/r05a_gen_bench.txt
 timeout 900 python -m pytest tests/test_gpu_sketch.py tests/test_gpu_linear.py -x -q 2>&1 | tail -15 | tee gpurun_out/r05a_tests.log
 P=fewbit_amd/libfewbit_hip.so; G1=scratch/libfewbit_hip_g1.so
 {

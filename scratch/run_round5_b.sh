@@ -2,7 +2,7 @@
 # round 5, call b: wave-specialisation probe; the Gaussian sketch with S written to memory once (fragments) against the fused kernel
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 300 scratch/gen_bench > gpurun_out/r05b_gen_bench.txt 2>&1; tail -8 gpurun_out/r05b_gen_bench.txt
+timeout 300 scratch/bin/gen_bench > gpurun_out/r05b_gen_bench.txt 2>&1; tail -8 gpurun_out/r05b_gen_bench.txt
 timeout 1200 python -m pytest tests/test_gpu_sketch.py tests/test_gpu_linear.py -x -q 2>&1 | tail -15 | tee gpurun_out/r05b_tests.log
 P=fewbit_amd/libfewbit_hip.so
 {

@@ -60,10 +60,10 @@ for dt in fp32 bf16; do
     done
 done
 python3 tools/summarize_profiles.py "$R" "$RAW" "$OUT" insitu > "$RAW/insitu.log" 2>&1
-if [ -x scratch/stream_bench ]; then
-    scratch/stream_bench 32 > "$OUT/${R}_stream_bench_32MiB.txt" 2>&1
-    scratch/stream_bench 128 > "$OUT/${R}_stream_bench_128MiB.txt" 2>&1
-    scratch/stream_bench 4 > "$OUT/${R}_stream_bench_4MiB.txt" 2>&1
+if [ -x scratch/bin/stream_bench ]; then
+    scratch/bin/stream_bench 32 > "$OUT/${R}_stream_bench_32MiB.txt" 2>&1
+    scratch/bin/stream_bench 128 > "$OUT/${R}_stream_bench_128MiB.txt" 2>&1
+    scratch/bin/stream_bench 4 > "$OUT/${R}_stream_bench_4MiB.txt" 2>&1
 fi
 python3 scratch/hostcost.py > "$RAW/hostcost.log" 2>&1 && cp gpurun_out/hostcost.json "$OUT/${R}_hostcost.json"
 # 7. the random-projection kernel: TFLOP/s per shape against torch.randn/randint + torch.matmul, the README
