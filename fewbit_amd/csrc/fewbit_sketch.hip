@@ -781,9 +781,9 @@ template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(
 // result still written as fp32 from the fp32 sums (measured, 16384 rows: p = 3276: -10 % at 768 features, -9...-19 % at 3072;
 // p = 1638: -14 % / break-even; profiles/r04_sketch_preconvert.txt).  The products are the same numbers either way: both
 // round M to bf16 with the same round-to-nearest-even conversion.
-__global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ m, size_t rows, size_t features, size_t ld, uint16_t *__restrict__ out) {
+// piece i (8 consecutive features of one row) of the conversion
+__device__ __forceinline__ void to_bf16_piece(size_t i, const float *__restrict__ m, size_t rows, size_t features, size_t ld, uint16_t *__restrict__ out) {
     const size_t per_row = (features + 7) / 8;
-    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= rows * per_row) return;
     const size_t r = i / per_row, f = (i % per_row) * 8;
     const float *src = m + r * ld + f;
@@ -802,6 +802,9 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ 
         for (size_t e = 0; f + e < features; ++e) dst[e] = static_cast<uint16_t>(Operand<FEWBIT_BF16>::pack(src[e], 0.0f) & 0xffffu);
     }
 }
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ m, size_t rows, size_t features, size_t ld, uint16_t *__restrict__ out) {
+    to_bf16_piece(static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x, m, rows, features, ld, out);
+}
 
 // ---- S written to memory once, in MFMA fragment order (the Gaussian sketch of layers wider than one column tile) --------------
 // In the fused kernel every column tile of the grid regenerates the rows of S it multiplies: features / 256 times the generator's
@@ -814,10 +817,9 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float *__restrict__ 
 // fused kernel's (same streams, same Box-Muller, same rounding): which path ran is not visible in the result beyond the
 // association of the slices' fp32 sums.  One wave = one 32-row block of S x one 256-row block of M = 16 fragments (16 KiB).
 template <int DIST, int DT>
-__global__ __launch_bounds__(256) void sketch_fragments_kernel(Key key, const Key *__restrict__ key_dev, size_t nblocks, u32x4 *__restrict__ out) {
-    if (key_dev != nullptr) key = *key_dev;
+__device__ __forceinline__ void fragments_of_block(Key key, size_t b4, size_t rb, size_t nblocks, u32x4 *__restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-    const size_t b = static_cast<size_t>(blockIdx.x) * 4 + wave, rb = blockIdx.y;
+    const size_t b = b4 * 4 + wave;
     if (b >= nblocks) return;
     const uint32_t srow = static_cast<uint32_t>(32 * rb + c), blk = static_cast<uint32_t>(2 * b + h);
     u32x4 *dst = out + ((rb * nblocks + b) * 16) * 64 + lane;
@@ -841,6 +843,15 @@ __global__ __launch_bounds__(256) void sketch_fragments_kernel(Key key, const Ke
         }
     }
 }
+template <int DIST, int DT>
+__global__ __launch_bounds__(256) void sketch_fragments_kernel(Key key, const Key *__restrict__ key_dev, size_t nblocks, u32x4 *__restrict__ out) {
+    if (key_dev != nullptr) key = *key_dev;
+    fragments_of_block<DIST, DT>(key, blockIdx.x, blockIdx.y, nblocks, out);
+}
+// (Tried and not kept, round 5: the fp32 -> bf16 pass of an fp32 input and S's fragments prepared by ONE launch whose workgroups were
+// interleaved in proportion, on the idea that one job is bound by memory and the other by VALU issue: 16384 x 768 fp32, p = 3276:
+// 132.7 against 130.1 us as two launches, 3072 wide 386.0 against 393.9, RoBERTa-base fp32 1.080x against 1.077x -- the generator's
+// 107 MB of stores and the conversion's 75 MB already share the memory system; profiles/r05_sketch_prepare_ab.txt.)
 
 // ---- seeds drawn on the device ----------------------------------------------------------------------------------------------
 // A launch recorded in a hipGraph replays its kernel ARGUMENTS: a seed passed by value would give every replay the same S.

@@ -199,6 +199,15 @@ def test_row_slices_are_deterministic_and_agree():
         cabi.tune_sketch_materialise(-1)
 
 
+def test_fp32_input_rounded_first_with_gaussian_fragments_from_memory():
+    """fp32 input with many row tiles + Gaussian S from memory (the path of an fp32 RoBERTa layer): conversion pass, fragment pass,
+    product from the two; ragged widths, a row stride, a very long and a very short input"""
+    for rows, features, proj, ld in ((3000, 770, 1400, None), (520, 264, 1300, 272), (70000, 40, 1290, None), (300, 1032, 2000, 1040)):
+        assert cabi.describe_sketch('gaussian', rows, features, proj, torch.float32)['converted_to_bf16_first'] is True
+        _product_case('gaussian', torch.float32, rows, features, proj, seed=rows, ld=ld)
+        assert ('from memory' in cabi.describe_sketch('gaussian', rows, features, proj, torch.float32)['kernel']) == (features > 256)
+
+
 def test_bf16_partial_sums_of_sliced_bf16_products():
     """bf16 result + sliced rows: the slices' sums cross the workspace in bf16 (half the bytes), are added in fp32 in slice order,
     deterministic; against fp32 partial sums the result moves by at most the roundings of the slices' sums"""

@@ -12,7 +12,7 @@
 #      micro-benchmark, host cost per call, clock-transient timeline, the fp32 ULP histogram written by the GPU test-suite
 #   6. RoBERTa-base step (both routes) and the rocprofv3 kernel stats of the few-bit kernels inside it
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
 export TMPDIR=/tmp
@@ -73,8 +73,15 @@ for v in "fp32 gaussian" "fp32 gaussian --torch-sketch" "fp32 gaussian --torch-s
     set -- $v; dt=$1; mm=$2; shift 2; tag=$(echo "$dt $mm $@" | tr " " "_" | tr -d "-" | sed 's/_$//')
     timeout 600 python3 tools/roberta_bench.py --table --dtype $dt --matmul $mm --steps 6 "$@" 2>> "$RAW/roberta.err" | tail -1 > "$OUT/${R}_roberta_table_$tag.json"
 done
-bash tools/profile_sketch.sh ${R}_rademacher_bf16 rademacher 16384 3072 1638 bf16 10 > "$OUT/${R}_sketch_rocprof_rademacher_16384x3072_p1638_bf16.txt" 2>&1
-bash tools/profile_sketch.sh ${R}_gaussian_bf16 gaussian 16384 3072 1638 bf16 10 > "$OUT/${R}_sketch_rocprof_gaussian_16384x3072_p1638_bf16.txt" 2>&1
+# the ratio the reference quotes (0.2: p = 3276 of 16384 rows), both layer widths of RoBERTa-base, both sketches
+for spec in "rademacher 3072" "gaussian 3072" "rademacher 768" "gaussian 768"; do set -- $spec
+    bash tools/profile_sketch.sh ${R}_$1_$2 $1 16384 $2 3276 bf16 10 2>&1 | cut -c1-1500 > "$OUT/${R}_sketch_rocprof_$1_16384x$2_p3276_bf16.txt"
+done
+# the randomized RoBERTa step with the arms interleaved in ONE process (S from memory / fused / fp32 partial sums / Rademacher),
+# where its GPU time goes by kernel class, and the counters behind the in-situ forward
+for dt in fp32 bf16; do timeout 900 python3 scratch/roberta_ab.py $dt 3 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_roberta_ab_$dt.txt"; done
+bash tools/profile_insitu_sketch.sh $R > "$RAW/insitu_sketch.log" 2>&1 && cp gpurun_out/${R}_roberta_randomized_insitu.json "$OUT/"
+[ -x scratch/bin/gen_bench ] && scratch/bin/gen_bench > "$OUT/${R}_gen_bench.txt" 2>&1
 python3 scratch/timeline.py 0.0 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_clock_transient_timeline.txt"
 [ -f gpurun_out/fp32_ulp.json ] && cp gpurun_out/fp32_ulp.json "$OUT/${R}_fp32_ulp.json"   # written by pytest -m gpu
 ls -la "$OUT"
