@@ -125,6 +125,12 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_philox4x32.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
         L.fewbit_hip_xoshiro128pp.restype = None
         L.fewbit_hip_xoshiro128pp.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), sz]
+        # FEWBIT_SKETCH_MATERIALISE=0|1: the Gaussian sketch never / whenever possible through the S-from-memory path (the built-in
+        # policy takes it for 16-bit input only: inside fp32 models it gained 3 % of the step on half the boxes of the pool and lost
+        # 5 % on the other half, profiles/r05_roberta_ab_fp32_boxes.txt)
+        forced = os.environ.get('FEWBIT_SKETCH_MATERIALISE', '')
+        if forced in ('0', '1'):
+            L.fewbit_hip_sketch_tune_materialise(int(forced))
         _lib = L
     return _lib
 

@@ -1,16 +1,21 @@
-// fewbit_sketch.hip -- the random-projection products of the randomized linear layers as ONE gfx950 kernel:
+// fewbit_sketch.hip -- the random-projection products of the randomized linear layers on gfx950:
 //
-//     P = scale * S . M        S: proj x rows, random (Rademacher +-1 or Gaussian N(0,1)), never stored anywhere
+//     P = scale * S . M        S: proj x rows, random (Rademacher +-1 or Gaussian N(0,1)), a FUNCTION of a 64-bit seed
 //                              M: rows x features (the layer's input X or the incoming gradient G), bf16 / fp16 / fp32
 //                              P: proj x features, the dtype of M
 //
 // What it replaces in the reference (skolai/fewbit): `proj = T.randn((proj_features, rows))` / `T.randint(...) - 0.5`
 // followed by `proj @ input_view` in LinearGRPFunc.forward (fewbit/functional/linear.py:133-146) and the same pair in
-// .backward (:195-208).  There S is a tensor in device memory (proj x rows elements, drawn twice: the backward re-draws it
-// from the saved generator state) and the product is a library GEMM.  Here S is a FUNCTION of (seed, row, column):
-// every lane of the matrix pipe computes its own A-operand fragment from a Philox4x32-10 counter in registers, feeds it
-// straight to v_mfma_f32_32x32x16_{bf16,f16}, and forward and backward regenerate the same S from the 64-bit seed alone.
-// HBM traffic of S: zero bytes (the reference: 2 x proj x rows x 4 B per layer and step).
+// .backward (:195-208).  There S is a tensor in device memory (proj x rows fp32 elements, drawn twice:
+// the backward re-draws it from the saved generator state) and the product is a library GEMM.  Here S is a function of
+// (seed, row, column), defined in the A-operand layout of v_mfma_f32_32x32x16_{bf16,f16}; forward and backward regenerate the
+// same S from the seed alone.  Two data paths (sketch_entry picks one; both give the same S):
+//   fused         every lane of the matrix pipe computes its own A fragment in registers and feeds it straight to the MFMA: S costs
+//                 no HBM, L2 or LDS byte.  Rademacher always (8 VALU per fragment); Gaussian for layers no wider than one tile.
+//   from memory   (Gaussian, more than one column tile) a VALU-only kernel writes S ONCE, as ready-made A fragments, into the
+//                 workspace and the product kernel reads them back: a Gaussian fragment costs as many issue cycles as the 8 MFMAs
+//                 it feeds, and on a CDNA4 SIMD nothing hides VALU work behind the matrix pipe (scratch/gen_bench.hip,
+//                 profiles/r05_gen_bench.txt) -- regenerating S per column tile was the kernel's bound.
 //
 // ---- the definition of S (a pure function; tests/sketch_reference.py evaluates the same formulas with numpy) -------------
 //   philox(c0, c1, c2, c3) = Philox4x32-10 with key (seed_lo, seed_hi)          [Salmon et al. 2011; the generator behind
@@ -18,12 +23,15 @@
 //   Rademacher:  S[i][r] = bit ? -1 : +1,   bit = bit ((j%2 ? 31 : 15) - (4*(s%4) + j/2)) of word s/4 of philox(i, 2*(r/256) + h, 0, 0)
 //                with s = (r%256)/16, h = (r/8)%2, j = r%8        (one call = 128 signs = this lane's 16 MFMA steps; the bit
 //                order is the one that turns a word into operand sign bits with one shift and one and-or per dword)
-//   Gaussian:    S[i][r] = Box-Muller on 16-bit uniforms: with w = word j/2 of philox(i, r/8, 0, 1), j = r%8,
-//                u1 = ((w & 0xffff) + 0.5) / 65536, u2 = (w >> 16) / 65536, rad = sqrt(-2 ln u1),
-//                S = rad * cos(2 pi u2) for even j, rad * sin(2 pi u2) for odd j, rounded to the operand dtype
-//                (one call = 8 normals = this lane's A fragment of one MFMA step; ln/sqrt/sin/cos are the hardware's
-//                v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32, ~1 ulp each -- the host model uses libm, and the test
-//                allows one step of the 16-bit operand dtype)
+//   Gaussian:    S[i][r] = Box-Muller on 16-bit uniforms of a 32-bit word w: u1 = ((w & 0xffff) + 0.5) / 65536, u2 = (w >> 16) / 65536,
+//                rad = sqrt(-2 ln u1), S = rad * cos(2 pi u2) for even j, rad * sin(2 pi u2) for odd j, rounded to the operand dtype
+//                (ln/sqrt/sin/cos are the hardware's v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32, ~1 ulp each -- the host model
+//                uses libm, and the test allows one step of the 16-bit operand dtype).  The word: with s, h, j as above and
+//                q = j/2, w = output number 2 s + q%2 of the xoshiro128++ stream [Blackman & Vigna 2019] whose state is
+//                philox(i, 2*(r/256) + h, q/2, 2) -- per lane and 256-row block TWO streams, each seeded by one Philox call and
+//                advanced two words per MFMA step; stream t feeds operand dwords 2t, 2t+1 of every fragment (so that the two
+//                waves of the 128 x 512 tile, which share their fragments, can each run one).  (Round 4's definition -- one Philox
+//                call per fragment -- is kept as a measurement build, -DFEWBIT_GAUSSIAN_GEN=1.)
 //
 // ---- tiling (three shapes, `Tile<W, NH>` below; the host picks one per call, make_plan) -------------------------------------
 //   workgroup  W waves (4 or 8); wave w owns 32 rows of S x 256 features = 8 MFMA column blocks of 32 -> 8 x 16 fp32
@@ -40,9 +48,10 @@
 //              inside the tile: MFMA block t, column c  <->  feature 8c + t.  It costs nothing: the epilogue finds the 8
 //              accumulators of a lane (t = 0..7) holding 8 CONSECUTIVE features -> one 16/32-byte store per output row.
 //   split K    gridDim.z slices of the rows (multiples of 256) when the tile grid alone cannot fill 256 CUs (proj x
-//              features is small, rows is long): slices write fp32 partials, a second kernel adds them IN A FIXED ORDER
-//              (deterministic: the same seed gives the same bits), scales and casts.
-// Measurement builds: -DFEWBIT_SKETCH_ABLATE=bits (stages compiled out), -DFEWBIT_SKETCH_TRACE (per-stage shader-clock stamps).
+//              features is small, rows is long): slices write partial sums (fp32; bf16 when the result is bf16), a second kernel
+//              adds them IN A FIXED ORDER (deterministic: the same seed gives the same bits), scales and casts.
+// Measurement builds: -DFEWBIT_SKETCH_ABLATE=bits (stages compiled out), -DFEWBIT_SKETCH_TRACE (per-stage shader-clock stamps),
+// -DFEWBIT_SKETCH_XCD=0 / -DFEWBIT_FRAG_AHEAD=n (tile order / prefetch depth of the from-memory kernel).
 // Roofline class: MFMA (bf16 dense peak 2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md); flops = 2*proj*rows*features.
 #include <hip/hip_runtime.h>
 
@@ -1081,19 +1090,24 @@ bool converts_first(int dtype, size_t rows, size_t proj) {
 constexpr size_t kWorkspaceAlign = 256;
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// S in memory first?  The Gaussian sketch (a fragment costs ~100 issue slots; Rademacher's 8 are not worth a byte of traffic) on
-// the 16-bit pipe, when at least two column tiles would otherwise regenerate it and its fragments (bf16, rows of S padded to
-// 256, rows of M to 256) stay under 1 GiB.  tune: 0 never, 1 whenever possible, -1 this policy.
+// S in memory first?  The Gaussian sketch (a fragment costs ~100 issue slots; Rademacher's 8 are not worth a byte of traffic) of
+// a 16-bit INPUT, when at least two column tiles would otherwise regenerate it and its fragments (bf16, rows of S padded to
+// 256, rows of M to 256) stay under 1 GiB.  Not for fp32 input that is rounded to bf16 first, although stand-alone it is 5-15 %
+// faster there too (16384 x 768, p = 3276: 130 against 142 us): inside an fp32 model the step got SLOWER with it on three of
+// five boxes of the pool (RoBERTa-base fp32, arms interleaved in one process: 1.16-1.18x vanilla against 1.11x fused; 1.07-1.08x
+// on the other two) -- every other kernel of the step, the clock-bound fp32 GEMMs first, ran 5-8 % longer behind the extra
+// ~300 MB of scratch traffic per product, while bf16 models gained on every box (1.54-1.56x against 1.65-1.66x);
+// profiles/r05_roberta_ab_*.txt, DESIGN.md 5.1.  tune: 0 never, 1 whenever possible (fp32 input included), -1 this policy.
 FEWBIT_HIDDEN std::atomic<long long> g_forced_materialise{-1};
 size_t fragment_blocks(size_t rows) { return (rows + 255) / 256; }                  // 256-row blocks of M = 16 MFMA steps each
 size_t fragment_row_blocks(size_t proj) { return (proj + 255) / 256 * 8; }          // 32-row blocks of S, padded to whole 256-row tiles
 size_t fragment_bytes(size_t rows, size_t proj) { return (fragment_row_blocks(proj) * fragment_blocks(rows) * 16 + kFragAhead) * 1024; }
-bool materialises(int dist, int operand_dtype, size_t rows, size_t features, size_t proj) {
+bool materialises(int dist, int operand_dtype, bool converted, size_t rows, size_t features, size_t proj) {
     if (dist != FEWBIT_SKETCH_GAUSSIAN || operand_dtype == FEWBIT_F32 || rows == 0) return false;
     const long long forced = g_forced_materialise.load(std::memory_order_relaxed);
     if (forced == 0 || fragment_row_blocks(proj) > 65535) return false;
     if (forced == 1) return true;
-    return features > BN && fragment_bytes(rows, proj) <= (1ull << 30);
+    return !converted && features > BN && fragment_bytes(rows, proj) <= (1ull << 30);
 }
 
 // the workspace of one call: [partial sums][bf16 copy of an fp32 M][A fragments of S], each part aligned to kWorkspaceAlign
@@ -1102,7 +1116,7 @@ Layout layout(int dist, int dtype, size_t rows, size_t features, size_t proj) {
     Layout L{};
     L.converted = converts_first(dtype, rows, proj);
     L.operand_dtype = L.converted ? static_cast<int>(FEWBIT_BF16) : dtype;
-    L.materialised = materialises(dist, L.operand_dtype, rows, features, proj);
+    L.materialised = materialises(dist, L.operand_dtype, L.converted, rows, features, proj);
     L.plan_dist = L.materialised ? static_cast<int>(FEWBIT_SKETCH_RADEMACHER) : dist;      // (fragments from memory: the one-half tiles' plan)
     const Plan p = make_plan(L.plan_dist, L.operand_dtype, rows, features, proj, L.materialised);
     L.partial_bytes = (p.gz > 1 || dtype != L.operand_dtype)

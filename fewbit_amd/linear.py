@@ -23,15 +23,17 @@ constructor / call signatures; the implementation is this repository's own:
 * without a user generator the sketch seed comes from the host default generator (so ``torch.manual_seed`` makes
   runs reproducible) and never reads back from the device -- no stream synchronisation in forward or backward;
 * on the GPU the dense sketches (``'gaussian'``, ``'rademacher'``) of fp32 / fp16 / bf16 tensors run on this package's own
-  gfx950 kernel (``fewbit_amd/csrc/fewbit_sketch.hip`` through the C-ABI ``fewbit_hip_sketch``): ``S`` is never
-  materialised -- it is a pure function of a 64-bit seed, generated in registers from a Philox4x32-10 counter and fed
-  straight to the matrix cores; what a layer keeps for backward is the ``p x features`` projection and ONE integer, and
-  backward regenerates the same ``S`` from that integer.  The reference draws ``proj x rows`` random numbers into device
-  memory twice per layer and step (fewbit/functional/linear.py:133-137,195-199).  fp32 operands are rounded to bf16 on their
+  gfx950 kernels (``fewbit_amd/csrc/fewbit_sketch.hip`` through the C-ABI ``fewbit_hip_sketch``): ``S`` is a pure function
+  of a 64-bit seed (Philox4x32-10; Gaussian: xoshiro128++ streams seeded by it) -- Rademacher signs are generated in registers
+  and fed straight to the matrix cores, a Gaussian ``S`` of a layer wider than 256 features is written once per product into a
+  scratch workspace as MFMA fragments and read back (it costs as much to generate as to multiply: regenerating it per column
+  tile was slower than ``randn`` + ``matmul``); what a layer keeps for backward is the ``p x features`` projection and ONE
+  integer, and backward regenerates the same ``S`` from that integer.  The reference draws ``proj x rows`` random numbers into
+  device memory twice per layer and step (fewbit/functional/linear.py:133-137,195-199).  fp32 operands are rounded to bf16 on their
   way into the matrix pipe (accumulation is fp32): a zero-mean relative perturbation of 2^-9 per element under an estimator
   whose own relative noise is ~ sqrt(rows / p).  ``use_native_sketch(False)`` (or ``FEWBIT_SKETCH_NATIVE=0``) selects
-  the PyTorch formulation (randn / randint + matmul) instead; host tensors, float64 and the sampled transforms always
-  take it;
+  the PyTorch formulation (randn / randint + matmul) instead, and so does an EXPLICIT ``sketch_dtype=torch.float32`` /
+  ``float64`` (a request for products of that precision); host tensors, float64 and the sampled transforms always take it;
 * the native path can be captured into a hipGraph (``torch.cuda.graph``) after one eager warm-up call per device: while
   the stream is capturing, the seed is a device word that a recorded one-thread kernel re-derives on every replay
   (``_sketch_seed``), so a replayed training step draws a fresh ``S`` each time -- a seed recorded by value would repeat
@@ -239,6 +241,7 @@ class _LinearGRP(torch.autograd.Function):
             # saved bytes of an fp32 layer, and the small GEMM of backward runs on the 16-bit matrix pipe as well
             low = sketch_dtype if sketch_dtype is not None and sketch_dtype != flat.dtype else None
             ctx.low = low
+            # (the sketch before or after the layer's own GEMM: no difference, profiles/r05_roberta_ab_order.txt)
             sketch = _native_sketch(kind, flat.detach() if low is None else flat.detach().to(low), p, ctx.native_seed, 1.0 / p)
             ctx.save_for_backward(sketch, weight)
             ctx.p, ctx.kind = p, kind

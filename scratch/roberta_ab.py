@@ -1,6 +1,6 @@
 """RoBERTa-base, every encoder Linear randomized (ratio 0.2): ONE process, the arms interleaved round by round on the same
-box -- vanilla model | Gaussian sketch with S written to memory once (the policy) | Gaussian generated inside the product
-kernel (tune_materialise 0) | the same with fp32 partial sums (round 4's data path) | Rademacher.  Step time per arm.
+box -- vanilla model | Gaussian sketch by the library's policy | with S written to memory once (tune_materialise 1) | generated
+inside the product kernel (0) | the same with fp32 partial sums (round 4's data path) | Rademacher.  Step time per arm.
    python scratch/roberta_ab.py fp32|bf16 [rounds]"""
 import os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -48,11 +48,12 @@ def arm(kind, mem, p16):
 
 
 arms = {'vanilla': lambda: steps(vanilla),
-        'gaussian, S from memory (policy)': lambda: arm('gaussian', -1, -1),
-        'gaussian, fused': lambda: arm('gaussian', 0, -1),
-        'gaussian, fused, fp32 partial sums': lambda: arm('gaussian', 0, 0),
+        'gaussian (the policy: S from memory for 16-bit input, fused for fp32 input)': lambda: arm('gaussian', -1, -1),
+        'gaussian, S from memory (forced)': lambda: arm('gaussian', 1, -1),
+        'gaussian, fused (forced)': lambda: arm('gaussian', 0, -1),
+        'gaussian, fused, fp32 partial sums (round 4\'s data path)': lambda: arm('gaussian', 0, 0),
         'rademacher': lambda: arm('rademacher', -1, -1),
-        'rademacher, fp32 partial sums': lambda: arm('rademacher', -1, 0)}
+        'rademacher, fp32 partial sums (round 4\'s data path)': lambda: arm('rademacher', -1, 0)}
 res = {k: [] for k in arms}
 for r in range(rounds):
     for k, f in arms.items():
@@ -60,4 +61,4 @@ for r in range(rounds):
 base = statistics.median(res['vanilla'])
 print(f'# RoBERTa-base b128 x s128 {sys.argv[1] if len(sys.argv) > 1 else "fp32"}, ms per step: median of {rounds} interleaved rounds of 6 steps (min..max), x vanilla')
 for k, v in res.items():
-    print(f'{k:40s} {statistics.median(v):7.2f} ({min(v):7.2f}..{max(v):7.2f})  {statistics.median(v) / base:.3f}x', flush=True)
+    print(f'{k:78s} {statistics.median(v):7.2f} ({min(v):7.2f}..{max(v):7.2f})  {statistics.median(v) / base:.3f}x', flush=True)

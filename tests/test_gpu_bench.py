@@ -81,6 +81,29 @@ def test_pmc_traffic_is_measured_by_the_run_itself():
     assert got['write_bytes'] >= 4096 * 4096 * (2 + 3 / 8)
 
 
+def test_sketch_extra_quotes_the_reference_ratio_at_both_widths():
+    """the `sketch` object of the default line: proj_dim_ratio 0.2 (p = 3276 of 16384 rows, the reference README's ratio) at 3072
+    and 768 features, both distributions, each with its roofline, the torch pair timed beside it and a `wins_vs_torch` flag"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_module', ROOT / 'bench.py')
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import torch
+    got = bench.measure_sketch(torch.device('cuda:0'))
+    assert set(got['ratio_0.2']) == {'16384x3072', '16384x768'}
+    for shape, rec in got['ratio_0.2'].items():
+        features = int(shape.split('x')[1])
+        for dist, pair in (('rademacher', 'randint_plus_matmul_us'), ('gaussian', 'randn_plus_matmul_us')):
+            e = rec[dist]
+            flops = 2.0 * 3276 * 16384 * features
+            assert e['roofline']['bound'] == 'mfma' and e['roofline']['peak'] == 2500.0
+            assert abs(e['roofline']['achieved'] - flops / e['us'] / 1e6) <= 0.02 * e['roofline']['achieved'] and 0.05 < e['roofline']['frac'] < 1.0
+            assert e['torch_us'] == rec['torch'][pair] and e['wins_vs_torch'] == (e['us'] <= e['torch_us'])
+            assert e['plan']['grid'][0] == features // 256
+        assert 'from memory' in rec['gaussian']['plan']['kernel'] and 'from memory' not in rec['rademacher']['plan']['kernel']
+    assert got['wins_vs_torch'] is True, got                    # (a regression of any of the four entries shows up here and in the driver's line)
+
+
 def test_self_launched_ranks_line():
     line = _bench('--gpus', '2', '--steps', '5', '--warmup', '2')
     _check_contract(line, 2, 5, 2)

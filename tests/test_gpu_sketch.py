@@ -121,8 +121,13 @@ def test_gaussian_fragments_from_memory_are_the_fused_kernels_matrix():
     first and for a device-resident seed"""
     assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 3072, 3276)['kernel']
     assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 768, 3276)['kernel']
-    assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 768, 3276, torch.float32)['kernel']            # (converted to bf16 first)
-    assert 'from memory' not in cabi.describe_sketch('gaussian', 16384, 768, 1000, torch.float32)['kernel']        # (fp32 operand staged in the kernel)
+    assert 'from memory' not in cabi.describe_sketch('gaussian', 16384, 768, 3276, torch.float32)['kernel']        # fp32 input: the fused kernel by policy
+    try:
+        cabi.tune_sketch_materialise(1)                                                                             # ... unless asked for
+        assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 768, 3276, torch.float32)['kernel']        # (converted to bf16 first)
+        assert 'from memory' not in cabi.describe_sketch('gaussian', 16384, 768, 1000, torch.float32)['kernel']    # (fp32 operand staged in the kernel)
+    finally:
+        cabi.tune_sketch_materialise(-1)
     assert 'from memory' not in cabi.describe_sketch('gaussian', 16384, 256, 3276)['kernel']                       # one column tile: nothing to share
     assert 'from memory' not in cabi.describe_sketch('rademacher', 16384, 3072, 3276)['kernel']
     assert cabi.describe_sketch('gaussian', 2**21, 768, 2**10)['s_fragment_bytes'] == 0                             # 4 GiB of fragments: the fused kernel
@@ -199,13 +204,18 @@ def test_row_slices_are_deterministic_and_agree():
         cabi.tune_sketch_materialise(-1)
 
 
-def test_fp32_input_rounded_first_with_gaussian_fragments_from_memory():
-    """fp32 input with many row tiles + Gaussian S from memory (the path of an fp32 RoBERTa layer): conversion pass, fragment pass,
-    product from the two; ragged widths, a row stride, a very long and a very short input"""
-    for rows, features, proj, ld in ((3000, 770, 1400, None), (520, 264, 1300, 272), (70000, 40, 1290, None), (300, 1032, 2000, 1040)):
-        assert cabi.describe_sketch('gaussian', rows, features, proj, torch.float32)['converted_to_bf16_first'] is True
-        _product_case('gaussian', torch.float32, rows, features, proj, seed=rows, ld=ld)
-        assert ('from memory' in cabi.describe_sketch('gaussian', rows, features, proj, torch.float32)['kernel']) == (features > 256)
+def test_fp32_input_rounded_first_with_and_without_gaussian_fragments_from_memory():
+    """fp32 input with many row tiles: conversion pass, then the fused kernel (the policy for fp32 input) or -- forced -- fragment
+    pass + product from memory; ragged widths, a row stride, a very long and a very short input"""
+    try:
+        for rows, features, proj, ld in ((3000, 770, 1400, None), (520, 264, 1300, 272), (70000, 40, 1290, None), (300, 1032, 2000, 1040)):
+            for mem in (-1, 1):                      # the policy keeps fp32 input on the fused kernel; 1 forces S from memory
+                cabi.tune_sketch_materialise(mem)
+                plan = cabi.describe_sketch('gaussian', rows, features, proj, torch.float32)
+                assert plan['converted_to_bf16_first'] is True and ('from memory' in plan['kernel']) == (mem == 1)
+                _product_case('gaussian', torch.float32, rows, features, proj, seed=rows, ld=ld)
+    finally:
+        cabi.tune_sketch_materialise(-1)
 
 
 def test_bf16_partial_sums_of_sliced_bf16_products():

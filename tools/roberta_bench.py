@@ -132,7 +132,7 @@ def main():
     ap.add_argument('--matmul', default='gaussian', choices=('gaussian', 'rademacher'), help='kind of dense sketch of the randomized layers')
     ap.add_argument('--torch-sketch', action='store_true',
                     help='draw S with torch.randn / randint and multiply with torch.matmul (what round 3 measured) instead of the '
-                         'Philox-in-register MFMA kernel (fewbit_amd/csrc/fewbit_sketch.hip)')
+                         'gfx950 sketch kernels (fewbit_amd/csrc/fewbit_sketch.hip)')
     args = ap.parse_args()
     dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[args.dtype]
     dev = torch.device('cuda:0')
@@ -162,7 +162,7 @@ def main():
             r['step_time_ratio'] = round(r['ms_per_step'] / rows[0]['ms_per_step'], 3)
         print(json.dumps({'config': f'RoBERTa-base (random init) batch {args.batch} x seq {args.seq}, {args.dtype}, '
                                     f'fwd+bwd+SGD step; randomized linear proj_dim_ratio={args.linear_ratio}'
-                                    + f', {args.matmul} sketch, ' + ('torch.randn/randint + torch.matmul' if args.torch_sketch else 'Philox-in-register MFMA kernel')
+                                    + f', {args.matmul} sketch, ' + ('torch.randn/randint + torch.matmul' if args.torch_sketch else 'gfx950 sketch kernels (fewbit_hip_sketch)')
                                     + (', sketch GEMMs in bf16' if args.sketch_bf16 else ''),
                           'rows': rows}))
         return
