@@ -706,9 +706,11 @@ template <int DT> __global__ __launch_bounds__(256) void sketch_reduce4_kernel(c
     }
 }
 
-// bf16 partial sums -> bf16 result: the same fixed order, sums in fp32, one scale, one rounding.  8 elements (16 bytes) per thread
-// and slice when n % 8 == 0 (VEC), else one element
-template <bool VEC> __global__ __launch_bounds__(256) void sketch_reduce_bf16_kernel(const uint16_t *__restrict__ ws, size_t n, int slices, float scale, uint16_t *__restrict__ out) {
+// bf16 partial sums -> bf16 (or, OUT32, fp32) result: the same fixed order, sums in fp32, one scale, one rounding.  8 elements (16
+// bytes) per thread and slice when n % 8 == 0 (VEC), else one element
+template <bool VEC, bool OUT32> __global__ __launch_bounds__(256) void sketch_reduce_bf16_kernel(const uint16_t *__restrict__ ws, size_t n, int slices, float scale, void *__restrict__ out_) {
+    typedef typename std::conditional<OUT32, float, uint16_t>::type out_t;
+    out_t *out = static_cast<out_t *>(out_);
     const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
     auto up = [](uint32_t hw) { return __builtin_bit_cast(float, hw << 16); };
     if constexpr (VEC) {
@@ -736,15 +738,22 @@ template <bool VEC> __global__ __launch_bounds__(256) void sketch_reduce_bf16_ke
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s[2 * e] += up(v[e] & 0xffffu); s[2 * e + 1] += up(v[e] >> 16); }
         }
-        u32x4 o;
+        if constexpr (OUT32) {
+            f32x4 *o = reinterpret_cast<f32x4 *>(out) + 2 * i;
+            o[0] = f32x4{s[0] * scale, s[1] * scale, s[2] * scale, s[3] * scale};
+            o[1] = f32x4{s[4] * scale, s[5] * scale, s[6] * scale, s[7] * scale};
+        } else {
+            u32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = Operand<FEWBIT_BF16>::pack(s[2 * e] * scale, s[2 * e + 1] * scale);
-        reinterpret_cast<u32x4 *>(out)[i] = o;
+            for (int e = 0; e < 4; ++e) o[e] = Operand<FEWBIT_BF16>::pack(s[2 * e] * scale, s[2 * e + 1] * scale);
+            reinterpret_cast<u32x4 *>(out)[i] = o;
+        }
     } else {
         if (i >= n) return;
         float s = up(ws[i]);
         for (int z = 1; z < slices; ++z) s += up(ws[static_cast<size_t>(z) * n + i]);
-        out[i] = static_cast<uint16_t>(Operand<FEWBIT_BF16>::pack(s * scale, 0.0f) & 0xffffu);
+        if constexpr (OUT32) out[i] = s * scale;
+        else out[i] = static_cast<uint16_t>(Operand<FEWBIT_BF16>::pack(s * scale, 0.0f) & 0xffffu);
     }
 }
 
@@ -998,15 +1007,19 @@ int launch_kernel(const Plan &p, bool ragged, const void *m, size_t rows, size_t
     return ragged ? go(sketch_kernel<DIST, DT, PARTIAL, true, W, NH>) : go(sketch_kernel<DIST, DT, PARTIAL, false, W, NH>);
 }
 
-// bf16 partial sums: when the result is bf16 anyway and the rows are sliced, the slices' round trip through memory (written by
+// bf16 partial sums: when the rows are sliced and the operands are bf16, the slices' round trip through memory (written by
 // the product kernel, read back by the reduce kernel -- 2 x gz x proj x features x 4 bytes, the K-independent part of a 768-wide
-// product's time) is made in bf16: each slice's sum is rounded once, the slices are added in fp32 in the same fixed order.  The
-// error of the result grows from one bf16 rounding to about sqrt(2) of one (gz roundings of sums sqrt(gz) times smaller).
-// tune: 0 never, 1 whenever the result is bf16, -1 this policy.
+// product's time) is made in bf16: each slice's sum is rounded once, the slices are added in fp32 in the same fixed order.
+//   * bf16 result: its error grows from one bf16 rounding to about sqrt(2) of one (gz roundings of sums sqrt(gz) times smaller);
+//   * fp32 result of an fp32 input that was rounded to bf16 first: the sums already carry the operands' rounding (2^-9 per
+//     element of M -- and of a Gaussian S --: ~0.6-0.8 x 2^-9 of a slice's sum in its standard deviation); rounding the slice's sum to
+//     bf16 adds ~0.4 x 2^-9 of it, +12 % on that error, under an estimator whose own relative noise is sqrt(rows / p).
+// fp16 keeps fp32 partial sums (range).  tune: 0 never, 2 for bf16 results only, 1 / -1 this policy.
 FEWBIT_HIDDEN std::atomic<long long> g_forced_partial16{-1};
 bool partial16(int dtype, int out_dtype, unsigned gz) {
-    if (dtype != FEWBIT_BF16 || out_dtype != FEWBIT_BF16 || gz <= 1) return false;
-    return g_forced_partial16.load(std::memory_order_relaxed) != 0;
+    if (dtype != FEWBIT_BF16 || gz <= 1 || (out_dtype != FEWBIT_BF16 && out_dtype != FEWBIT_F32)) return false;
+    const long long forced = g_forced_partial16.load(std::memory_order_relaxed);
+    return forced != 0 && !(forced == 2 && out_dtype != FEWBIT_BF16);
 }
 
 template <int DIST, int DT, int PARTIAL>
@@ -1041,8 +1054,14 @@ int launch(const void *m, size_t rows, size_t features, size_t ld, size_t proj, 
                 if (rc != FEWBIT_OK) return rc;
                 const uint16_t *ws = static_cast<const uint16_t *>(workspace);
                 const bool vec = n % 8 == 0 && (reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
-                if (vec) hipLaunchKernelGGL((sketch_reduce_bf16_kernel<true>), dim3(static_cast<unsigned>((n / 8 + 255) / 256)), dim3(256), 0, s, ws, n, z, scale, static_cast<uint16_t *>(out));
-                else hipLaunchKernelGGL((sketch_reduce_bf16_kernel<false>), dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, ws, n, z, scale, static_cast<uint16_t *>(out));
+                const dim3 grid(static_cast<unsigned>(((vec ? n / 8 : n) + 255) / 256));
+                if (out_dtype == FEWBIT_F32) {
+                    if (vec) hipLaunchKernelGGL((sketch_reduce_bf16_kernel<true, true>), grid, dim3(256), 0, s, ws, n, z, scale, out);
+                    else hipLaunchKernelGGL((sketch_reduce_bf16_kernel<false, true>), grid, dim3(256), 0, s, ws, n, z, scale, out);
+                } else {
+                    if (vec) hipLaunchKernelGGL((sketch_reduce_bf16_kernel<true, false>), grid, dim3(256), 0, s, ws, n, z, scale, out);
+                    else hipLaunchKernelGGL((sketch_reduce_bf16_kernel<false, false>), grid, dim3(256), 0, s, ws, n, z, scale, out);
+                }
                 const hipError_t e = hipGetLastError();
                 if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sketch: %s", hipGetErrorString(e));
                 return FEWBIT_OK;
@@ -1258,7 +1277,7 @@ int fewbit_hip_sketch_tune_slices(long long slices) {
 }
 
 int fewbit_hip_sketch_tune_partials(long long bf16_partials) {
-    if (bf16_partials < -1 || bf16_partials > 1) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: bf16 partial sums are 0 (never), 1 / -1 (for bf16 results), got %lld", bf16_partials);
+    if (bf16_partials < -1 || bf16_partials > 2) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: bf16 partial sums are 0 (never), 2 (bf16 results only), 1 / -1 (the policy), got %lld", bf16_partials);
     g_forced_partial16.store(bf16_partials, std::memory_order_relaxed);
     return FEWBIT_OK;
 }

@@ -165,15 +165,17 @@ int fewbit_hip_unpack_codes(const uint8_t *state, int32_t *codes, size_t n, int 
  *   replaces  `proj = T.randn((proj_features, rows)); proj @ input_view`  and the Rademacher twin,
  *             fewbit/functional/linear.py:133-146 (forward) and :195-208 (backward, which re-draws the same matrix
  *             from the saved generator state)
- *   S    proj x rows, NEVER materialised: a pure function of (seed, row, column) evaluated in registers and fed to the
- *        matrix cores (definition: fewbit_amd/csrc/fewbit_sketch.hip header; host model: tests/sketch_reference.py).
- *        Forward and backward pass the same seed and get the same S.
+ *   S    proj x rows, a pure function of (seed, row, column) in the operand layout of the matrix cores (definition:
+ *        fewbit_amd/csrc/fewbit_sketch.hip header; host model: tests/sketch_reference.py): evaluated in registers inside the product
+ *        kernel, or (Gaussian, 16-bit input wider than 256 features) written once per call into the workspace as MFMA fragments and
+ *        read back -- never kept.  Forward and backward pass the same seed and get the same S.
  *   m    rows x features, row-major with leading dimension `ld` (elements), dtype F32 / F16 / BF16; fp32 is rounded to bf16
- *        (while it is staged, or for many row tiles in one pass beforehand) -- the products run on the bf16 matrix pipe,
- *        accumulation is fp32
+ *        (while it is staged, or for many row tiles in one pass beforehand) -- the products run on the bf16 matrix pipe and are
+ *        accumulated in fp32; when the rows are sliced and the operands are bf16, each slice's sum crosses the workspace rounded to
+ *        bf16 and the slices are added in fp32 (fewbit_hip_sketch_tune_partials)
  *   out  proj x features, contiguous, the dtype of m
- *   workspace  fewbit_hip_sketch_workspace(dist, dtype, rows, features, proj) bytes of device memory (0 when the rows are not sliced);
- *        contents are scratch.  The result is deterministic: the same arguments give the same bits.
+ *   workspace  fewbit_hip_sketch_workspace(dist, dtype, rows, features, proj) bytes of device memory (0 for small unsliced calls, a few
+ *        hundred MB for a large Gaussian one); contents are scratch.  The result is deterministic: the same arguments give the same bits.
  */
 typedef enum fewbit_sketch_dist { FEWBIT_SKETCH_RADEMACHER = 0, FEWBIT_SKETCH_GAUSSIAN = 1 } fewbit_sketch_dist;
 
@@ -209,9 +211,10 @@ int fewbit_hip_sketch_tune_halves(long long halves);
  * (the result stays fp32, from the fp32 sums; the numbers are the ones the in-kernel conversion gives): 0 never, 1 always,
  * -1 that policy.  fewbit_hip_sketch_workspace already counts the copy. */
 int fewbit_hip_sketch_tune_convert(long long convert);
-/* bf16 results with sliced rows: the slices' partial sums make their round trip through the workspace in bf16 instead of fp32
- * (half the bytes; each slice's sum is rounded once, the slices are added in fp32 in a fixed order): 0 never, 1 or -1 that
- * policy.  fewbit_hip_sketch_workspace follows the setting. */
+/* Sliced rows, bf16 operands (a bf16 input, or an fp32 input that was rounded to bf16 first): the slices' partial sums make their
+ * round trip through the workspace in bf16 instead of fp32 (half the bytes; each slice's sum is rounded once, the slices are added
+ * in fp32 in a fixed order; the result is bf16 or fp32 as before): 0 never, 2 for bf16 results only, 1 or -1 the policy (both).
+ * fewbit_hip_sketch_workspace follows the setting. */
 int fewbit_hip_sketch_tune_partials(long long bf16_partials);
 /* Gaussian sketch of a layer wider than one 256-feature tile: S is generated ONCE, by a VALU-only kernel, into the workspace as the
  * bf16 / fp16 A fragments of the matrix pipe, and the product kernel reads them back (instead of every column tile regenerating

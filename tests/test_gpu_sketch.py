@@ -84,7 +84,7 @@ def _product_case(dist, dtype, rows, features, proj, seed, ld=None, scale=1.0):
     slack = (2.0**-8 if dist == 'gaussian' else 0.0) * bound / max(rows, 1)**0.5 * 8
     plan = cabi.describe_sketch(dist, rows, features, proj, dtype)
     if plan['partial_sums'] == 'bf16':           # every slice's sum makes its way to the reduce kernel rounded to bf16: at most 2^-8 of it each
-        assert dtype == torch.bfloat16 and plan['grid'][2] > 1
+        assert plan['grid'][2] > 1 and (dtype == torch.bfloat16 or (dtype == torch.float32 and plan['converted_to_bf16_first']))
         ks = plan['k_slice']
         slack = slack + abs(scale) * 2.0**-8 * sum((S[:, z:z + ks] @ mm[z:z + ks]).abs() for z in range(0, rows, ks)) * 1.01
     floor = 2.0**-24 if dtype == torch.float16 else 1e-30          # fp16 results below 6e-5 are subnormal: steps of 2^-24
@@ -248,7 +248,8 @@ def test_bf16_partial_sums_of_sliced_bf16_products():
             cabi.tune_sketch_slices(3)
             _product_case(dist, torch.bfloat16, 3000, 389, 130, seed=4)
             assert cabi.describe_sketch(dist, 8192, 392, 200, torch.float16)['partial_sums'] == 'fp32'
-            assert cabi.describe_sketch(dist, 8192, 392, 200, torch.float32)['partial_sums'] == 'fp32'
+            assert cabi.describe_sketch(dist, 8192, 392, 200, torch.float32)['partial_sums'] == 'fp32'           # (fp32 operand staged in the kernel: p <= 1280)
+            assert cabi.describe_sketch(dist, 8192, 392, 1400, torch.float32)['partial_sums'] == 'bf16'          # (rounded to bf16 first: bf16 operands)
         cabi.tune_sketch_slices(1)
         assert cabi.describe_sketch('rademacher', 8192, 392, 200)['partial_sums'] is None
     finally:
@@ -368,6 +369,7 @@ def test_fp32_input_converted_to_bf16_first_gives_the_same_products():
     assert cabi.describe_sketch('gaussian', 16384, 768, 1280, torch.float32)['converted_to_bf16_first'] is False
     assert cabi.describe_sketch('rademacher', 16384, 768, 3276, torch.bfloat16)['converted_to_bf16_first'] is False
     try:
+        cabi.tune_sketch_partials(2)           # (fp32 partial sums for the fp32 result: the two routes are then the same sums up to association)
         for dist in ('rademacher', 'gaussian'):
             for rows, features, proj, ld in ((3000, 770, 200, None), (4096, 512, 1400, None), (512, 100, 64, 136), (2048, 1024, 1300, 1032), (1000, 37, 5, None)):
                 g = torch.Generator().manual_seed(rows)
@@ -386,8 +388,17 @@ def test_fp32_input_converted_to_bf16_first_gives_the_same_products():
                 bound = 0.25 * (cabi.sketch_matrix(dist, torch.float32, 99, proj, rows).abs() @ m.abs())
                 assert bool(((got[0] - got[1]).abs() <= 2.0**-20 * bound + 1e-30).all()), (dist, rows, features, proj)
                 _product_case(dist, torch.float32, rows, features, proj, seed=5, ld=ld)                # (convert = 1 still set)
+                cabi.tune_sketch_partials(-1)      # the policy: sliced rows of a converted input exchange bf16 partial sums, fp32 result
+                cabi.tune_sketch_slices(3)
+                plan = cabi.describe_sketch(dist, rows, features, proj, torch.float32)
+                assert plan['partial_sums'] == ('bf16' if plan['grid'][2] > 1 else 'fp32') and (plan['grid'][2] > 1) == (rows >= 2048)
+                _product_case(dist, torch.float32, rows, features, proj, seed=6, ld=ld)
+                cabi.tune_sketch_slices(-1)
+                cabi.tune_sketch_partials(2)
     finally:
         cabi.tune_sketch_convert(-1)
+        cabi.tune_sketch_partials(-1)
+        cabi.tune_sketch_slices(-1)
 
 
 def test_sketch_and_randomized_layer_capture_into_a_hip_graph(monkeypatch):

@@ -1,10 +1,17 @@
 """The generator behind the random-projection kernel, without a GPU: Philox4x32-10 and xoshiro128++ of the library (host entry
 points of the C-ABI) and of the numpy model against published known-answer vectors, and the statistics of the model's matrices."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import torch
 
 import sketch_reference as ref
 from fewbit_amd import cabi
+from helpers import ROOT
 
 # Random123 kat_vectors, philox4x32 with 10 rounds: (counter, key, expected)
 KAT = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
@@ -105,3 +112,36 @@ def test_model_matrices_have_the_right_moments_and_are_functions_of_the_seed():
     # E[S^T S] = proj * I: the property the estimator's unbiasedness rests on
     S = ref.rademacher(3, 4096, 24)
     assert float((S.T @ S / 4096 - torch.eye(24)).abs().max()) < 0.07
+
+
+def _plan(dist, dtype, rows, features, proj):
+    """fewbit_hip_sketch_describe through ctypes (the host-side planner: no GPU needed, an absent device counts as 256 CUs)"""
+    L = cabi.lib()
+    buf = ctypes.create_string_buffer(1024)
+    assert L.fewbit_hip_sketch_describe(cabi.SKETCH_DISTS.index(dist), cabi.DTYPES[dtype], rows, features, proj, buf, 1024) == 0
+    return json.loads(buf.value.decode())
+
+
+def test_data_path_policy_of_the_sketch_without_a_gpu():
+    """which of the data paths a call takes: Gaussian S from memory for 16-bit input wider than one tile, the fused
+    kernel for fp32 input (FEWBIT_SKETCH_MATERIALISE=1 overrides) and for Rademacher; bf16 partial sums for sliced bf16 operands;
+    the workspace is the sum of its parts"""
+    g = _plan('gaussian', torch.bfloat16, 16384, 768, 3276)
+    assert 'from memory' in g['kernel'] and g['grid'] == [3, 13, 6] and g['partial_sums'] == 'bf16'
+    frag = (13 * 8 * 64 * 16 + 4) * 1024
+    assert g['s_fragment_bytes'] == frag and g['workspace_bytes'] == 6 * 3276 * 768 * 2 + frag          # (the partial sums end on a 256-byte boundary here)
+    assert 'from memory' in _plan('gaussian', torch.float16, 16384, 3072, 3276)['kernel']
+    assert _plan('gaussian', torch.float16, 16384, 3072, 3276)['partial_sums'] == 'fp32'                 # fp16: range
+    assert 'from memory' not in _plan('gaussian', torch.bfloat16, 16384, 256, 3276)['kernel']            # one column tile: nothing to share
+    assert 'from memory' not in _plan('rademacher', torch.bfloat16, 16384, 3072, 3276)['kernel']
+    assert _plan('gaussian', torch.bfloat16, 2**21, 768, 2**10)['s_fragment_bytes'] == 0                 # 4 GiB of fragments: the fused kernel
+    f = _plan('gaussian', torch.float32, 16384, 768, 3276)                                                # fp32 input: rounded to bf16 first, fused kernel
+    assert f['converted_to_bf16_first'] is True and 'from memory' not in f['kernel'] and f['partial_sums'] == 'bf16'
+    assert f['workspace_bytes'] == -(-(f['grid'][2] * 3276 * 768 * 2) // 256) * 256 + 16384 * 768 * 2
+    small = _plan('rademacher', torch.float32, 16384, 768, 200)                                           # fp32 operand staged in the kernel
+    assert small['converted_to_bf16_first'] is False and small['partial_sums'] == 'fp32'
+    code = ("import ctypes, json, torch; from fewbit_amd import cabi; L = cabi.lib(); b = ctypes.create_string_buffer(1024); "
+            "L.fewbit_hip_sketch_describe(1, 0, 16384, 768, 3276, b, 1024); print(json.loads(b.value.decode())['kernel'])")
+    for env, expect in (('1', True), ('0', False)):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, FEWBIT_SKETCH_MATERIALISE=env, PYTHONPATH=str(ROOT)), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and ('from memory' in r.stdout) == expect, (env, r.stdout, r.stderr[-500:])
