@@ -109,6 +109,9 @@ constexpr int kGaussianRounds = FEWBIT_GAUSSIAN_ROUNDS;
 #ifndef FEWBIT_GAUSSIAN_GEN
 #define FEWBIT_GAUSSIAN_GEN 2       // 2: xoshiro128++ streams seeded by Philox (the definition of S); 1: one Philox call per fragment (the
 #endif                              // round-4 definition, kept as a measurement build only -- the host model no longer follows it)
+#ifndef FEWBIT_GAUSSIAN_WOVEN
+#define FEWBIT_GAUSSIAN_WOVEN 1     // the fused 256 x 256 Gaussian kernel generates the NEXT step's A fragment between this step's MFMAs (0: as
+#endif                              // one clump in front of the step's MFMAs, the form of every other fused kernel)
 #ifndef FEWBIT_SKETCH_ABLATE
 #define FEWBIT_SKETCH_ABLATE 0      // measurement builds only (results are WRONG): 1 no staging of M after the first stage, 2 no barrier in
 #endif                              // the K loop, 4 constant A operand (no generator), 8 B fragments read once (no LDS reads in the loop)
@@ -210,6 +213,16 @@ __device__ __forceinline__ void box_muller(uint32_t w, float &z0, float &z1) {
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // -2 ln u = -2 ln2 * log2 u
     z0 = rad * __builtin_amdgcn_cosf(u2);                                                             // v_cos_f32 takes turns
     z1 = rad * __builtin_amdgcn_sinf(u2);
+}
+
+// the same in two halves (for the woven generator: first half behind one MFMA, second half behind the next)
+__device__ __forceinline__ void box_muller_begin(uint32_t w, float &l2, float &u2) {
+    l2 = __builtin_amdgcn_logf(__builtin_fmaf(static_cast<float>(w & 0xffffu), 1.0f / 65536.0f, 0.5f / 65536.0f));
+    u2 = static_cast<float>(w >> 16) * (1.0f / 65536.0f);
+}
+template <int DT> __device__ __forceinline__ uint32_t box_muller_end(float l2, float u2) {
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * l2);
+    return Operand<DT>::pack(rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2));
 }
 
 // one 32-bit word -> two normals, packed as one operand dword (even element low)
@@ -520,6 +533,19 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
         publish_fragments(0, std::true_type{});
         __syncthreads();
     }
+    // woven generator: the fragment of the step AFTER the current one is generated between the current step's MFMAs -- word + log of
+    // pair q behind MFMA 2q, sqrt / cos / sin / pack behind MFMA 2q + 1 -- instead of as one clump of ~90 instructions in front of the
+    // step, during which the wave feeds the matrix pipe nothing.  The SIMD's issue time is the same; the gain is the part of the clump
+    // the wave's partner on the SIMD could not cover: 16384 x 768, p = 3276 bf16 116.8 -> 113.7 us, fp32 input 137.0 -> 130.1, 3072 wide
+    // 428.6 -> 414.2 (profiles/r05_sketch_woven_ab.txt; scratch/gen_bench.hip had said -8 % for the bare loop).  The 4-wave tile
+    // measured +-0.5 % and keeps the clump, as do the Rademacher kernels (8 instructions per fragment) and the two-half tile (its
+    // waves generate for each other at different steps already).
+    constexpr bool kWoven = FEWBIT_GAUSSIAN_WOVEN != 0 && kStreams && NH == 1 && W == 8 && NT == 8 && (FEWBIT_SKETCH_ABLATE & (4 | 16)) == 0;
+    u32x4 a_next = {0u, 0u, 0u, 0u};
+    if constexpr (kWoven) {
+        refresh_signs(0);
+        a_next = make_fragment(0, 0);
+    }
     // the multiply phase of one stage; FAST: the staging of stage s+1 (registers -> LDS) and the loads of stage s+2 are
     // unconditional and woven into the MFMA stream by the group barriers (one basic block)
     auto stage = [&](size_t s, auto fast_tag, auto first_tag) __attribute__((always_inline)) {
@@ -535,7 +561,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
             stage_to_lds(s + 1, m1, nxt);
             fetch(s + 2, m2);
         }
-        if constexpr (NH == 1) refresh_signs(s);
+        if constexpr (NH == 1 && !kWoven) refresh_signs(s);
         if constexpr (NH > 1 && !FAST) publish_fragments(s + 1, std::true_type{});
         __builtin_amdgcn_sched_barrier(0);
         // B fragments: all 8 of a 16-row step are in registers before its first MFMA, and each register is refilled with the
@@ -562,7 +588,15 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
             }
             u32x4 a;
             if constexpr (NH > 1) a = *reinterpret_cast<const u32x4 *>(abuf + (s & 1) * kABytes + ((rg * kSteps + ks) * 64 + lane) * 16);
+            else if constexpr (kWoven) {
+                a = a_next;                                    // generated between the MFMAs of the step before
+                if (ks == kSteps - 1) {                        // the next step opens stage s + 1: its block's streams first, if it opens a block
+                    refresh_signs(s + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             else a = make_fragment(s, ks);
+            float wl2 = 0.0f, wu2 = 0.0f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = Operand<DT>::mfma(a, bq[t], acc[t]);
@@ -571,6 +605,10 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
                 if constexpr (FAST) {
                     if (ks == first) store_feature<BNT>(blk, nxt, so, sfc, t);
                     if (ks == first + 1) raw.row[t] = load_raw<DT>(next_base + t * row_bytes + off0);
+                }
+                if constexpr (kWoven) {                        // dword t / 2 of the next step's fragment: word + log behind MFMA t, the rest behind t + 1
+                    if ((t & 1) == 0) box_muller_begin(xoshiro128pp(gs[t >> 2]), wl2, wu2);
+                    else a_next[t >> 1] = box_muller_end<DT>(wl2, wu2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
