@@ -424,6 +424,25 @@ def test_sketch_and_randomized_layer_capture_into_a_hip_graph(monkeypatch):
     torch.cuda.synchronize()
     want = ref.rademacher(5, 130, 2048).double() @ data.double()
     assert float((out.cpu().double() - want).abs().max() / want.abs().max()) < 2.0**-7
+    # the Gaussian sketch with S from memory is three launches (fragments, product, reduce) on the stream: captured and replayed, seed
+    # by value and seed in device memory, it gives the eager call's bits
+    assert 'from memory' in cabi.describe_sketch('gaussian', 2048, 512, 130)['kernel']
+    gws = torch.empty(cabi.sketch_workspace_bytes('gaussian', 2048, 512, 130), dtype=torch.uint8, device=DEV)
+    gout = torch.empty(130, 512, device=DEV, dtype=torch.bfloat16)
+    word = torch.tensor([77], dtype=torch.int64, device=DEV)
+    for seed in (77, word):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            cabi.sketch('gaussian', m, 130, seed, 0.5, out=gout, workspace=gws)
+        torch.cuda.current_stream().wait_stream(side)
+        gg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gg):
+            cabi.sketch('gaussian', m, 130, seed, 0.5, out=gout, workspace=gws)
+        gout.zero_()
+        gg.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gout, cabi.sketch('gaussian', m, 130, 77, 0.5)) and float(gout.float().abs().max()) > 0
+        del gg
     # a layer step: forward + backward of RandomizedLinear inside one graph
     lin = fewbit.RandomizedLinear(64, 32, proj_dim_ratio=0.25, matmul='rademacher', device=DEV)
     x = torch.zeros(512, 64, device=DEV, requires_grad=True)
