@@ -304,6 +304,40 @@ def test_inputs_beyond_four_gib_against_the_materialised_matrix(dist, dtype, row
     assert torch.allclose(moved, S @ m[rows - tail:].to(op).double(), rtol=0, atol=float(want.abs().max()) * 2 * out_eps + 1e-2)
 
 
+def test_half_a_gigabyte_of_fragments_against_the_materialised_matrix():
+    """S from memory with a long input: 2^20 + 3 rows, 200 rows of S = 537 MB of fragments (fragment offsets past 2^29, 4097 blocks of
+    256 rows, the last one nearly empty), sliced rows with bf16 partial sums -- against S itself times m in fp64, in row chunks"""
+    rows, features, proj, seed = 2**20 + 3, 264, 200, 0x5eed0123456789
+    plan = cabi.describe_sketch('gaussian', rows, features, proj)
+    assert 'from memory' in plan['kernel'] and plan['s_fragment_bytes'] == (8 * 4097 * 16 + 4) * 1024 > 2**29 and plan['partial_sums'] == 'bf16'
+    m = torch.randn(rows, features, generator=torch.Generator(device=DEV).manual_seed(6), device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    got = cabi.sketch('gaussian', m, proj, seed)
+    assert torch.equal(got, cabi.sketch('gaussian', m, proj, seed))
+    want = torch.zeros(proj, features, dtype=torch.float64, device=DEV)
+    bound = torch.zeros_like(want)
+    parts = torch.zeros_like(want)
+    ks, step = plan['k_slice'], 2**17
+    for z0 in range(0, rows, ks):
+        pz = torch.zeros_like(want)
+        for r0 in range(z0, min(z0 + ks, rows), step):
+            n = min(step, min(z0 + ks, rows) - r0)
+            S = cabi.sketch_matrix('gaussian', torch.bfloat16, seed, proj, n, 0, r0).double()
+            mm = m[r0:r0 + n].double()
+            pz += S @ mm
+            bound += S.abs() @ mm.abs()
+        want += pz
+        parts += pz.abs()
+    err = (got.double() - want).abs()
+    assert bool((err <= 2.0**-7 * want.abs() + 2.0**-8 * parts * 1.01 + 2.0**-24 * rows**0.5 * 16 * bound).all()), float((err / bound).max())
+    assert float(want.abs().mean()) > 100.0
+    try:                                             # the fused kernel on the same input: the same sums up to the slices' roundings
+        cabi.tune_sketch_materialise(0)
+        fused = cabi.sketch('gaussian', m, proj, seed)
+    finally:
+        cabi.tune_sketch_materialise(-1)
+    assert bool(((fused.double() - got.double()).abs() <= 2.0**-6 * want.abs() + 2.0**-7 * parts).all())
+
+
 def test_unsupported_sizes_are_refused_not_wrapped():
     wide = torch.zeros(8, 8 * 2**20, dtype=torch.bfloat16, device=DEV)      # a K stage of this row stride spans > 2 GiB
     with pytest.raises(cabi.FewbitHipError, match='leading dimension'):
