@@ -17,6 +17,10 @@ CLASSES = (('sketch', ('fewbit_hip::sketch::', )), ('fewbit activation', ('fewbi
            ('reduce', ('reduce', 'Reduce')))
 
 
+def classify(name):
+    return next((c for c, keys in CLASSES if any(k in name for k in keys)), 'other')
+
+
 def main():
     root, steps = sys.argv[1], int(sys.argv[2])
     hits = sorted(glob.glob(os.path.join(root, '**', '*kernel_stats.csv'), recursive=True))
@@ -27,7 +31,7 @@ def main():
         for row in csv.DictReader(f):
             name, ns, calls = row['Name'], float(row['TotalDurationNs']), int(row['Calls'])
             total += ns
-            cls = next((c for c, keys in CLASSES if any(k in name for k in keys)), 'other')
+            cls = classify(name)
             a = acc.setdefault(cls, [0.0, 0])
             a[0] += ns
             a[1] += calls
