@@ -389,7 +389,9 @@ def sketch_workspace_bytes(dist: str, rows: int, features: int, proj: int, dtype
 def sketch(dist: str, m: torch.Tensor, proj: int, seed, scale: float = 1.0, out: Optional[torch.Tensor] = None,
            workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
     """``scale * S @ m`` for the ``proj x rows`` random matrix S(seed) of kind ``dist`` ('rademacher' / 'gaussian'), which is
-    never materialised.  ``m``: 2-D, rows x features, unit stride along the features (any row stride).  ``seed``: an int, or a
+    never kept (generated inside the product kernel, or -- Gaussian, 16-bit ``m`` wider than 256 features -- written once into the
+    workspace as MFMA fragments and read back).  ``m``: 2-D, rows x features, unit stride along the features (any row stride).
+    ``workspace``: ``sketch_workspace_bytes(...)`` bytes of scratch, allocated here when not given.  ``seed``: an int, or a
     one-element int64 tensor on the device of ``m`` whose value is read when the kernel runs (``next_sketch_seed``)."""
     if m.device.type != 'cuda':
         raise FewbitHipError(f'm must live on the GPU (got {m.device})')
