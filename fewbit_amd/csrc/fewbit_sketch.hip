@@ -1150,11 +1150,12 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // S in memory first?  The Gaussian sketch (a fragment costs ~100 issue slots; Rademacher's 8 are not worth a byte of traffic) of
 // a 16-bit INPUT, when at least two column tiles would otherwise regenerate it and its fragments (bf16, rows of S padded to
 // 256, rows of M to 256) stay under 1 GiB.  Not for fp32 input that is rounded to bf16 first, although stand-alone it is 5-15 %
-// faster there too (16384 x 768, p = 3276: 130 against 142 us): inside an fp32 model the step got SLOWER with it on thirteen of
-// seventeen leases (RoBERTa-base fp32, arms interleaved in one process: 1.10-1.18x vanilla against 1.09-1.12x fused; 1.05-1.09x
-// on the other four) -- every other kernel of the step, the fp32 GEMMs first, ran 5-9 % longer: the same GPU cycles and L2
-// traffic at a lower shader clock (rocprofv3 --pmc, profiles/r05_insitu_pmc_roberta.txt), well under the package power cap --
-// while bf16 models gained on every box (1.53-1.56x against 1.63-1.68x);
+// faster there too (16384 x 768, p = 3276: 130 against 142 us): inside an fp32 model the step got SLOWER with it on fourteen of
+// twenty-four leases (RoBERTa-base fp32, arms interleaved in one process: 1.10-1.18x vanilla against 1.09-1.12x fused; 1.05-1.09x
+// on the other ten) -- every other kernel of the step, the fp32 GEMMs first, ran 5-9 % longer: the same GPU cycles and L2
+// traffic at a lower shader clock (rocprofv3 --pmc, profiles/r05_insitu_pmc_roberta.txt), well under the package power cap.  It
+// follows the box's power-management firmware (behind on SMC 04.86.10 / 04.86.15, ahead on 04.86.16:
+// profiles/r05_box_fingerprints.txt); bf16 models gained on every box (1.53-1.56x against 1.63-1.68x);
 // profiles/r05_roberta_ab_*.txt, DESIGN.md 5.1.  tune: 0 never, 1 whenever possible (fp32 input included), -1 this policy.
 FEWBIT_HIDDEN std::atomic<long long> g_forced_materialise{-1};
 size_t fragment_blocks(size_t rows) { return (rows + 255) / 256; }                  // 256-row blocks of M = 16 MFMA steps each

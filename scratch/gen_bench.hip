@@ -97,7 +97,13 @@ __device__ __forceinline__ uint32_t bm8(uint32_t h) {            // Box-Muller p
 }
 // GEN: 0 constant operand, 1 Philox-10 per fragment + bm16 (round 4), 2 xoshiro128++ x4 + bm16 (round 5), 3 xoshiro x2 + bm8,
 //      4 xoshiro x4 only (no Box-Muller), 5 bm16 only (words = counter), 6 Philox-10 per TWO fragments + bm8
-struct GenState { uint32_t s0[4], s1[4]; uint32_t ctr; uint32_t w[4]; };
+//      7 xoshiro x4 + inverse-CDF table in LDS (16384 half-normal bf16 entries, 2 gathers per dword, signs from bits 15 / 31)
+struct GenState { uint32_t s0[4], s1[4]; uint32_t ctr; uint32_t w[4]; const uint8_t *table; };
+__device__ __forceinline__ uint32_t table_pair(const uint8_t *table, uint32_t w) {
+    const uint32_t lo = *reinterpret_cast<const uint16_t *>(table + ((w << 1) & 0x7ffeu));
+    const uint32_t hi = *reinterpret_cast<const uint16_t *>(table + ((w >> 15) & 0x7ffeu));
+    return (lo | (hi << 16)) ^ (w & 0x80008000u);
+}
 template <int GEN> __device__ __forceinline__ u32x4 generate(GenState &g, Key key, int step) {
     u32x4 a;
     if constexpr (GEN == 0) { a = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; }
@@ -111,8 +117,16 @@ template <int GEN> __device__ __forceinline__ u32x4 generate(GenState &g, Key ke
         const uint32_t w0 = g.w[2 * (step & 1)], w1 = g.w[2 * (step & 1) + 1];
         a[0] = bm8(w0); a[1] = bm8(w0 >> 16); a[2] = bm8(w1); a[3] = bm8(w1 >> 16);
     }
+    else if constexpr (GEN == 7) {
+        a[0] = table_pair(g.table, xoshiro(g.s0)); a[1] = table_pair(g.table, xoshiro(g.s0));
+        a[2] = table_pair(g.table, xoshiro(g.s1)); a[3] = table_pair(g.table, xoshiro(g.s1));
+    }
     return a;
 }
+#define GEN_TABLE(G, g, nthreads)                                                                                                \
+    __shared__ __attribute__((aligned(16))) uint16_t gtable[(G) == 7 ? 16384 : 8];                                               \
+    if constexpr ((G) == 7) { for (int i = threadIdx.x; i < 16384; i += (nthreads)) gtable[i] = static_cast<uint16_t>(0x3c00u + (i >> 4)); } \
+    (g).table = reinterpret_cast<const uint8_t *>(gtable);
 
 // the product kernel's shape: per step the fragment, then 8 MFMAs each followed by one conflict-free ds_read_b128 (B operand);
 // 8 steps per "stage" and a barrier.  The generator is a clump in front of the step's MFMAs, as hipcc places it in the kernel.
@@ -127,6 +141,8 @@ template <int GEN, int WAVES> __global__ __launch_bounds__(64 * WAVES) void gen_
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
     GenState g;
+    GEN_TABLE(GEN, g, 64 * WAVES)
+    __syncthreads();
     const Key key{seed, seed ^ 0x5555u};
     philox<10>(threadIdx.x, blockIdx.x, 0, 2, key, g.s0);
     philox<10>(threadIdx.x, blockIdx.x, 1, 2, key, g.s1);
@@ -167,6 +183,8 @@ template <int GEN, int WAVES> __global__ __launch_bounds__(64 * WAVES) void gen_
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
     GenState g;
+    GEN_TABLE(GEN, g, 64 * WAVES)
+    __syncthreads();
     const Key key{seed, seed ^ 0x5555u};
     philox<10>(threadIdx.x, blockIdx.x, 0, 2, key, g.s0);
     philox<10>(threadIdx.x, blockIdx.x, 1, 2, key, g.s1);
@@ -206,6 +224,9 @@ template <int GEN> __global__ __launch_bounds__(512) void gen_special(float *out
     __syncthreads();
     uint8_t *abuf = lds + 16384;
     float s = 0.0f;
+    GenState g;
+    GEN_TABLE(GEN, g, 512)
+    __syncthreads();
     if (wave < 4) {
         f32x16 acc[8];
 #pragma unroll
@@ -233,7 +254,6 @@ template <int GEN> __global__ __launch_bounds__(512) void gen_special(float *out
 #pragma unroll
         for (int t = 0; t < 8; ++t) s += acc[t][0] + acc[t][7];
     } else {
-        GenState g;
         const Key key{seed, seed ^ 0x5555u};
         philox<10>(threadIdx.x, blockIdx.x, 0, 2, key, g.s0);
         philox<10>(threadIdx.x, blockIdx.x, 1, 2, key, g.s1);
@@ -281,11 +301,11 @@ int main() {
     FILLN(0, 8); FILLN(0, 4);
     FILL(1, 4, 8); FILL(1, 8, 8); FILL(2, 4, 8); FILL(2, 8, 8); FILL(3, 4, 8); FILL(3, 8, 8); FILL(4, 4, 8); FILL(4, 8, 8);
     FILL(5, 8, 8); FILL(6, 8, 8); FILL(7, 4, 8); FILL(7, 8, 8); FILL(8, 8, 8); FILL(8, 16, 8);
-    printf("# B: generator candidates beside 8 MFMAs + 8 ds_read_b128 per step (gen0 none, 1 Philox-10 + BM16 = round 4, 2 xoshiro x4 + BM16 = round 5, 3 xoshiro x2 + BM8, 4 xoshiro x4 only, 5 BM16 only, 6 Philox-10 per two fragments + BM8)\n");
-    GEN(0, 8); GEN(1, 8); GEN(2, 8); GEN(3, 8); GEN(4, 8); GEN(5, 8); GEN(6, 8);
-    GEN(0, 4); GEN(1, 4); GEN(2, 4); GEN(3, 4);
+    printf("# B: generator candidates beside 8 MFMAs + 8 ds_read_b128 per step (gen0 none, 1 Philox-10 + BM16 = round 4, 2 xoshiro x4 + BM16 = round 5, 3 xoshiro x2 + BM8, 4 xoshiro x4 only, 5 BM16 only, 6 Philox-10 per two fragments + BM8, 7 xoshiro x4 + 32 KB inverse-CDF table in LDS)\n");
+    GEN(0, 8); GEN(1, 8); GEN(2, 8); GEN(3, 8); GEN(4, 8); GEN(5, 8); GEN(6, 8); GEN(7, 8);
+    GEN(0, 4); GEN(1, 4); GEN(2, 4); GEN(3, 4); GEN(7, 4);
     printf("# C: wave specialisation, 4 multiply waves + 4 generator waves per workgroup (ns per MFMA per SIMD counts the 4 multiply waves)\n");
     timeit("special gen0", gen_special<0>, 512, out, 32); timeit("special gen1", gen_special<1>, 512, out, 32); timeit("special gen2", gen_special<2>, 512, out, 32);
-    timeit("special gen3", gen_special<3>, 512, out, 32); timeit("special gen5", gen_special<5>, 512, out, 32);
+    timeit("special gen3", gen_special<3>, 512, out, 32); timeit("special gen5", gen_special<5>, 512, out, 32); timeit("special gen7", gen_special<7>, 512, out, 32);
     return 0;
 }
