@@ -126,8 +126,8 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_xoshiro128pp.restype = None
         L.fewbit_hip_xoshiro128pp.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), sz]
         # FEWBIT_SKETCH_MATERIALISE=0|1: the Gaussian sketch never / whenever possible through the S-from-memory path (the built-in
-        # policy takes it for 16-bit input only: inside fp32 models it gained 3 % of the step on half the boxes of the pool and lost
-        # 5 % on the other half, profiles/r05_roberta_ab_fp32_boxes.txt)
+        # policy takes it for 16-bit input, and for fp32 input on layers of 2048 features or more: on the narrower layers of an fp32
+        # model it gained 3 % of the step on some boxes of the pool and lost 5 % on the others, profiles/r05_roberta_ab_width.txt)
         forced = os.environ.get('FEWBIT_SKETCH_MATERIALISE', '')
         if forced in ('0', '1'):
             L.fewbit_hip_sketch_tune_materialise(int(forced))
@@ -488,7 +488,7 @@ def tune_sketch_partials(bf16_partials: int) -> None:
 
 def tune_sketch_materialise(materialise: int) -> None:
     """measurement hook: Gaussian S written to the workspace once as MFMA fragments and read back by the product kernel (1),
-    always regenerated inside the product kernel (0), built-in policy (-1)"""
+    always regenerated inside the product kernel (0), built-in policy (-1), the policy with the width rule of fp32 input inverted (2)"""
     _check(lib().fewbit_hip_sketch_tune_materialise(int(materialise)))
 
 

@@ -1147,16 +1147,20 @@ bool converts_first(int dtype, size_t rows, size_t proj) {
 constexpr size_t kWorkspaceAlign = 256;
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// S in memory first?  The Gaussian sketch (a fragment costs ~100 issue slots; Rademacher's 8 are not worth a byte of traffic) of
-// a 16-bit INPUT, when at least two column tiles would otherwise regenerate it and its fragments (bf16, rows of S padded to
-// 256, rows of M to 256) stay under 1 GiB.  Not for fp32 input that is rounded to bf16 first, although stand-alone it is 5-15 %
-// faster there too (16384 x 768, p = 3276: 130 against 142 us): inside an fp32 model the step got SLOWER with it on fourteen of
-// twenty-four leases (RoBERTa-base fp32, arms interleaved in one process: 1.10-1.18x vanilla against 1.09-1.12x fused; 1.05-1.09x
-// on the other ten) -- every other kernel of the step, the fp32 GEMMs first, ran 5-9 % longer: the same GPU cycles and L2
-// traffic at a lower shader clock (rocprofv3 --pmc, profiles/r05_insitu_pmc_roberta.txt), well under the package power cap.  It
-// follows the box's power-management firmware (behind on SMC 04.86.10 / 04.86.15, ahead on 04.86.16:
-// profiles/r05_box_fingerprints.txt); bf16 models gained on every box (1.53-1.56x against 1.63-1.68x);
-// profiles/r05_roberta_ab_*.txt, DESIGN.md 5.1.  tune: 0 never, 1 whenever possible (fp32 input included), -1 this policy.
+// S in memory first?  The Gaussian sketch (a fragment costs ~100 issue slots; Rademacher's 8 are not worth a byte of traffic) when
+// at least two column tiles would otherwise regenerate it and its fragments (bf16, rows of S padded to 256, rows of M to 256) stay
+// under 1 GiB -- for a 16-bit INPUT always, for fp32 input that is rounded to bf16 first only on layers at least kWideLayer
+// features wide.  Stand-alone it is 5-15 % faster on narrow fp32 layers too (16384 x 768, p = 3276: 130 against 142 us), but
+// inside an fp32 model every other kernel of the step, the fp32 GEMMs first, then ran 5-9 % longer on most boxes: the same GPU
+// cycles and L2 traffic at a lower shader clock (rocprofv3 --pmc, profiles/r05_insitu_pmc_roberta.txt), well under the package
+// power cap, mostly on the older power-management firmware of the pool (profiles/r05_box_fingerprints.txt).  RoBERTa-base fp32,
+// arms interleaved in one process, seven leases (profiles/r05_roberta_ab_width.txt): every fragment launch costs the rest of
+// the step 40-70 us there -- more than a 768-wide product gains (S from memory on those 120 of the step's 144 products only:
+// 1.07-1.18x vanilla against 1.084-1.096x fused), less than a 3072-wide one gains (71 us; on those 24 only: 1.065-1.088x, ahead
+// of the fused kernel by 0.7-1.8 % on all seven).  bf16 models gained on every box (1.53-1.56x against 1.63-1.68x);
+// DESIGN.md 5.1.  tune: 0 never, 1 whenever possible (any fp32 input included), -1 this policy, 2 the policy with the width rule
+// of fp32 input inverted (the measurement arm "narrow layers only").
+constexpr size_t kWideLayer = 2048;
 FEWBIT_HIDDEN std::atomic<long long> g_forced_materialise{-1};
 size_t fragment_blocks(size_t rows) { return (rows + 255) / 256; }                  // 256-row blocks of M = 16 MFMA steps each
 size_t fragment_row_blocks(size_t proj) { return (proj + 255) / 256 * 8; }          // 32-row blocks of S, padded to whole 256-row tiles
@@ -1166,7 +1170,8 @@ bool materialises(int dist, int operand_dtype, bool converted, size_t rows, size
     const long long forced = g_forced_materialise.load(std::memory_order_relaxed);
     if (forced == 0 || fragment_row_blocks(proj) > 65535) return false;
     if (forced == 1) return true;
-    return !converted && features > BN && fragment_bytes(rows, proj) <= (1ull << 30);
+    const bool wide = features >= kWideLayer;
+    return (!converted || (forced == 2 ? !wide : wide)) && features > BN && fragment_bytes(rows, proj) <= (1ull << 30);
 }
 
 // the workspace of one call: [partial sums][bf16 copy of an fp32 M][A fragments of S], each part aligned to kWorkspaceAlign
@@ -1323,7 +1328,7 @@ int fewbit_hip_sketch_tune_partials(long long bf16_partials) {
 }
 
 int fewbit_hip_sketch_tune_materialise(long long materialise) {
-    if (materialise < -1 || materialise > 1) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: materialise is 0 (never), 1 (whenever possible) or -1 (policy), got %lld", materialise);
+    if (materialise < -1 || materialise > 2) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: materialise is 0 (never), 1 (whenever possible), -1 (policy) or 2 (fp32 input: narrow layers instead of wide ones), got %lld", materialise);
     g_forced_materialise.store(materialise, std::memory_order_relaxed);
     return FEWBIT_OK;
 }

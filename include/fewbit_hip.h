@@ -218,9 +218,10 @@ int fewbit_hip_sketch_tune_convert(long long convert);
 int fewbit_hip_sketch_tune_partials(long long bf16_partials);
 /* Gaussian sketch of a layer wider than one 256-feature tile: S is generated ONCE, by a VALU-only kernel, into the workspace as the
  * bf16 / fp16 A fragments of the matrix pipe, and the product kernel reads them back (instead of every column tile regenerating
- * its rows of S beside its MFMAs): 0 never (always the fused kernel), 1 whenever possible, -1 the policy (16-bit input, features >
- * 256 and the fragments <= 1 GiB; fp32 input keeps the fused kernel: inside fp32 models the extra scratch traffic cost more than it
- * saved on most boxes).  The same S either way.  fewbit_hip_sketch_workspace follows the setting. */
+ * its rows of S beside its MFMAs): 0 never (always the fused kernel), 1 whenever possible, -1 the policy (features > 256 and the
+ * fragments <= 1 GiB; fp32 input that is rounded to bf16 first only on layers of 2048 features or more: inside fp32 models every
+ * fragment launch slowed the rest of the step by more than a narrower product gains, on most boxes), 2 that policy with the width
+ * rule of fp32 input inverted (a measurement arm).  The same S either way.  fewbit_hip_sketch_workspace follows the setting. */
 int fewbit_hip_sketch_tune_materialise(long long materialise);
 /* Philox4x32-10 on the HOST (the generator behind S; known-answer tests run it without a GPU) */
 void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);

@@ -123,7 +123,8 @@ def test_gaussian_fragments_from_memory_are_the_fused_kernels_matrix():
     first and for a device-resident seed"""
     assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 3072, 3276)['kernel']
     assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 768, 3276)['kernel']
-    assert 'from memory' not in cabi.describe_sketch('gaussian', 16384, 768, 3276, torch.float32)['kernel']        # fp32 input: the fused kernel by policy
+    assert 'from memory' not in cabi.describe_sketch('gaussian', 16384, 768, 3276, torch.float32)['kernel']        # fp32 input: the fused kernel by policy ...
+    assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 3072, 3276, torch.float32)['kernel']           # ... on layers narrower than 2048 features
     try:
         cabi.tune_sketch_materialise(1)                                                                             # ... unless asked for
         assert 'from memory' in cabi.describe_sketch('gaussian', 16384, 768, 3276, torch.float32)['kernel']        # (converted to bf16 first)
@@ -207,14 +208,16 @@ def test_row_slices_are_deterministic_and_agree():
 
 
 def test_fp32_input_rounded_first_with_and_without_gaussian_fragments_from_memory():
-    """fp32 input with many row tiles: conversion pass, then the fused kernel (the policy for fp32 input) or -- forced -- fragment
-    pass + product from memory; ragged widths, a row stride, a very long and a very short input"""
+    """fp32 input with many row tiles: conversion pass, then the fused kernel (the policy for fp32 input narrower than 2048 features) or
+    -- forced, or by policy on a wide layer -- fragment pass + product from memory; ragged widths, a row stride, a very long and a
+    very short input"""
     try:
-        for rows, features, proj, ld in ((3000, 770, 1400, None), (520, 264, 1300, 272), (70000, 40, 1290, None), (300, 1032, 2000, 1040)):
-            for mem in (-1, 1):                      # the policy keeps fp32 input on the fused kernel; 1 forces S from memory
+        for rows, features, proj, ld in ((3000, 770, 1400, None), (520, 264, 1300, 272), (70000, 40, 1290, None), (300, 1032, 2000, 1040), (700, 2056, 1300, None)):
+            for mem in (-1, 1, 2):                   # the policy keeps narrow fp32 input on the fused kernel; 1 forces S from memory; 2 = narrow instead of wide
                 cabi.tune_sketch_materialise(mem)
                 plan = cabi.describe_sketch('gaussian', rows, features, proj, torch.float32)
-                assert plan['converted_to_bf16_first'] is True and ('from memory' in plan['kernel']) == (mem == 1)
+                want = mem == 1 or (features > 256 and (features >= 2048) == (mem == -1))
+                assert plan['converted_to_bf16_first'] is True and ('from memory' in plan['kernel']) == want, (plan, mem)
                 _product_case('gaussian', torch.float32, rows, features, proj, seed=rows, ld=ld)
     finally:
         cabi.tune_sketch_materialise(-1)

@@ -123,9 +123,9 @@ def _plan(dist, dtype, rows, features, proj):
 
 
 def test_data_path_policy_of_the_sketch_without_a_gpu():
-    """which of the data paths a call takes: Gaussian S from memory for 16-bit input wider than one tile, the fused
-    kernel for fp32 input (FEWBIT_SKETCH_MATERIALISE=1 overrides) and for Rademacher; bf16 partial sums for sliced bf16 operands;
-    the workspace is the sum of its parts"""
+    """which of the data paths a call takes: Gaussian S from memory for 16-bit input wider than one tile and for fp32
+    input of 2048 features or more, the fused kernel for narrower fp32 input (FEWBIT_SKETCH_MATERIALISE=1 overrides) and for
+    Rademacher; bf16 partial sums for sliced bf16 operands; the workspace is the sum of its parts"""
     g = _plan('gaussian', torch.bfloat16, 16384, 768, 3276)
     assert 'from memory' in g['kernel'] and g['grid'] == [3, 13, 6] and g['partial_sums'] == 'bf16'
     frag = (13 * 8 * 64 * 16 + 4) * 1024
@@ -138,6 +138,10 @@ def test_data_path_policy_of_the_sketch_without_a_gpu():
     f = _plan('gaussian', torch.float32, 16384, 768, 3276)                                                # fp32 input: rounded to bf16 first, fused kernel
     assert f['converted_to_bf16_first'] is True and 'from memory' not in f['kernel'] and f['partial_sums'] == 'bf16'
     assert f['workspace_bytes'] == -(-(f['grid'][2] * 3276 * 768 * 2) // 256) * 256 + 16384 * 768 * 2
+    w = _plan('gaussian', torch.float32, 16384, 3072, 3276)                                               # ... a wide layer: S from memory
+    assert w['converted_to_bf16_first'] is True and 'from memory' in w['kernel'] and w['s_fragment_bytes'] == frag
+    assert w['workspace_bytes'] == -(-(-(-(w['grid'][2] * 3276 * 3072 * 2) // 256) * 256 + 16384 * 3072 * 2) // 256) * 256 + frag
+    assert 'from memory' not in _plan('gaussian', torch.float32, 16384, 2040, 3276)['kernel'] and 'from memory' in _plan('gaussian', torch.float32, 16384, 2048, 3276)['kernel']
     small = _plan('rademacher', torch.float32, 16384, 768, 200)                                           # fp32 operand staged in the kernel
     assert small['converted_to_bf16_first'] is False and small['partial_sums'] == 'fp32'
     code = ("import ctypes, json, torch; from fewbit_amd import cabi; L = cabi.lib(); b = ctypes.create_string_buffer(1024); "
