@@ -94,6 +94,36 @@ template <int W, int NH = 1> struct Tile {
 };
 // internal "distribution" of the product kernel: the A fragments were written to memory beforehand (sketch_fragments_kernel)
 constexpr int kFromMemory = 2;
+// measurement builds only (scratch/roberta_ab_variants.sh; WRONG results): 1 = the product kernel reads whatever the workspace holds, no
+// fragment launch; 2 = the fragment launch, then the fused product kernel on the one-half plan (the fragments are not read)
+#ifndef FEWBIT_SKETCH_ABLATE_FRAGMENTS
+#define FEWBIT_SKETCH_ABLATE_FRAGMENTS 0
+#endif
+// measurement builds: non-temporal stores of the fragments / non-temporal loads of them in the product kernel / the fragment launch in
+// front of the conversion pass of an fp32 input instead of behind it
+#ifndef FEWBIT_FRAG_STORE_NT
+#define FEWBIT_FRAG_STORE_NT 0
+#endif
+#ifndef FEWBIT_FRAG_LOAD_NT
+#define FEWBIT_FRAG_LOAD_NT 0
+#endif
+#ifndef FEWBIT_FRAG_FIRST
+#define FEWBIT_FRAG_FIRST 0
+#endif
+template <typename T> __device__ __forceinline__ void frag_store(T *p, T v) {
+#if FEWBIT_FRAG_STORE_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+template <typename T> __device__ __forceinline__ T frag_load(const T *p) {
+#if FEWBIT_FRAG_LOAD_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 #ifndef FEWBIT_FRAG_AHEAD
 #define FEWBIT_FRAG_AHEAD 4
 #endif
@@ -479,13 +509,13 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
         static_assert(kSteps % kAhead == 0, "the register ring is indexed by the step within a stage");
         afrag = static_cast<const uint8_t *>(frags) + (((m0 / 32 + rg) * frag_steps + (k_begin >> 4)) * 64 + lane) * 16;
 #pragma unroll
-        for (int d = 0; d < kAhead; ++d) apre[d] = *reinterpret_cast<const u32x4 *>(afrag + static_cast<size_t>(d) * 1024);
+        for (int d = 0; d < kAhead; ++d) apre[d] = frag_load(reinterpret_cast<const u32x4 *>(afrag + static_cast<size_t>(d) * 1024));
     }
     // (Gaussian streams and fragments from memory: called ONCE per step and in step order -- every call consumes the next words)
     auto make_fragment = [&](size_t st, int ks) __attribute__((always_inline)) -> u32x4 {
         if constexpr (DIST == kFromMemory) {
             const u32x4 a = apre[ks % kAhead];
-            apre[ks % kAhead] = *reinterpret_cast<const u32x4 *>(afrag + (st * kSteps + ks + kAhead) * 1024);
+            apre[ks % kAhead] = frag_load(reinterpret_cast<const u32x4 *>(afrag + (st * kSteps + ks + kAhead) * 1024));
             return a;
         }
         else if constexpr ((FEWBIT_SKETCH_ABLATE & 4) != 0) return u32x4{srow, srow, srow, srow};
@@ -883,7 +913,7 @@ __device__ __forceinline__ void fragments_of_block(Key key, size_t b4, size_t rb
         uint32_t signs[4];
         philox4x32(srow, blk, 0u, 0u, key, signs);
 #pragma unroll
-        for (int st = 0; st < 16; ++st) dst[st * 64] = rademacher_fragment<DT>(signs, st);
+        for (int st = 0; st < 16; ++st) frag_store(dst + st * 64, rademacher_fragment<DT>(signs, st));
     } else {
         uint32_t g0[4], g1[4];
         philox4x32<kGaussianRounds>(srow, blk, 0u, 2u, key, g0);
@@ -895,7 +925,7 @@ __device__ __forceinline__ void fragments_of_block(Key key, size_t b4, size_t rb
             a[1] = gaussian_pair<DT>(xoshiro128pp(g0));
             a[2] = gaussian_pair<DT>(xoshiro128pp(g1));
             a[3] = gaussian_pair<DT>(xoshiro128pp(g1));
-            dst[st * 64] = a;
+            frag_store(dst + st * 64, a);
         }
     }
 }
@@ -1223,6 +1253,14 @@ static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t 
     if (L.total != 0 && (workspace == nullptr || workspace_bytes < L.total))
         return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", L.total, workspace_bytes);
     uint8_t *ws = static_cast<uint8_t *>(workspace);
+    auto launch_fragments = [&]() {
+        const size_t nblocks = fragment_blocks(rows);
+        const dim3 grid(static_cast<unsigned>((nblocks + 3) / 4), static_cast<unsigned>(fragment_row_blocks(proj)));
+        u32x4 *frag = reinterpret_cast<u32x4 *>(ws + L.frag_off);
+        if (L.operand_dtype == FEWBIT_F16) hipLaunchKernelGGL((sketch_fragments_kernel<FEWBIT_SKETCH_GAUSSIAN, FEWBIT_F16>), grid, dim3(256), 0, s, key.value, key.device, nblocks, frag);
+        else hipLaunchKernelGGL((sketch_fragments_kernel<FEWBIT_SKETCH_GAUSSIAN, FEWBIT_BF16>), grid, dim3(256), 0, s, key.value, key.device, nblocks, frag);
+    };
+    if (FEWBIT_FRAG_FIRST != 0 && L.materialised && FEWBIT_SKETCH_ABLATE_FRAGMENTS != 1) launch_fragments();
     if (L.converted) {                                // fp32 input, many row tiles: rounded to bf16 once
         uint16_t *copy = reinterpret_cast<uint16_t *>(ws + L.copy_off);
         const size_t pieces = rows * ((features + 7) / 8);
@@ -1233,10 +1271,11 @@ static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t 
     const float fscale = static_cast<float>(scale);
     if (L.materialised) {                             // S once, as A fragments; then the product kernel that reads them
         const size_t nblocks = fragment_blocks(rows);
-        const dim3 grid(static_cast<unsigned>((nblocks + 3) / 4), static_cast<unsigned>(fragment_row_blocks(proj)));
         u32x4 *frag = reinterpret_cast<u32x4 *>(ws + L.frag_off);
-        if (L.operand_dtype == FEWBIT_F16) hipLaunchKernelGGL((sketch_fragments_kernel<FEWBIT_SKETCH_GAUSSIAN, FEWBIT_F16>), grid, dim3(256), 0, s, key.value, key.device, nblocks, frag);
-        else hipLaunchKernelGGL((sketch_fragments_kernel<FEWBIT_SKETCH_GAUSSIAN, FEWBIT_BF16>), grid, dim3(256), 0, s, key.value, key.device, nblocks, frag);
+        if (FEWBIT_FRAG_FIRST == 0 && FEWBIT_SKETCH_ABLATE_FRAGMENTS != 1) launch_fragments();
+#if FEWBIT_SKETCH_ABLATE_FRAGMENTS == 2
+        return launch_dtype<FEWBIT_SKETCH_GAUSSIAN>(L.operand_dtype, m, rows, features, ld, proj, key, fscale, out, dtype, workspace, L.partial_bytes, Frags{nullptr, 0}, s);
+#endif
         // (the kFragAhead steps of padding behind the last fragment are read, never used: any bytes will do)
         return launch_dtype<kFromMemory>(L.operand_dtype, m, rows, features, ld, proj, key, fscale, out, dtype, workspace, L.partial_bytes, Frags{frag, nblocks * 16}, s);
     }

@@ -38,6 +38,9 @@ def steps(m, opt, n=6, warm=2):
 models = {k: make(k) for k in (None, 'gaussian')}
 arms = [('vanilla', None, -1), ('fused everywhere', 'gaussian', 0), ('S from memory everywhere', 'gaussian', 1),
         ('S from memory, 3072 wide only (policy)', 'gaussian', -1), ('S from memory, 768 wide only', 'gaussian', 2)]
+if os.environ.get('ARMS'):                       # e.g. ARMS=0,2: vanilla + the arms with those tune values
+    keep = {int(x) for x in os.environ['ARMS'].split(',')}
+    arms = [a for a in arms if a[1] is None or a[2] in keep]
 res = {a[0]: [] for a in arms}
 for r in range(rounds):
     for name, kind, mem in arms:
