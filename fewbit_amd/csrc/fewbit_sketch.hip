@@ -94,8 +94,10 @@ template <int W, int NH = 1> struct Tile {
 };
 // internal "distribution" of the product kernel: the A fragments were written to memory beforehand (sketch_fragments_kernel)
 constexpr int kFromMemory = 2;
-// measurement builds only (scratch/roberta_ab_variants.sh; WRONG results): 1 = the product kernel reads whatever the workspace holds, no
-// fragment launch; 2 = the fragment launch, then the fused product kernel on the one-half plan (the fragments are not read)
+// measurement builds only (scratch/run_round5_ag.sh; WRONG results): 1 = the product kernel reads whatever the workspace holds, no
+// fragment launch; 2 = the fragment launch, then the fused product kernel on the one-half plan (the fragments are not read); 3 / 4 = two
+// fragment regions, the product kernel reads the one the previous call wrote / one that is never written; 5 / 6 = 50 us of nothing
+// between fragment launch and product kernel (fresh / never-written region); 7 / 8 = the stored operand is +-1.0 / 0
 #ifndef FEWBIT_SKETCH_ABLATE_FRAGMENTS
 #define FEWBIT_SKETCH_ABLATE_FRAGMENTS 0
 #endif
@@ -925,6 +927,13 @@ __device__ __forceinline__ void fragments_of_block(Key key, size_t b4, size_t rb
             a[1] = gaussian_pair<DT>(xoshiro128pp(g0));
             a[2] = gaussian_pair<DT>(xoshiro128pp(g1));
             a[3] = gaussian_pair<DT>(xoshiro128pp(g1));
+#if FEWBIT_SKETCH_ABLATE_FRAGMENTS == 7        // (measurement builds: the same work and traffic, but the stored operand is +-1.0 -- the sign bits only -- or 0)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (a[e] & 0x80008000u) | 0x3f803f80u;
+#elif FEWBIT_SKETCH_ABLATE_FRAGMENTS == 8
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = a[e] == 0x12345678u ? 1u : 0u;
+#endif
             frag_store(dst + st * 64, a);
         }
     }
@@ -938,6 +947,12 @@ __global__ __launch_bounds__(256) void sketch_fragments_kernel(Key key, const Ke
 // interleaved in proportion, on the idea that one job is bound by memory and the other by VALU issue: 16384 x 768 fp32, p = 3276:
 // 132.7 against 130.1 us as two launches, 3072 wide 386.0 against 393.9, RoBERTa-base fp32 1.080x against 1.077x -- the generator's
 // 107 MB of stores and the conversion's 75 MB already share the memory system; profiles/r05_sketch_prepare_ab.txt.)
+
+// (measurement builds 5 / 6: ~50 us of nothing between the fragment launch and the product kernel -- one wave watching the 100 MHz clock)
+__global__ void sketch_pause_kernel(unsigned ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 
 // ---- seeds drawn on the device ----------------------------------------------------------------------------------------------
 // A launch recorded in a hipGraph replays its kernel ARGUMENTS: a seed passed by value would give every replay the same S.
@@ -1184,8 +1199,10 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // inside an fp32 model every other kernel of the step, the fp32 GEMMs first, then ran 5-9 % longer on most boxes: the same GPU
 // cycles and L2 traffic at a lower shader clock (rocprofv3 --pmc, profiles/r05_insitu_pmc_roberta.txt), well under the package
 // power cap, mostly on the older power-management firmware of the pool (profiles/r05_box_fingerprints.txt).  RoBERTa-base fp32,
-// arms interleaved in one process, seven leases (profiles/r05_roberta_ab_width.txt): every fragment launch costs the rest of
-// the step 40-70 us there -- more than a 768-wide product gains (S from memory on those 120 of the step's 144 products only:
+// arms interleaved in one process, seven leases (profiles/r05_roberta_ab_width.txt): every from-memory product costs the rest of
+// the step 40-70 us there (it is the operand: the same kernels on fragments of zeros cost nothing, on +-1 half --
+// profiles/r05_roberta_ab_variants.txt: the matrix pipe at its highest duty on full-entropy operands, and the clock goes down
+// behind it) -- more than a 768-wide product gains (S from memory on those 120 of the step's 144 products only:
 // 1.07-1.18x vanilla against 1.084-1.096x fused), less than a 3072-wide one gains (71 us; on those 24 only: 1.065-1.088x, ahead
 // of the fused kernel by 0.7-1.8 % on all seven).  bf16 models gained on every box (1.53-1.56x against 1.63-1.68x);
 // DESIGN.md 5.1.  tune: 0 never, 1 whenever possible (any fp32 input included), -1 this policy, 2 the policy with the width rule
@@ -1217,7 +1234,7 @@ Layout layout(int dist, int dtype, size_t rows, size_t features, size_t proj) {
                           ? static_cast<size_t>(p.gz) * proj * features * (partial16(L.operand_dtype, dtype, p.gz) ? sizeof(uint16_t) : sizeof(float)) : 0;
     size_t end = L.partial_bytes;
     if (L.converted) { L.copy_off = round_up(end, kWorkspaceAlign); L.copy_bytes = rows * features * sizeof(uint16_t); end = L.copy_off + L.copy_bytes; }
-    if (L.materialised) { L.frag_off = round_up(end, kWorkspaceAlign); L.frag_bytes = fragment_bytes(rows, proj); end = L.frag_off + L.frag_bytes; }
+    if (L.materialised) { L.frag_off = round_up(end, kWorkspaceAlign); L.frag_bytes = fragment_bytes(rows, proj) * (FEWBIT_SKETCH_ABLATE_FRAGMENTS >= 3 && FEWBIT_SKETCH_ABLATE_FRAGMENTS <= 6 ? 2 : 1);   /* (two regions in the measurement builds) */ end = L.frag_off + L.frag_bytes; }
     L.total = end;
     return L;
 }
@@ -1253,10 +1270,19 @@ static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t 
     if (L.total != 0 && (workspace == nullptr || workspace_bytes < L.total))
         return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", L.total, workspace_bytes);
     uint8_t *ws = static_cast<uint8_t *>(workspace);
+    // (measurement builds 3 / 4: two fragment regions; the product kernel reads the one this call did NOT write -- 3: the one the
+    // previous call wrote, 4: one that is never written)
+    size_t write_off = L.frag_off, read_off = L.frag_off;
+    if (FEWBIT_SKETCH_ABLATE_FRAGMENTS >= 3 && FEWBIT_SKETCH_ABLATE_FRAGMENTS <= 6 && L.materialised) {
+        static std::atomic<unsigned> calls{0};
+        const unsigned parity = FEWBIT_SKETCH_ABLATE_FRAGMENTS == 3 ? (calls.fetch_add(1) & 1u) : 0u;
+        write_off = L.frag_off + parity * (L.frag_bytes / 2);
+        read_off = FEWBIT_SKETCH_ABLATE_FRAGMENTS == 5 ? write_off : L.frag_off + (1u - parity) * (L.frag_bytes / 2);
+    }
     auto launch_fragments = [&]() {
         const size_t nblocks = fragment_blocks(rows);
         const dim3 grid(static_cast<unsigned>((nblocks + 3) / 4), static_cast<unsigned>(fragment_row_blocks(proj)));
-        u32x4 *frag = reinterpret_cast<u32x4 *>(ws + L.frag_off);
+        u32x4 *frag = reinterpret_cast<u32x4 *>(ws + write_off);
         if (L.operand_dtype == FEWBIT_F16) hipLaunchKernelGGL((sketch_fragments_kernel<FEWBIT_SKETCH_GAUSSIAN, FEWBIT_F16>), grid, dim3(256), 0, s, key.value, key.device, nblocks, frag);
         else hipLaunchKernelGGL((sketch_fragments_kernel<FEWBIT_SKETCH_GAUSSIAN, FEWBIT_BF16>), grid, dim3(256), 0, s, key.value, key.device, nblocks, frag);
     };
@@ -1271,8 +1297,9 @@ static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t 
     const float fscale = static_cast<float>(scale);
     if (L.materialised) {                             // S once, as A fragments; then the product kernel that reads them
         const size_t nblocks = fragment_blocks(rows);
-        u32x4 *frag = reinterpret_cast<u32x4 *>(ws + L.frag_off);
+        u32x4 *frag = reinterpret_cast<u32x4 *>(ws + read_off);
         if (FEWBIT_FRAG_FIRST == 0 && FEWBIT_SKETCH_ABLATE_FRAGMENTS != 1) launch_fragments();
+        if (FEWBIT_SKETCH_ABLATE_FRAGMENTS == 5 || FEWBIT_SKETCH_ABLATE_FRAGMENTS == 6) hipLaunchKernelGGL(sketch_pause_kernel, dim3(1), dim3(64), 0, s, 5000u);
 #if FEWBIT_SKETCH_ABLATE_FRAGMENTS == 2
         return launch_dtype<FEWBIT_SKETCH_GAUSSIAN>(L.operand_dtype, m, rows, features, ld, proj, key, fscale, out, dtype, workspace, L.partial_bytes, Frags{nullptr, 0}, s);
 #endif
