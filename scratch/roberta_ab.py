@@ -48,7 +48,7 @@ def arm(kind, mem, p16):
 
 
 arms = {'vanilla': lambda: steps(vanilla),
-        'gaussian (the policy: S from memory for 16-bit input, fused for fp32 input)': lambda: arm('gaussian', -1, -1),
+        'gaussian (the policy: S from memory for 16-bit input and for fp32 input from 2048 features on)': lambda: arm('gaussian', -1, -1),
         'gaussian, S from memory (forced)': lambda: arm('gaussian', 1, -1),
         'gaussian, fused (forced)': lambda: arm('gaussian', 0, -1),
         'gaussian, fused, fp32 partial sums (round 4\'s data path)': lambda: arm('gaussian', 0, 0),
