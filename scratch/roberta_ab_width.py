@@ -13,8 +13,17 @@ labels = torch.randint(0, 2, (128,), generator=g).to(dev)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 
 
+def build_model():
+    if not os.environ.get('LARGE'):
+        return rb.build(torch.float32, dev)
+    from transformers import RobertaConfig, RobertaForSequenceClassification      # RoBERTa-large: 1024 / 4096 wide, 24 layers
+    torch.manual_seed(0)
+    cfg = RobertaConfig(num_labels=2, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    return RobertaForSequenceClassification(cfg).to(device=dev, dtype=torch.float32).train()
+
+
 def make(kind):
-    m = rb.build(torch.float32, dev)
+    m = build_model()
     if kind:
         rb.swap_linear(m, 0.2, None, kind)
     return m, torch.optim.SGD(m.parameters(), lr=1e-4)
@@ -37,7 +46,8 @@ def steps(m, opt, n=6, warm=2):
 
 models = {k: make(k) for k in (None, 'gaussian')}
 arms = [('vanilla', None, -1), ('fused everywhere', 'gaussian', 0), ('S from memory everywhere', 'gaussian', 1),
-        ('S from memory, 3072 wide only (policy)', 'gaussian', -1), ('S from memory, 768 wide only', 'gaussian', 2)]
+        ('S from memory, 3072 wide only (policy)' if not os.environ.get('LARGE') else 'S from memory, 4096 wide only (policy)', 'gaussian', -1),
+        ('S from memory, 768 wide only' if not os.environ.get('LARGE') else 'S from memory, 1024 wide only', 'gaussian', 2)]
 if os.environ.get('ARMS'):                       # e.g. ARMS=0,2: vanilla + the arms with those tune values
     keep = {int(x) for x in os.environ['ARMS'].split(',')}
     arms = [a for a in arms if a[1] is None or a[2] in keep]
