@@ -1198,7 +1198,7 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // features wide.  Stand-alone it is 5-15 % faster on narrow fp32 layers too (16384 x 768, p = 3276: 130 against 142 us), but
 // inside an fp32 model every other kernel of the step, the fp32 GEMMs first, then ran 5-9 % longer on most boxes: the same GPU
 // cycles and L2 traffic at a lower shader clock (rocprofv3 --pmc, profiles/r05_insitu_pmc_roberta.txt), well under the package
-// power cap, mostly on the older power-management firmware of the pool (profiles/r05_box_fingerprints.txt).  RoBERTa-base fp32,
+// power cap, on some physical GPUs of the pool and not on others (the same on every lease of a unit: profiles/r05_roberta_ab_units.txt).  RoBERTa-base fp32,
 // arms interleaved in one process, seven leases (profiles/r05_roberta_ab_width.txt): every from-memory product costs the rest of
 // the step 40-70 us there (it is the operand: the same kernels on fragments of zeros cost nothing, on +-1 half --
 // profiles/r05_roberta_ab_variants.txt: the matrix pipe at its highest duty on full-entropy operands, and the clock goes down
