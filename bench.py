@@ -327,54 +327,102 @@ def measure_op_level(cfg, device, reps=200):
     return out
 
 
+def sketch_workload_text(plan, proj, rows, features, dtype_name):
+    """Where S lives for the call a fewbit_hip_sketch_describe plan belongs to: `s_fragment_bytes` == 0 <=> S is generated in the
+    registers of the product kernel and never materialised; otherwise it is written once per call into the workspace, as the
+    MFMA A fragments the product kernel reads back (tests/test_gpu_bench.py pins this equivalence)."""
+    frag = int(plan.get('s_fragment_bytes', 0))
+    where = ('generated in registers (never materialised)' if frag == 0 else
+             f'written once per call into the workspace as MFMA A fragments ({frag} B) and read back by the product kernel')
+    return f'out = S . M, S {proj} x {rows} {where}, M {rows} x {features} {dtype_name}'
+
+
+SKETCH_SETTLE_S = 0.04         # as the headline's steady figures: the same launches for >= 40 ms first (clock transient after idle)
+SKETCH_REPS = 100              # 3 x 100 timed launches per figure (tools/profile_sketch.sh: >= 200 dispatches under rocprofv3)
+
+
+def settled_us(f, reps=SKETCH_REPS, rounds=3):
+    """median over `rounds` of the average of `reps` back-to-back launches between two HIP events, after >= 40 ms of the same launches"""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < SKETCH_SETTLE_S:
+        for _ in range(10):
+            f()
+        torch.cuda.synchronize()
+    return sorted(event_time_us([f], reps, preroll=2) for _ in range(rounds))[rounds // 2]
+
+
+def measure_sampled_transform(device, rows, features, proj, dtype, dense_rademacher_us=None):
+    """The reference's O(n log n) estimators (fewbit/functional/linear.py:113-131: `dct(input_view, dim=0, norm='ortho')[proj]`
+    and `T.fft.fft(...)[proj]`) as this package runs them on the GPU (fewbit_amd.linear._sketch), beside their byte floor -- read M
+    once, write the p sampled rows -- and the dense Rademacher sketch of the same shape."""
+    from fewbit_amd import linear
+    m = torch.randn(rows, features, device=device).to(dtype)
+    gen = torch.Generator(device=device).manual_seed(3)
+    es = m.element_size()
+    floor_bytes = rows * features * es + proj * features * es
+    rec = {'workload': f"dct(M, dim=0, norm='ortho')[idx], M {rows} x {features} {str(dtype).split('.')[-1]}, {proj} sampled rows",
+           'byte_floor': {'bytes': floor_bytes, 'us_at_8TBs': round(floor_bytes / HBM_PEAK_GBS / 1e3, 2)}}
+    for kind in ('dct', 'dft'):
+        us = settled_us(lambda: linear._sketch(kind, m, proj, gen), reps=20)
+        rec[kind] = {'us': round(us, 1), 'x_byte_floor': round(us / (floor_bytes / HBM_PEAK_GBS / 1e3), 1), 'path': linear.sampled_transform_path(kind, m)}
+    if dense_rademacher_us is not None:
+        rec['dense_rademacher_us'] = dense_rademacher_us
+    return rec
+
+
 def measure_sketch(device):
-    """the random-projection product of the randomized linear layers (fewbit_hip_sketch, S generated in registers
-    -> MFMA) where the reference quotes it: proj_dim_ratio 0.2 of 16384 tokens (README "Randomized Linear (20 %)", p = 3276) at
-    both layer widths of RoBERTa-base (3072 and 768 features), bf16, both distributions, each with its roofline (class MFMA:
-    2*p*rows*features flops against the 2.5 PFLOP/s dense bf16 peak) and beside what it replaces (S drawn into HBM + torch.matmul,
-    timed in the same process).  `wins_vs_torch` makes a regression visible in the line.  p = 1638 (ratio 0.1) stays as an extra."""
+    """the random-projection product of the randomized linear layers (fewbit_hip_sketch) where the reference quotes
+    it: proj_dim_ratio 0.2 of 16384 tokens (README "Randomized Linear (20 %)", p = 3276) at both layer widths of RoBERTa-base
+    (3072 and 768 features), bf16, both distributions, each with its roofline (class MFMA: 2*p*rows*features flops against the
+    2.5 PFLOP/s dense bf16 peak) and beside what it replaces (S drawn into HBM + torch.matmul, timed in the same process).
+    `wins_vs_torch` makes a regression visible in the line.  Every figure is settled (settled_us).  p = 1638 (ratio 0.1) stays as
+    an extra.  `sampled_transform`: the reference's 'dct' / 'dft' estimators at the same shapes."""
     from fewbit_amd import cabi
     rows = 16384
-
-    def timed(f, reps=20):
-        for _ in range(5):
-            f()
-        best = []
-        for _ in range(3):
-            best.append(event_time_us([f], reps, preroll=1))
-        return sorted(best)[1]
 
     def one(features, proj, fp32_too):
         m = torch.randn(rows, features, device=device).to(torch.bfloat16)
         flops = 2.0 * proj * rows * features
-        rec = {'workload': f'out = S . M, S {proj} x {rows} (never materialised), M {rows} x {features} bf16', 'flops': flops,
-               'S_bytes_not_materialised': proj * rows * 2}
+        rec = {'flops': flops}
         ws = torch.empty(max(max(cabi.sketch_workspace_bytes(d, rows, features, proj) for d in cabi.SKETCH_DISTS), 1), dtype=torch.uint8, device=device)
         o = torch.empty(proj, features, dtype=torch.bfloat16, device=device)
         S = torch.randn(proj, rows, device=device, dtype=torch.bfloat16)
-        rec['torch'] = {'randn_plus_matmul_us': round(timed(lambda: torch.randn(proj, rows, device=device, dtype=torch.bfloat16) @ m), 1),
-                        'randint_plus_matmul_us': round(timed(lambda: (torch.randint(0, 2, (proj, rows), device=device, dtype=torch.int8).to(torch.bfloat16) * 2 - 1) @ m), 1),
-                        'matmul_alone_us': round(timed(lambda: S @ m), 1)}
+        rec['torch'] = {'randn_plus_matmul_us': round(settled_us(lambda: torch.randn(proj, rows, device=device, dtype=torch.bfloat16) @ m), 1),
+                        'randint_plus_matmul_us': round(settled_us(lambda: (torch.randint(0, 2, (proj, rows), device=device, dtype=torch.int8).to(torch.bfloat16) * 2 - 1) @ m), 1),
+                        'matmul_alone_us': round(settled_us(lambda: S @ m), 1)}
         del S
         for dist, pair in (('rademacher', 'randint_plus_matmul_us'), ('gaussian', 'randn_plus_matmul_us')):
-            us = timed(lambda: cabi.sketch(dist, m, proj, 1234, 1.0 / proj, out=o, workspace=ws))
-            rec[dist] = {'us': round(us, 1), 'torch_us': rec['torch'][pair], 'wins_vs_torch': bool(us <= rec['torch'][pair]),
-                         'plan': cabi.describe_sketch(dist, rows, features, proj),
-                         'roofline': {'bound': 'mfma', 'achieved': round(flops / us / 1e6, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(flops / us / 1e6 / 2500.0, 4)}}
-        if fp32_too:    # fp32 input (the reference's own dtype): M is rounded to bf16 once, into the workspace, then the same kernel; fp32 result
+            us = settled_us(lambda: cabi.sketch(dist, m, proj, 1234, 1.0 / proj, out=o, workspace=ws))
+            plan = cabi.describe_sketch(dist, rows, features, proj)
+            rec[dist] = {'workload': sketch_workload_text(plan, proj, rows, features, 'bf16'), 'us': round(us, 1), 'torch_us': rec['torch'][pair],
+                         'wins_vs_torch': bool(us <= rec['torch'][pair]), 'plan': plan,
+                         's_fragment_bytes': plan['s_fragment_bytes'], 'workspace_bytes': plan['workspace_bytes'],
+                         'roofline': {'bound': 'mfma', 'achieved': round(flops / us / 1e6, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(flops / us / 1e6 / 2500.0, 4),
+                                      'note': 'flops of the product only over the time of the whole call (fragment launch, product, slice reduction)'}}
+        if fp32_too:    # fp32 input (the reference's own dtype): bf16 OPERANDS -- M is rounded to bf16 (once, into the workspace), fp32 sums and result
             m32 = m.float()
             ws32 = torch.empty(max(max(cabi.sketch_workspace_bytes(d, rows, features, proj, torch.float32) for d in cabi.SKETCH_DISTS), 1), dtype=torch.uint8, device=device)
             o32 = torch.empty(proj, features, dtype=torch.float32, device=device)
-            rec['fp32_input'] = {dist: {'us': round(timed(lambda: cabi.sketch(dist, m32, proj, 1234, 1.0 / proj, out=o32, workspace=ws32)), 1),
-                                        'converted_to_bf16_first': cabi.describe_sketch(dist, rows, features, proj, torch.float32)['converted_to_bf16_first']}
-                                 for dist in ('rademacher', 'gaussian')}
+            rec['fp32_input'] = {}
+            for dist in ('rademacher', 'gaussian'):
+                plan = cabi.describe_sketch(dist, rows, features, proj, torch.float32)
+                rec['fp32_input'][dist] = {'workload': sketch_workload_text(plan, proj, rows, features, 'fp32 (bf16 operands)'),
+                                           'us': round(settled_us(lambda: cabi.sketch(dist, m32, proj, 1234, 1.0 / proj, out=o32, workspace=ws32)), 1),
+                                           'operands': 'bf16 operands: the fp32 input is rounded to bf16 on its way into the matrix pipe, S likewise; fp32 accumulation and result '
+                                                       '(the reference multiplies fp32 randn by fp32 input)',
+                                           'converted_to_bf16_first': plan['converted_to_bf16_first'], 's_fragment_bytes': plan['s_fragment_bytes']}
         return rec
 
-    out = {'note': 'proj_dim_ratio 0.2 (p = 3276 of 16384 rows) is the ratio of the reference README and tools/roberta_bench.py; 0.1 is an extra',
-           'ratio_0.2': {'16384x3072': one(3072, 3276, True), '16384x768': one(768, 3276, False)},
+    out = {'note': 'proj_dim_ratio 0.2 (p = 3276 of 16384 rows) is the ratio of the reference README and tools/roberta_bench.py; 0.1 is an extra; '
+                   f'every figure: >= {int(SKETCH_SETTLE_S * 1e3)} ms of the same launches first, then the median of 3 x {SKETCH_REPS} launches between HIP events',
+           'ratio_0.2': {'16384x3072': one(3072, 3276, True), '16384x768': one(768, 3276, True)},
            'ratio_0.1': {'16384x3072': one(3072, 1638, False)}}
     out['wins_vs_torch'] = all(out['ratio_0.2'][shape][dist]['wins_vs_torch'] for shape in out['ratio_0.2'] for dist in ('rademacher', 'gaussian'))
-    out['evidence'] = 'profiles/r05_sketch_bench.json, profiles/r05_sketch_rocprof_*.txt, DESIGN.md 3.1 / 5.1'
+    out['sampled_transform'] = {f'16384x{features}_{name}': _guarded(f'sampled_transform.{features}.{name}', lambda features=features, dt=dt: measure_sampled_transform(
+                                    device, rows, features, 3276, dt, out['ratio_0.2'][f'16384x{features}']['rademacher']['us'] if dt == torch.bfloat16 else
+                                    out['ratio_0.2'][f'16384x{features}'].get('fp32_input', {}).get('rademacher', {}).get('us')))
+                                for features in (768, 3072) for name, dt in (('bf16', torch.bfloat16), ('fp32', torch.float32))}
+    out['evidence'] = 'profiles/r06_sketch_bench.json, profiles/r06_sketch_rocprof_*_p3276_bf16.txt (tools/profile_sketch.sh), DESIGN.md section 5'
     return out
 
 

@@ -30,7 +30,7 @@ CONTINUOUS = ('celu', 'elu', 'gelu', 'hardswish', 'logsigmoid', 'mish', 'selu', 
 STEPWISE1 = ('hardshrink', 'hardsigmoid', 'hardtanh', 'leaky_relu', 'relu', 'relu6', 'softshrink', 'threshold')
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 SKETCH_DISTS = ('rademacher', 'gaussian')      # enum fewbit_sketch_dist
-ABI_VERSION = 4                                # FEWBIT_HIP_ABI_VERSION this binding was written against
+ABI_VERSION = 5                                # FEWBIT_HIP_ABI_VERSION this binding was written against
 
 # every symbol include/fewbit_hip.h declares
 SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwidth', 'fewbit_hip_state_nbytes',
@@ -40,7 +40,6 @@ SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwid
            'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune',
            'fewbit_hip_sketch_workspace', 'fewbit_hip_sketch', 'fewbit_hip_sketch_device_seed', 'fewbit_hip_sketch_next_seed',
            'fewbit_hip_sketch_mix_seed', 'fewbit_hip_sketch_matrix', 'fewbit_hip_sketch_describe',
-           'fewbit_hip_sketch_tune_slices', 'fewbit_hip_sketch_tune_waves', 'fewbit_hip_sketch_tune_halves', 'fewbit_hip_sketch_tune_convert', 'fewbit_hip_sketch_tune_partials', 'fewbit_hip_sketch_tune_materialise',
            'fewbit_hip_philox4x32', 'fewbit_hip_xoshiro128pp')
 
 
@@ -109,28 +108,16 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_sketch_matrix.argtypes = [i32, i32, u64, sz, sz, sz, sz, vp, vp]
         L.fewbit_hip_sketch_describe.restype = i32
         L.fewbit_hip_sketch_describe.argtypes = [i32, i32, sz, sz, sz, cp, sz]
-        L.fewbit_hip_sketch_tune_slices.restype = i32
-        L.fewbit_hip_sketch_tune_slices.argtypes = [ctypes.c_longlong]
-        L.fewbit_hip_sketch_tune_waves.restype = i32
-        L.fewbit_hip_sketch_tune_waves.argtypes = [ctypes.c_longlong]
-        L.fewbit_hip_sketch_tune_convert.restype = i32
-        L.fewbit_hip_sketch_tune_convert.argtypes = [ctypes.c_longlong]
-        L.fewbit_hip_sketch_tune_halves.restype = i32
-        L.fewbit_hip_sketch_tune_halves.argtypes = [ctypes.c_longlong]
-        L.fewbit_hip_sketch_tune_partials.restype = i32
-        L.fewbit_hip_sketch_tune_partials.argtypes = [ctypes.c_longlong]
-        L.fewbit_hip_sketch_tune_materialise.restype = i32
-        L.fewbit_hip_sketch_tune_materialise.argtypes = [ctypes.c_longlong]
         L.fewbit_hip_philox4x32.restype = None
         L.fewbit_hip_philox4x32.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
         L.fewbit_hip_xoshiro128pp.restype = None
         L.fewbit_hip_xoshiro128pp.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), sz]
-        # FEWBIT_SKETCH_MATERIALISE=0|1: the Gaussian sketch never / whenever possible through the S-from-memory path (the built-in
-        # policy takes it for 16-bit input, and for fp32 input on layers of 2048 features or more: on the narrower layers of an fp32
-        # model it gained 3 % of the step on some boxes of the pool and lost 5 % on the others, profiles/r05_roberta_ab_width.txt)
+        # FEWBIT_SKETCH_MATERIALISE=0|1: the Gaussian sketch never through the S-from-memory path / also on the narrow layers of an fp32
+        # model (the built-in policy takes it for 16-bit input, and for fp32 input on layers of 2048 features or more; the 1 GiB cap
+        # on the fragments and the one-tile rule hold under either setting)
         forced = os.environ.get('FEWBIT_SKETCH_MATERIALISE', '')
         if forced in ('0', '1'):
-            L.fewbit_hip_sketch_tune_materialise(int(forced))
+            L.fewbit_hip_tune(b'sketch_materialise', int(forced))
         _lib = L
     return _lib
 
@@ -461,35 +448,36 @@ def describe_sketch(dist: str, rows: int, features: int, proj: int, dtype: torch
     return _describe(lib().fewbit_hip_sketch_describe, SKETCH_DISTS.index(dist), DTYPES[dtype], rows, features, proj, device=device)
 
 
+# test and measurement seams: the random-projection keys of the one tuning hook (fewbit_hip_tune), -1 = built-in policy
 def tune_sketch_slices(slices: int) -> None:
-    """measurement hook: force the number of row slices (-1 = built-in policy)"""
-    _check(lib().fewbit_hip_sketch_tune_slices(int(slices)))
+    """force the number of row slices"""
+    tune(sketch_slices=slices)
 
 
 def tune_sketch_waves(waves: int) -> None:
-    """measurement hook: waves per workgroup, 4 (128-row tile) or 8 (256-row tile); -1 = built-in policy"""
-    _check(lib().fewbit_hip_sketch_tune_waves(int(waves)))
+    """waves per workgroup: 4 (128-row tile) or 8 (256-row tile)"""
+    tune(sketch_waves=waves)
 
 
 def tune_sketch_halves(halves: int) -> None:
-    """measurement hook: column halves per workgroup, 1 or 2 (the 128 x 512 tile); -1 = built-in policy"""
-    _check(lib().fewbit_hip_sketch_tune_halves(int(halves)))
+    """column halves per workgroup: 1 or 2 (the 128 x 512 tile)"""
+    tune(sketch_halves=halves)
 
 
 def tune_sketch_convert(convert: int) -> None:
-    """measurement hook: round fp32 input to bf16 in one pass before the product (1), never (0), built-in policy (-1)"""
-    _check(lib().fewbit_hip_sketch_tune_convert(int(convert)))
+    """round fp32 input to bf16 in one pass before the product (1), never (0)"""
+    tune(sketch_convert=convert)
 
 
 def tune_sketch_partials(bf16_partials: int) -> None:
-    """measurement hook: partial sums of sliced bf16 products in bf16 (1 / -1, the policy) or always in fp32 (0)"""
-    _check(lib().fewbit_hip_sketch_tune_partials(int(bf16_partials)))
+    """partial sums of sliced bf16 products in bf16 (1 / -1, the policy; 2: bf16 results only) or always in fp32 (0)"""
+    tune(sketch_partials=bf16_partials)
 
 
 def tune_sketch_materialise(materialise: int) -> None:
-    """measurement hook: Gaussian S written to the workspace once as MFMA fragments and read back by the product kernel (1),
-    always regenerated inside the product kernel (0), built-in policy (-1), the policy with the width rule of fp32 input inverted (2)"""
-    _check(lib().fewbit_hip_sketch_tune_materialise(int(materialise)))
+    """Gaussian S written to the workspace once as MFMA fragments and read back by the product kernel also on narrow fp32 layers (1),
+    always regenerated inside the product kernel (0)"""
+    tune(sketch_materialise=materialise)
 
 
 def xoshiro128pp(state, n: int):

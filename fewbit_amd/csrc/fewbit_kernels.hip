@@ -81,10 +81,7 @@ struct Span {
 //               block granularity for free (device-scope atomics cost ~10 ns per claim on this part), which is what a
 //               large tensor needs: CUs/XCDs do not progress at the same rate and a static split waits for the slowest.
 // `slack`: full groups that must remain after the last tile (the wide-code backward over-reads a few bytes)
-#ifndef FEWBIT_STATE_STAGE
-#define FEWBIT_STATE_STAGE 0     // experiment (round 4, profiles/r04_state_staging_ab.txt): pattern-table forward with the packed
-#endif                           // state of up to 4 CONSECUTIVE tiles of a wave staged in LDS and written as 16-byte pieces
-template <int U, int WPB = kWavesPerBlock, bool WAVE_CONTIGUOUS = false> __device__ __forceinline__ Span make_span(size_t n, int chunk, size_t slack = 0) {
+template <int U, int WPB = kWavesPerBlock> __device__ __forceinline__ Span make_span(size_t n, int chunk, size_t slack = 0) {
     Span s;
     s.lane = threadIdx.x & (kWave - 1);
     const size_t wib = static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
@@ -97,16 +94,9 @@ template <int U, int WPB = kWavesPerBlock, bool WAVE_CONTIGUOUS = false> __devic
     if (chunk > 0) {
         const size_t per_block = static_cast<size_t>(WPB) * static_cast<size_t>(chunk);
         const size_t b0 = static_cast<size_t>(blockIdx.x) * per_block;
-        if constexpr (WAVE_CONTIGUOUS) {          // wave j of the block takes the `chunk` consecutive tiles b0 + j*chunk ...
-            s.t0 = b0 + wib * static_cast<size_t>(chunk);
-            const size_t e = s.t0 + static_cast<size_t>(chunk);
-            s.t_end = e < s.ntiles ? e : s.ntiles;
-            s.stride = 1;
-        } else {
-            s.t0 = b0 + wib;
-            s.t_end = b0 + per_block < s.ntiles ? b0 + per_block : s.ntiles;
-            s.stride = WPB;
-        }
+        s.t0 = b0 + wib;
+        s.t_end = b0 + per_block < s.ntiles ? b0 + per_block : s.ntiles;
+        s.stride = WPB;
     } else {
         s.t0 = s.wave;
         s.t_end = s.ntiles;
@@ -115,17 +105,6 @@ template <int U, int WPB = kWavesPerBlock, bool WAVE_CONTIGUOUS = false> __devic
     s.tail_owner = s.wave == s.nwaves - 1;
     return s;
 }
-
-#ifdef FEWBIT_TRACE
-// debug variant: per-wave timestamps (s_memrealtime, 100 MHz) of the pipeline stages
-__device__ unsigned long long g_trace[1 << 17];
-#define FEWBIT_STAMP(slot)                                                                      \
-    do {                                                                                        \
-        if ((threadIdx.x & 63) == 0 && s.wave < (1u << 13)) g_trace[s.wave * 16 + (slot)] = wall_clock64(); \
-    } while (0)
-#else
-#define FEWBIT_STAMP(slot) do { } while (0)
-#endif
 
 // Two-buffer software pipeline over the tiles of one wave: the loads of the next tile are issued
 // before the current tile is processed, and the two register buffers alternate (no copies), so the
@@ -137,21 +116,8 @@ __device__ unsigned long long g_trace[1 << 17];
 // (in-place, as the reference op), and with noalias inputs LLVM sinks the prefetch loads below the
 // stores of process(), right in front of their use, which undoes the pipeline.
 //   init()          runs once, after the first two tiles' loads are in flight (table setup hides there)
-//   EARLY           both buffers are requested before init() (see below)
-#ifndef FEWBIT_EARLY_ALL
-#define FEWBIT_EARLY_ALL 0    // tuning hook: early head for every kernel, not only the pattern-table forward
-#endif
-#ifndef FEWBIT_SETPRIO
-#define FEWBIT_SETPRIO 0      // tuning hook: raise the wave's issue priority while it computes and stores a tile (s_setprio)
-#endif
-#if FEWBIT_SETPRIO
-#define FEWBIT_PRIO_HI() __builtin_amdgcn_s_setprio(FEWBIT_SETPRIO)
-#define FEWBIT_PRIO_LO() __builtin_amdgcn_s_setprio(0)
-#else
-#define FEWBIT_PRIO_HI() do { } while (0)
-#define FEWBIT_PRIO_LO() do { } while (0)
-#endif
-template <typename Buf, bool EARLY = (FEWBIT_EARLY_ALL != 0), typename Init, typename Load, typename Process>
+//   EARLY           both buffers are requested before init() (the pattern-table forward only, see below)
+template <typename Buf, bool EARLY = false, typename Init, typename Load, typename Process>
 __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&load, Process &&process) {
     Buf A, B;
     size_t t = s.t0;
@@ -165,7 +131,6 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
     // a neighbour's tiles, and not to a whole hot tile either (1-2 KiB of L2 -> L1 fill per wave for nothing: with one or
     // two tiles per wave that is as much fill traffic again as the real reads)
     const size_t hot = s.ntiles - 1;
-    FEWBIT_STAMP(0);
     load(t, s.lane, A);
     if constexpr (EARLY) {
     // head: BOTH buffers are requested before init() (table build / LDS staging + barrier), so that the memory system
@@ -177,20 +142,12 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
     size_t t1 = t + s.stride;
     load(t1 < s.t_end ? t1 : hot, t1 < s.t_end ? s.lane : 0, B);
     init();
-    FEWBIT_STAMP(1);
-    int slot = 2;
     for (;;) {
-        FEWBIT_PRIO_HI();
         process(t, A);
-        FEWBIT_PRIO_LO();
-        FEWBIT_STAMP(slot); ++slot;
         if (t1 >= s.t_end) break;
         const size_t t2 = t1 + s.stride;
         load(t2 < s.t_end ? t2 : hot, t2 < s.t_end ? s.lane : 0, A);
-        FEWBIT_PRIO_HI();
         process(t1, B);
-        FEWBIT_PRIO_LO();
-        FEWBIT_STAMP(slot); ++slot;
         if (t2 >= s.t_end) break;
         t = t2;
         t1 = t2 + s.stride;
@@ -198,40 +155,17 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
     }
     } else {
     init();
-    FEWBIT_STAMP(1);
-    int slot = 2;
     for (;;) {
         const size_t t1 = t + s.stride;
         load(t1 < s.t_end ? t1 : hot, t1 < s.t_end ? s.lane : 0, B);
-        FEWBIT_PRIO_HI();
         process(t, A);
-        FEWBIT_PRIO_LO();
-        FEWBIT_STAMP(slot); ++slot;
         if (t1 >= s.t_end) break;
         const size_t t2 = t1 + s.stride;
         load(t2 < s.t_end ? t2 : hot, t2 < s.t_end ? s.lane : 0, A);
-        FEWBIT_PRIO_HI();
         process(t1, B);
-        FEWBIT_PRIO_LO();
-        FEWBIT_STAMP(slot); ++slot;
         if (t2 >= s.t_end) break;
         t = t2;
     }
-    }
-}
-
-// y of the forward.  FEWBIT_INPLACE_STORE (measurement builds): what an IN PLACE call (y == x, the reference operator's own
-// contract) does with a store the out-of-place policy makes nontemporal -- 0: the same nontemporal store, 1: a plain store
-// (wave-uniform branch on the two kernel arguments), 2: plain stores always.
-#ifndef FEWBIT_INPLACE_STORE
-#define FEWBIT_INPLACE_STORE 0
-#endif
-template <int DT, bool NT> __device__ __forceinline__ void store_y(const void *x, void *y, size_t g, const float (&v)[8]) {
-    if constexpr (NT && FEWBIT_INPLACE_STORE == 1) {
-        if (x == y) GroupIO<DT>::template store<false>(y, g, v);
-        else GroupIO<DT>::template store<true>(y, g, v);
-    } else {
-        GroupIO<DT>::template store<(NT && FEWBIT_INPLACE_STORE != 2)>(y, g, v);
     }
 }
 
@@ -272,9 +206,6 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) v
     pipeline2<Buf>(
         s, [&]() { spread_borders<NB>(mine, b); },
         [&](size_t t, int ln, Buf &buf) {
-#if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 4)
-            t = s.t0;  // ablation: every iteration re-reads and re-writes the wave's first tile (cache resident)
-#endif
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if constexpr (kSplit) {
@@ -287,16 +218,10 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) v
             }
         },
         [&](size_t t, const Buf &buf) {
-#if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 4)
-            t = s.t0;
-#endif
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 float v[8];
                 GroupIO<DT>::unpack(buf.r[u], v);      // (the split layout unpacks the same way: v[0..3] | v[4..7] are its two halves)
-#if defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 2)
-                const uint32_t w = f32_bits(v[0]) & 0xffffffu;  // ablation: no bucketing
-#else
                 uint32_t w;
                 float key[8];
 #pragma unroll
@@ -307,11 +232,8 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) v
                 } else {
                     w = pack_group<K>(key, b);
                 }
-#endif
-#if !(defined(FEWBIT_ABLATE) && (FEWBIT_ABLATE & 1))
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = Act<FN, kFast>::eval(v[i], p0, p1);
-#endif
                 const size_t g = (t * U + u) * kWave + s.lane;
                 // y: nontemporal for 16-bit dtypes (not read again here; keeps the remaining input resident in L2 /
                 // Infinity Cache).  fp32 groups are stored as two 16 B pieces at a 32 B lane stride, i.e. each store
@@ -319,7 +241,7 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) v
                 // state: plain store -- it is what backward reads, and a backward that follows closely finds it
                 // cached (4096x4096 bf16 step 26.5 -> 25.6 us); when backward runs much later it makes no difference.
                 if constexpr (kSplit) SplitF32::store<true>(y, g, s.lane, v);
-                else store_y<DT, kStreamY>(x, y, g, v);
+                else GroupIO<DT>::template store<kStreamY>(y, g, v);
                 store_state_quad<K, false>(state, g, s.lane, w);
             }
         });
@@ -355,10 +277,7 @@ __global__ __launch_bounds__(kBlock, (forward_waves_per_simd<FN, DT, K, U>())) v
 // instructions -- independent of K -- and runs on the otherwise idle LDS unit, which takes the forward from
 // VALU-bound back to memory-bound.  Blocks are 1024 threads (16 waves) so that two of them (2 x 64 KiB of LDS) fill
 // a CU with 32 waves.
-#ifndef FEWBIT_LUT_BLOCK
-#define FEWBIT_LUT_BLOCK 1024   // threads per block of the pattern-table kernels (512 or 1024)
-#endif
-constexpr int kLutBlock = FEWBIT_LUT_BLOCK;
+constexpr int kLutBlock = 1024;   // threads per block of the pattern-table kernels
 constexpr int kLutWaves = kLutBlock / kWave;
 // two blocks per CU (2 x 64 KiB of LDS): 1024 threads -> 8 waves per SIMD (<= 64 VGPRs), 512 threads -> 4 (<= 128)
 template <int BLOCK> constexpr int lut_waves_per_simd() { return 2 * BLOCK / 256; }
@@ -378,13 +297,7 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
     constexpr uint32_t kInf = (DT == FEWBIT_BF16) ? 0x7f80u : 0x7c00u;
     typedef typename GroupIO<DT>::Raw Raw;
     __shared__ __attribute__((aligned(16))) uint8_t lut[65536];
-    constexpr bool kStage = (FEWBIT_STATE_STAGE != 0) && K == 3 && U == 1;
-#if FEWBIT_STATE_STAGE
-    __shared__ __attribute__((aligned(16))) uint8_t state_stage[kLutWaves * 768];
-#endif
-    // (staged variant: only in the chunked shape, where a wave's tiles are made consecutive)
-    const bool staged = kStage && chunk > 0;
-    const Span s = staged ? make_span<U, kLutWaves, true>(n, chunk) : make_span<U, kLutWaves, false>(n, chunk);
+    const Span s = make_span<U, kLutWaves>(n, chunk);
 
     // the table's global loads go out FIRST (lane j fetches border j, as a float and as a raw pattern): the build then
     // waits only for them, not for the first tile of x that pipeline2 issues right after
@@ -441,14 +354,8 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
         __syncthreads();
     };
 
-#ifndef FEWBIT_ABLATE_LUT
-#define FEWBIT_ABLATE_LUT 0     // measurement builds only: 1 no activation, 2 no table lookup, 4 no table build, 8 no state store, 16 nontemporal state store
-#endif
-    auto build_or_not = [&]() {
-        if constexpr ((FEWBIT_ABLATE_LUT & 4) == 0) build();
-    };
     pipeline2<Buf, true>(
-        s, build_or_not,
+        s, build,
         [&](size_t t, int ln, Buf &buf) {
 #pragma unroll
             for (int u = 0; u < U; ++u) buf.r[u] = GroupIO<DT>::load_raw(x, (t * U + u) * kWave + ln);
@@ -457,48 +364,19 @@ __global__ __launch_bounds__(BLOCK, (lut_waves_per_simd<BLOCK>())) void quantize
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint32_t w = 0;
-                if constexpr ((FEWBIT_ABLATE_LUT & 2) != 0) {
-                    w = buf.r[u].q[0] ^ buf.r[u].q[1] ^ buf.r[u].q[2] ^ buf.r[u].q[3];
-                } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t d = buf.r[u].q[i];
-                        w |= static_cast<uint32_t>(lut[d & 0xffffu]) << (K * 2 * i);
-                        w |= static_cast<uint32_t>(lut[d >> 16]) << (K * (2 * i + 1));
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t d = buf.r[u].q[i];
+                    w |= static_cast<uint32_t>(lut[d & 0xffffu]) << (K * 2 * i);
+                    w |= static_cast<uint32_t>(lut[d >> 16]) << (K * (2 * i + 1));
                 }
                 float v[8];
                 GroupIO<DT>::unpack(buf.r[u], v);
-                if constexpr ((FEWBIT_ABLATE_LUT & 1) == 0) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
-                }
+                for (int i = 0; i < 8; ++i) v[i] = Act<FN, true>::eval(v[i], p0, p1);
                 const size_t g = (t * U + u) * kWave + s.lane;
-                store_y<DT, true>(x, y, g, v);
-#if FEWBIT_STATE_STAGE
-                if (staged) {
-                    // this tile's 192 state bytes -> slot (t - t0) % 4 of the wave's LDS strip (the same quad regroup as
-                    // store_state_quad: lane i of a quad holds dword min(i, 2) of the quad's 12 bytes); every 4th tile, and at
-                    // the end of the wave's chunk, the strip leaves as 16-byte pieces: lane L < 12 f writes bytes [16 L, 16 L + 16)
-                    // of the f staged tiles (lanes beyond repeat the last piece: same address, same data, no divergence)
-                    uint8_t *strip = state_stage + (threadIdx.x >> 6) * 768;
-                    const int i = s.lane & 3, j = i < 2 ? i : 2;
-                    const uint32_t lo = quad_perm<FEWBIT_QUAD_PERM(0, 1, 2, 2)>(w), hi = quad_perm<FEWBIT_QUAD_PERM(1, 2, 3, 3)>(w);
-                    const uint32_t d = (lo >> (8 * j)) | (hi << (24 - 8 * j));
-                    const size_t k_in = (t - s.t0) & 3;
-                    *reinterpret_cast<uint32_t *>(strip + k_in * 192 + 12 * (s.lane >> 2) + 4 * j) = d;
-                    const bool last = t + 1 >= s.t_end;
-                    if (k_in == 3 || last) {                                    // wave-uniform
-                        const int pieces = 12 * static_cast<int>(k_in + 1);
-                        const int piece = s.lane < pieces ? s.lane : pieces - 1;
-                        const u32x4 v = *reinterpret_cast<const u32x4 *>(strip + 16 * piece);
-                        const size_t first_tile = t - k_in;
-                        store_as<false, 1>(state + first_tile * (static_cast<size_t>(K) * kWave) + 16 * piece, v);
-                    }
-                } else
-#endif
-                if constexpr ((FEWBIT_ABLATE_LUT & 8) == 0) store_state_quad<K, (FEWBIT_ABLATE_LUT & 16) != 0>(state, g, s.lane, w);
-                else if (w == 0x12345u) store_state_quad<K, false>(state, g, s.lane, w);
+                GroupIO<DT>::template store<true>(y, g, v);
+                store_state_quad<K, false>(state, g, s.lane, w);      // plain store: a backward that follows closely finds it cached
             }
         });
 
@@ -761,11 +639,7 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
                 } else {
                     buf.r[u] = GroupIO<DT>::load_raw(gy, (t * U + u) * kWave + ln);
                 }
-#ifndef FEWBIT_ABLATE_BWD
-#define FEWBIT_ABLATE_BWD 0     // measurement builds only: 1 no level gather / multiply, 2 no state load, 4 plain gx stores
-#endif
-                if constexpr ((FEWBIT_ABLATE_BWD & 2) != 0) buf.w[u] = static_cast<uint32_t>(ln) * 0x9e3779b9u;
-                else buf.w[u] = load_state_quad_raw<K>(state, (t * U + u) * kWave + ln, ln);
+                buf.w[u] = load_state_quad_raw<K>(state, (t * U + u) * kWave + ln, ln);
             }
         },
         [&](size_t t, const Buf &buf) {
@@ -774,11 +648,6 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
                 float v[8];
                 GroupIO<DT>::unpack(buf.r[u], v);
                 const uint32_t w = load_state_quad_fix<K>(buf.w[u], s.lane);
-                if constexpr ((FEWBIT_ABLATE_BWD & 1) != 0) {
-                    if (w == 0x12345u) v[0] = 0.0f;
-                    GroupIO<DT>::template store<(FEWBIT_ABLATE_BWD & 4) == 0>(gx, (t * U + u) * kWave + s.lane, v);
-                    continue;
-                }
                 if constexpr (kSplit) {      // v[0..3] / v[4..7] are halves of two different groups (SplitF32)
                     uint32_t cA, cB;
                     split_word_to_halves<K>(w, s.lane, cA, cB);
@@ -796,7 +665,7 @@ __global__ __launch_bounds__(kBlock, (stream_waves_per_simd<DT, U>())) void quan
                 // be read out of L2 / Infinity Cache and is written back during the NEXT kernel (cache-cold backward at
                 // 4096x4096 bf16 15.3 -> 13.9 us, 2^26 elements forward+backward 100.6 -> 94.1 us; RoBERTa-base step
                 // unchanged).  fp32 in the split layout (above) stores whole lines and is nontemporal too.
-                GroupIO<DT>::template store<(DT != FEWBIT_F32) && (FEWBIT_ABLATE_BWD & 4) == 0>(gx, (t * U + u) * kWave + s.lane, v);
+                GroupIO<DT>::template store<(DT != FEWBIT_F32)>(gx, (t * U + u) * kWave + s.lane, v);
             }
         });
 
@@ -974,15 +843,14 @@ enum TuneKey {
     T_LUT_CHUNK,           // the same for the pattern-table forward
     T_LUT_BLOCKS_PER_CU,   // cap on resident pattern-table blocks per CU (at most 2 fit: 64 KiB of LDS each)
     T_LUT_MIN,             // smallest tensor (elements) that takes the pattern-table forward; 0 = always
-    T_LUT_BLOCK,           // threads per pattern-table block (512 or 1024), where the build has both
-    T_U_FWD, T_U_BWD, T_U_LUT, T_U_STEP1,     // groups per lane per pipeline stage (1, 2 or 4), where the build has them
+    T_U_FWD, T_U_BWD, T_U_STEP1,     // groups per lane per pipeline stage (1 or 2), where the kernel has both
     T_COUNT
 };
 struct TuneSpec { const char *key, *env; };
 constexpr TuneSpec kTuneSpec[T_COUNT] = {
     {"waves_per_cu", "FEWBIT_HIP_WAVES_PER_CU"}, {"chunk", "FEWBIT_HIP_CHUNK"}, {"lut_chunk", "FEWBIT_HIP_LUT_CHUNK"},
-    {"lut_blocks_per_cu", "FEWBIT_HIP_LUT_BLOCKS_PER_CU"}, {"lut_min", "FEWBIT_HIP_LUT_MIN"}, {"lut_block", "FEWBIT_HIP_LUT_BLOCK"},
-    {"u_fwd", "FEWBIT_HIP_U_FWD"}, {"u_bwd", "FEWBIT_HIP_U_BWD"}, {"u_lut", "FEWBIT_HIP_U_LUT"}, {"u_step1", "FEWBIT_HIP_U_STEP1"},
+    {"lut_blocks_per_cu", "FEWBIT_HIP_LUT_BLOCKS_PER_CU"}, {"lut_min", "FEWBIT_HIP_LUT_MIN"},
+    {"u_fwd", "FEWBIT_HIP_U_FWD"}, {"u_bwd", "FEWBIT_HIP_U_BWD"}, {"u_step1", "FEWBIT_HIP_U_STEP1"},
 };
 
 // What a call launched (or would launch: fewbit_hip_describe_*): kernel instantiation and launch shape.
@@ -996,6 +864,7 @@ extern FEWBIT_HIDDEN thread_local char g_last_error[256];
 extern FEWBIT_HIDDEN std::atomic<long long> g_tune[T_COUNT];
 FEWBIT_HIDDEN int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 FEWBIT_HIDDEN void tune_init();
+FEWBIT_HIDDEN int sketch_tune(const char *key, long long value, bool *known);      // fewbit_sketch.hip
 
 #if FEWBIT_CORE_TU
 thread_local char g_last_error[256] = "";
@@ -1154,18 +1023,8 @@ Shape launch_shape(size_t ntiles, int waves_per_block, size_t resident_blocks, l
 // search / backward / 1-bit kernels (cheap per-block setup): one tile per wave from 4 tiles per resident wave up;
 // pattern-table forward (64 KiB table per block): three tiles per wave (an odd count: chunks of a power-of-two size start
 // every block on the same memory channels, T = 4 measured 5-15 % slower than T = 3) from 12 tiles per resident wave up
-#ifndef FEWBIT_AUTO_CHUNK
-#define FEWBIT_AUTO_CHUNK 1
-#endif
-#ifndef FEWBIT_AUTO_CHUNK_RATIO
-#define FEWBIT_AUTO_CHUNK_RATIO 4
-#endif
-#ifndef FEWBIT_AUTO_LUT_CHUNK
-#define FEWBIT_AUTO_LUT_CHUNK 3
-#endif
-#ifndef FEWBIT_AUTO_LUT_CHUNK_RATIO
-#define FEWBIT_AUTO_LUT_CHUNK_RATIO 12
-#endif
+constexpr int kAutoChunk = 1, kAutoLutChunk = 3;
+constexpr size_t kAutoChunkRatio = 4, kAutoLutChunkRatio = 12;
 
 // launch (or, dry, only describe) a 256-thread streaming kernel instantiation; the kernels' last parameter is the chunk
 template <auto Kern, typename... Args>
@@ -1175,8 +1034,8 @@ void launch_tiled(Plan *plan, bool dry, const Device &dev, size_t n, int U, hipS
     const long long cap = tune(T_WAVES_PER_CU);
     if (cap >= kWavesPerBlock && cap / kWavesPerBlock < per_cu) per_cu = static_cast<int>(cap / kWavesPerBlock);
     const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
-    const Shape sh = launch_shape(ntiles, kWavesPerBlock, static_cast<size_t>(dev.cus) * per_cu, tune(T_CHUNK), FEWBIT_AUTO_CHUNK,
-                                  FEWBIT_AUTO_CHUNK_RATIO);
+    const Shape sh = launch_shape(ntiles, kWavesPerBlock, static_cast<size_t>(dev.cus) * per_cu, tune(T_CHUNK), kAutoChunk,
+                                  kAutoChunkRatio);
     if (plan) {
         plan->blocks = sh.blocks;
         plan->threads = kBlock;
@@ -1196,7 +1055,7 @@ void launch_lut(Plan *plan, bool dry, const Device &dev, size_t n, int U, hipStr
     if (cap >= 1 && cap < per_cu) per_cu = static_cast<int>(cap);
     const size_t ntiles = (n / 8) / (static_cast<size_t>(U) * kWave);
     const Shape sh = launch_shape(ntiles, BLOCK / kWave, static_cast<size_t>(dev.cus) * per_cu, tune(T_LUT_CHUNK),
-                                  FEWBIT_AUTO_LUT_CHUNK, FEWBIT_AUTO_LUT_CHUNK_RATIO);
+                                  kAutoLutChunk, kAutoLutChunkRatio);
     if (plan) {
         plan->blocks = sh.blocks;
         plan->threads = BLOCK;
@@ -1217,21 +1076,12 @@ size_t lut_min_elements(int k) {
     return k == 4 ? (static_cast<size_t>(9) << 19) : (static_cast<size_t>(6) << 20);
 }
 
-// Groups per lane per pipeline stage.  Which values a build holds: the policy's own (backward, 1-bit and fp32 forward: 1 and
-// 2; 16-bit forward: 1) unless built with -DFEWBIT_SWEEP (scratch measurement build: fewer functors, 1 / 2 / 4 for every
-// kernel, both table block sizes).
+// Groups per lane per pipeline stage, the values the policy uses: backward, 1-bit and fp32 forward 1 and 2; 16-bit forward 1
+// (U = 4 never won a size class: profiles/r03_backward_shape_sweep.txt).
 template <int... Us> struct UList {};
-#ifdef FEWBIT_SWEEP
-typedef UList<1, 2, 4> FwdUs16;
-typedef UList<1, 2> FwdUs32;
-typedef UList<1, 2, 4> LutUs;
-typedef UList<1, 2, 4> StreamUs16;
-#else
 typedef UList<1> FwdUs16;
 typedef UList<1, 2> FwdUs32;
-typedef UList<1> LutUs;
-typedef UList<1, 2> StreamUs16;        // (U = 4 never won a size class: profiles/r03_backward_shape_sweep.txt)
-#endif
+typedef UList<1, 2> StreamUs16;
 typedef UList<1, 2> StreamUs32;
 
 // call f(integral_constant<U>) for the U of the list that `want` names (the list's first entry if it names none)
@@ -1260,7 +1110,6 @@ template <int U0, int... Us, typename F> void with_u(UList<U0, Us...>, long long
 constexpr size_t kLargeStream16 = static_cast<size_t>(20) << 20;
 constexpr size_t kLargeForward32 = static_cast<size_t>(32) << 20;
 template <int DT> long long policy_u_fwd(size_t n) { return DT == FEWBIT_F32 && n >= kLargeForward32 ? 2 : 1; }
-template <int DT> long long policy_u_lut(size_t) { return 1; }
 template <int DT> long long policy_u_bwd(size_t n) { return DT == FEWBIT_F32 || n >= kLargeStream16 ? 1 : 2; }
 //   1-bit family (profiles/r03_shape_sweep_step1.txt, r03_shape_sweep_step1_sizes.txt; relu): these kernels are copies with a
 //     compare, and two groups per lane is the better copy -- 16-bit forward from 6 Mi elements on (4096x4096 bf16: 11.02 ->
@@ -1300,25 +1149,14 @@ int launch_forward(Plan *plan, bool dry, const void *x, void *y, uint8_t *state,
                 name("quantize_forward_lut_wide_kernel", 1, kLutBlock);
                 return dry ? FEWBIT_OK : check_launch("quantize_forward(lut)");
             }
-            with_u(LutUs{}, tuned(T_U_LUT, policy_u_lut<DT>(n)), [&](auto tag) {
-                constexpr int U = decltype(tag)::value;
-                auto go = [&](auto btag) {
-                    constexpr int B = decltype(btag)::value;
-                    switch (k) {
-                    case 1: launch_lut<quantize_forward_lut_kernel<FN, DT, 1, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
-                    case 2: launch_lut<quantize_forward_lut_kernel<FN, DT, 2, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
-                    case 3: launch_lut<quantize_forward_lut_kernel<FN, DT, 3, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
-                    default: launch_lut<quantize_forward_lut_kernel<FN, DT, 4, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
-                    }
-                    name("quantize_forward_lut_kernel", U, B);
-                };
-#ifdef FEWBIT_SWEEP
-                if (tune(T_LUT_BLOCK) == 512) go(std::integral_constant<int, 512>{});
-                else go(std::integral_constant<int, 1024>{});
-#else
-                go(std::integral_constant<int, kLutBlock>{});
-#endif
-            });
+            constexpr int U = 1, B = kLutBlock;      // one group per lane per stage, 1024-thread blocks (the only shape that ever won)
+            switch (k) {
+            case 1: launch_lut<quantize_forward_lut_kernel<FN, DT, 1, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+            case 2: launch_lut<quantize_forward_lut_kernel<FN, DT, 2, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+            case 3: launch_lut<quantize_forward_lut_kernel<FN, DT, 3, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+            default: launch_lut<quantize_forward_lut_kernel<FN, DT, 4, U, B>, B>(plan, dry, dev, n, U, s, x, y, state, n, borders, nborders, p0, p1); break;
+            }
+            name("quantize_forward_lut_kernel", U, B);
             return dry ? FEWBIT_OK : check_launch("quantize_forward(lut)");
         }
     }
@@ -1456,11 +1294,6 @@ int launch_step1_backward(Plan *plan, bool dry, const void *gy, const uint8_t *s
     return dry ? FEWBIT_OK : check_launch("stepwise1_backward");
 }
 
-// the functors a build holds (-DFEWBIT_SWEEP: measurement build, three of them)
-#ifdef FEWBIT_SWEEP
-#define FB_CONTINUOUS_CASES FB_CASE(FEWBIT_GELU) FB_CASE(FEWBIT_SILU)
-#define FB_STEPWISE_CASES FB_CASE(FEWBIT_RELU)
-#else
 #define FB_CONTINUOUS_CASES                                                                                  \
     FB_CASE(FEWBIT_CELU) FB_CASE(FEWBIT_ELU) FB_CASE(FEWBIT_GELU) FB_CASE(FEWBIT_HARDSWISH)                 \
     FB_CASE(FEWBIT_LOGSIGMOID) FB_CASE(FEWBIT_MISH) FB_CASE(FEWBIT_SELU) FB_CASE(FEWBIT_SIGMOID)            \
@@ -1469,7 +1302,6 @@ int launch_step1_backward(Plan *plan, bool dry, const void *gy, const uint8_t *s
 #define FB_STEPWISE_CASES                                                                                    \
     FB_CASE(FEWBIT_HARDSHRINK) FB_CASE(FEWBIT_HARDSIGMOID) FB_CASE(FEWBIT_HARDTANH) FB_CASE(FEWBIT_LEAKY_RELU) \
     FB_CASE(FEWBIT_RELU) FB_CASE(FEWBIT_RELU6) FB_CASE(FEWBIT_SOFTSHRINK) FB_CASE(FEWBIT_THRESHOLD)
-#endif
 
 // ---- the four entry points with a `dry` flag (describe = the same dispatch without the launch) ----
 int do_quantize_forward(Plan *plan, bool dry, int fn, int dtype, const void *x, void *y, uint8_t *state, size_t n,
@@ -1577,12 +1409,6 @@ using namespace fewbit_hip;
 
 extern "C" {
 
-#ifdef FEWBIT_TRACE
-int fewbit_hip_debug_trace(unsigned long long *host, size_t count) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-#endif
-
 int fewbit_hip_abi_version(void) { return FEWBIT_HIP_ABI_VERSION; }
 
 const char *fewbit_hip_last_error(void) { return g_last_error; }
@@ -1648,6 +1474,9 @@ int fewbit_hip_tune(const char *key, long long value) {
             return FEWBIT_OK;
         }
     }
+    bool known = false;                    // (the random-projection unit's own keys: fewbit_sketch.hip)
+    const int rc = sketch_tune(key, value, &known);
+    if (known) return rc;
     return fail(FEWBIT_ERR_INVALID_ARGUMENT, "tune: unknown key '%s'", key);
 }
 

@@ -30,8 +30,7 @@
 //                q = j/2, w = output number 2 s + q%2 of the xoshiro128++ stream [Blackman & Vigna 2019] whose state is
 //                philox(i, 2*(r/256) + h, q/2, 2) -- per lane and 256-row block TWO streams, each seeded by one Philox call and
 //                advanced two words per MFMA step; stream t feeds operand dwords 2t, 2t+1 of every fragment (so that the two
-//                waves of the 128 x 512 tile, which share their fragments, can each run one).  (Round 4's definition -- one Philox
-//                call per fragment -- is kept as a measurement build, -DFEWBIT_GAUSSIAN_GEN=1.)
+//                waves of the 128 x 512 tile, which share their fragments, can each run one).
 //
 // ---- tiling (three shapes, `Tile<W, NH>` below; the host picks one per call, make_plan) -------------------------------------
 //   workgroup  W waves (4 or 8); wave w owns 32 rows of S x 256 features = 8 MFMA column blocks of 32 -> 8 x 16 fp32
@@ -50,8 +49,6 @@
 //   split K    gridDim.z slices of the rows (multiples of 256) when the tile grid alone cannot fill 256 CUs (proj x
 //              features is small, rows is long): slices write partial sums (fp32; bf16 when the result is bf16), a second kernel
 //              adds them IN A FIXED ORDER (deterministic: the same seed gives the same bits), scales and casts.
-// Measurement builds: -DFEWBIT_SKETCH_ABLATE=bits (stages compiled out), -DFEWBIT_SKETCH_TRACE (per-stage shader-clock stamps),
-// -DFEWBIT_SKETCH_XCD=0 / -DFEWBIT_FRAG_AHEAD=n (tile order / prefetch depth of the from-memory kernel).
 // Roofline class: MFMA (bf16 dense peak 2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md); flops = 2*proj*rows*features.
 #include <hip/hip_runtime.h>
 
@@ -59,6 +56,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "fewbit_hip.h"
@@ -94,77 +92,15 @@ template <int W, int NH = 1> struct Tile {
 };
 // internal "distribution" of the product kernel: the A fragments were written to memory beforehand (sketch_fragments_kernel)
 constexpr int kFromMemory = 2;
-// measurement builds only (scratch/run_round5_ag.sh; WRONG results): 1 = the product kernel reads whatever the workspace holds, no
-// fragment launch; 2 = the fragment launch, then the fused product kernel on the one-half plan (the fragments are not read); 3 / 4 = two
-// fragment regions, the product kernel reads the one the previous call wrote / one that is never written; 5 / 6 = 50 us of nothing
-// between fragment launch and product kernel (fresh / never-written region); 7 / 8 = the stored operand is +-1.0 / 0
-#ifndef FEWBIT_SKETCH_ABLATE_FRAGMENTS
-#define FEWBIT_SKETCH_ABLATE_FRAGMENTS 0
-#endif
-// measurement builds: non-temporal stores of the fragments / non-temporal loads of them in the product kernel / the fragment launch in
-// front of the conversion pass of an fp32 input instead of behind it
-#ifndef FEWBIT_FRAG_STORE_NT
-#define FEWBIT_FRAG_STORE_NT 0
-#endif
-#ifndef FEWBIT_FRAG_LOAD_NT
-#define FEWBIT_FRAG_LOAD_NT 0
-#endif
-#ifndef FEWBIT_FRAG_FIRST
-#define FEWBIT_FRAG_FIRST 0
-#endif
-template <typename T> __device__ __forceinline__ void frag_store(T *p, T v) {
-#if FEWBIT_FRAG_STORE_NT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-template <typename T> __device__ __forceinline__ T frag_load(const T *p) {
-#if FEWBIT_FRAG_LOAD_NT
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-#ifndef FEWBIT_FRAG_AHEAD
-#define FEWBIT_FRAG_AHEAD 4
-#endif
-constexpr int kFragAhead = FEWBIT_FRAG_AHEAD;  // MFMA steps a fragment load runs ahead of its use (registers: 4 dwords per step)
-#ifndef FEWBIT_SKETCH_XCD
-#define FEWBIT_SKETCH_XCD 1                  // workgroup -> tile order that keeps a tile's neighbours on one XCD (0: the grid's own order)
-#endif
+constexpr int kFragAhead = 4;               // MFMA steps a fragment load runs ahead of its use (registers: 4 dwords per step)
 constexpr int kPhiloxRounds = 10;
-#ifndef FEWBIT_GAUSSIAN_ROUNDS
-#define FEWBIT_GAUSSIAN_ROUNDS 10
-#endif
-constexpr int kGaussianRounds = FEWBIT_GAUSSIAN_ROUNDS;
-#ifndef FEWBIT_GAUSSIAN_GEN
-#define FEWBIT_GAUSSIAN_GEN 2       // 2: xoshiro128++ streams seeded by Philox (the definition of S); 1: one Philox call per fragment (the
-#endif                              // round-4 definition, kept as a measurement build only -- the host model no longer follows it)
-#ifndef FEWBIT_GAUSSIAN_WOVEN
-#define FEWBIT_GAUSSIAN_WOVEN 1     // the fused 256 x 256 Gaussian kernel generates the NEXT step's A fragment between this step's MFMAs (0: as
-#endif                              // one clump in front of the step's MFMAs, the form of every other fused kernel)
-#ifndef FEWBIT_SKETCH_ABLATE
-#define FEWBIT_SKETCH_ABLATE 0      // measurement builds only (results are WRONG): 1 no staging of M after the first stage, 2 no barrier in
-#endif                              // the K loop, 4 constant A operand (no generator), 8 B fragments read once (no LDS reads in the loop)
+constexpr int kGaussianRounds = 10;         // Philox rounds of the calls that seed the Gaussian streams
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-
-#ifdef FEWBIT_SKETCH_TRACE
-// measurement builds only: shader-clock stamps (s_memtime) of workgroup (0,0,0), per wave and stage: [stage top, MFMAs issued, barrier passed]
-__device__ unsigned long long g_sketch_trace[8 * 512 * 12];      // slots 0..2 as above, 3 + ks: MFMA step ks begins
-#define SKETCH_STAMP(stage_idx, slot)                                                                                         \
-    do {                                                                                                                      \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (stage_idx) < 512)                          \
-            g_sketch_trace[(static_cast<size_t>(wave) * 512 + (stage_idx)) * 12 + (slot)] = __builtin_readcyclecounter();     \
-    } while (0)
-#else
-#define SKETCH_STAMP(stage_idx, slot) do { } while (0)
-#endif
 
 // ---- Philox4x32-10 -----------------------------------------------------------------------------------------------------
 struct Key { uint32_t k0, k1; };
@@ -259,23 +195,9 @@ template <int DT> __device__ __forceinline__ uint32_t box_muller_end(float l2, f
 
 // one 32-bit word -> two normals, packed as one operand dword (even element low)
 template <int DT> __device__ __forceinline__ uint32_t gaussian_pair(uint32_t w) {
-    if constexpr ((FEWBIT_SKETCH_ABLATE & 16) != 0) {          // (measurement only: no Box-Muller, the raw bits as operands)
-        return (w & 0x007f007fu) | Operand<DT>::kOnes;
-    } else {
-        float z0, z1;
-        box_muller(w, z0, z1);
-        return Operand<DT>::pack(z0, z1);
-    }
-}
-
-// the round-4 definition (FEWBIT_GAUSSIAN_GEN == 1, measurement builds): one Philox call per fragment
-template <int DT> __device__ __forceinline__ u32x4 gaussian_fragment(uint32_t row, uint32_t octet, Key key) {
-    uint32_t w[4];
-    philox4x32<kGaussianRounds>(row, octet, 0u, 1u, key, w);
-    u32x4 a;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = gaussian_pair<DT>(w[q]);
-    return a;
+    float z0, z1;
+    box_muller(w, z0, z1);
+    return Operand<DT>::pack(z0, z1);
 }
 
 // ---- M -> registers -> LDS -----------------------------------------------------------------------------------------------
@@ -414,7 +336,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     // 768 wide 115.1 -> 109.6); the kernels that generate S themselves measured 1.5-3 % SLOWER with it (Rademacher 280.7 ->
     // 285.5 / 82.9 -> 84.4 us) and keep the grid's own order (profiles/r05_sketch_xcd_prefetch_ab.txt).
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if constexpr (FEWBIT_SKETCH_XCD != 0 && DIST == kFromMemory) {
+    if constexpr (DIST == kFromMemory) {
         const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
         const unsigned orig = bx + gx * (by + gy * bz), xcd = orig % 8, q = nwg / 8, r = nwg % 8;
         const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
@@ -473,7 +395,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     // that frees.  Every load has a whole stage to land before it is touched; one barrier per stage.
     fetch(0, mode_of(0));
     stage_to_lds(0, mode_of(0), lds);
-    fetch(1, (FEWBIT_SKETCH_ABLATE & 1) ? 2 : mode_of(1));
+    fetch(1, mode_of(1));
     __syncthreads();
 
     uint32_t signs[4] = {0u, 0u, 0u, 0u};
@@ -482,15 +404,15 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     // Gaussian: the xoshiro128++ streams of this lane's 256-row block -- stream t feeds operand dwords 2t and 2t + 1 of every
     // step, two words per step, in step order.  One column half (NH == 1): the wave runs both streams; two halves: wave (g, hf)
     // runs stream hf only and its partner the other one (each writes its 8 bytes of every fragment, publish_fragments)
-    constexpr bool kStreams = DIST == FEWBIT_SKETCH_GAUSSIAN && FEWBIT_GAUSSIAN_GEN == 2;
+    constexpr bool kStreams = DIST == FEWBIT_SKETCH_GAUSSIAN;
     uint32_t gs[NH > 1 ? 1 : 2][4];
     auto refresh_signs = [&](size_t st) __attribute__((always_inline)) {
         if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) {
             // one Philox call covers this lane's 16 MFMA steps = 256 rows = 4 or 2 stages (k_begin is a multiple of 256)
-            if ((st & (kPerBlock - 1)) == 0 && !(FEWBIT_SKETCH_ABLATE & 4))
+            if ((st & (kPerBlock - 1)) == 0)
                 philox4x32(srow, static_cast<uint32_t>(2 * ((k_begin + st * BK) >> 8) + h), 0u, 0u, key, signs);
         } else if constexpr (kStreams) {
-            if ((st & (kPerBlock - 1)) == 0 && !(FEWBIT_SKETCH_ABLATE & 4)) {
+            if ((st & (kPerBlock - 1)) == 0) {
                 const uint32_t blk = static_cast<uint32_t>(2 * ((k_begin + st * BK) >> 8) + h);
                 if constexpr (NH > 1) {
                     philox4x32<kGaussianRounds>(srow, blk, static_cast<uint32_t>(hf), 2u, key, gs[0]);
@@ -511,18 +433,17 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
         static_assert(kSteps % kAhead == 0, "the register ring is indexed by the step within a stage");
         afrag = static_cast<const uint8_t *>(frags) + (((m0 / 32 + rg) * frag_steps + (k_begin >> 4)) * 64 + lane) * 16;
 #pragma unroll
-        for (int d = 0; d < kAhead; ++d) apre[d] = frag_load(reinterpret_cast<const u32x4 *>(afrag + static_cast<size_t>(d) * 1024));
+        for (int d = 0; d < kAhead; ++d) apre[d] = *reinterpret_cast<const u32x4 *>(afrag + static_cast<size_t>(d) * 1024);
     }
     // (Gaussian streams and fragments from memory: called ONCE per step and in step order -- every call consumes the next words)
     auto make_fragment = [&](size_t st, int ks) __attribute__((always_inline)) -> u32x4 {
         if constexpr (DIST == kFromMemory) {
             const u32x4 a = apre[ks % kAhead];
-            apre[ks % kAhead] = frag_load(reinterpret_cast<const u32x4 *>(afrag + (st * kSteps + ks + kAhead) * 1024));
+            apre[ks % kAhead] = *reinterpret_cast<const u32x4 *>(afrag + (st * kSteps + ks + kAhead) * 1024);
             return a;
         }
-        else if constexpr ((FEWBIT_SKETCH_ABLATE & 4) != 0) return u32x4{srow, srow, srow, srow};
         else if constexpr (DIST == FEWBIT_SKETCH_RADEMACHER) return rademacher_fragment<DT>(signs, static_cast<int>((st & (kPerBlock - 1)) * kSteps + ks));
-        else if constexpr (kStreams && NH == 1) {
+        else {                                         // Gaussian, one column half: both streams of this lane (two halves: publish_fragments)
             u32x4 a;
             a[0] = gaussian_pair<DT>(xoshiro128pp(gs[0]));
             a[1] = gaussian_pair<DT>(xoshiro128pp(gs[0]));
@@ -530,7 +451,6 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
             a[3] = gaussian_pair<DT>(xoshiro128pp(gs[NH > 1 ? 0 : 1]));
             return a;
         }
-        else return gaussian_fragment<DT>(srow, static_cast<uint32_t>(((k_begin + st * BK) >> 3) + 2 * ks + h), key);
     };
     // NH = 2: this wave's share of the A fragments of stage `st` (steps [hf * kSteps / 2, (hf + 1) * kSteps / 2)) -> the LDS
     // exchange buffer of that stage; its partner (same rows, other column half) writes the other steps
@@ -541,7 +461,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
                 if (st >= nstages) return;             // block-uniform (the interior loop never gets here)
             }
             refresh_signs(st);
-            if constexpr (kStreams && (FEWBIT_SKETCH_ABLATE & 4) == 0) {
+            if constexpr (kStreams) {
                 // this wave's stream = dwords 2 hf, 2 hf + 1 of EVERY step of the stage (8 of the fragment's 16 bytes)
                 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #pragma unroll
@@ -572,7 +492,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     // 428.6 -> 414.2 (profiles/r05_sketch_woven_ab.txt; scratch/gen_bench.hip had said -8 % for the bare loop).  The 4-wave tile
     // measured +-0.5 % and keeps the clump, as do the Rademacher kernels (8 instructions per fragment) and the two-half tile (its
     // waves generate for each other at different steps already).
-    constexpr bool kWoven = FEWBIT_GAUSSIAN_WOVEN != 0 && kStreams && NH == 1 && W == 8 && NT == 8 && (FEWBIT_SKETCH_ABLATE & (4 | 16)) == 0;
+    constexpr bool kWoven = kStreams && NH == 1 && W == 8 && NT == 8;
     u32x4 a_next = {0u, 0u, 0u, 0u};
     if constexpr (kWoven) {
         refresh_signs(0);
@@ -583,13 +503,12 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     auto stage = [&](size_t s, auto fast_tag, auto first_tag) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_tag)::value;
         constexpr int first = decltype(first_tag)::value;      // the step whose slots carry the LDS writes (the loads follow one step later)
-        SKETCH_STAMP(s, 0);
         uint8_t *cur = lds + (s & 1) * kStageBytes, *nxt = lds + ((s + 1) & 1) * kStageBytes;
         const uint8_t *next_base = stage_base + (s + 2) * stage_bytes;
         if constexpr (FAST) {
             finish_block<DT, false>(raw, blk, 8);      // (bf16 / fp16: nothing to do; fp32: the 16 v_cvt_pk_bf16_f32)
         } else {
-            const int m1 = (FEWBIT_SKETCH_ABLATE & 1) ? 2 : mode_of(s + 1), m2 = (FEWBIT_SKETCH_ABLATE & 1) ? 2 : mode_of(s + 2);   // block-uniform
+            const int m1 = mode_of(s + 1), m2 = mode_of(s + 2);   // block-uniform
             stage_to_lds(s + 1, m1, nxt);
             fetch(s + 2, m2);
         }
@@ -611,7 +530,6 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < kSteps; ++ks) {
-            SKETCH_STAMP(s, 3 + ks);
             if constexpr (NH > 1 && FAST) {
                 if (ks == first) {
                     publish_fragments(s + 1, std::false_type{});
@@ -632,7 +550,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = Operand<DT>::mfma(a, bq[t], acc[t]);
-                if (ks + 1 < kSteps && !(FEWBIT_SKETCH_ABLATE & 8))
+                if (ks + 1 < kSteps)
                     bq[t] = *reinterpret_cast<const u32x4 *>(frag + (static_cast<size_t>(2 * (ks + 1)) * BNT + 32 * t) * 16);
                 if constexpr (FAST) {
                     if (ks == first) store_feature<BNT>(blk, nxt, so, sfc, t);
@@ -645,9 +563,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        SKETCH_STAMP(s, 1);
-        if constexpr ((FEWBIT_SKETCH_ABLATE & 2) == 0) __syncthreads();
-        SKETCH_STAMP(s, 2);
+        __syncthreads();
     };
     // two loops, not one loop with a branch: the register allocator then sees the interior body (no branches, everything
     // pinned) on its own -- with both bodies in one loop it spilt half of the accumulators
@@ -661,7 +577,7 @@ __global__ __launch_bounds__(64 * W, 2) void sketch_kernel(const void *__restric
     // 159.6 / 159.1 against 160.5 us.  The older wave finishes a stage ~1600 cycles ahead and waits at the barrier, but the
     // SIMD's issue slots are busy either way)
     size_t s = 0;
-    if constexpr (!RAGGED && !(FEWBIT_SKETCH_ABLATE & 1)) {
+    if constexpr (!RAGGED) {
         if (W == 8 && wave >= 4) {
             if constexpr (W == 8) for (; s + 2 < nfull; ++s) stage(s, std::true_type{}, StepMid{});
         } else {
@@ -841,7 +757,6 @@ template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(
         v = ((w[s >> 2] >> (((j & 1) ? 31 : 15) - (4 * (s & 3) + (j >> 1)))) & 1u) ? -1.0f : 1.0f;
     } else {
         float z0, z1;
-#if FEWBIT_GAUSSIAN_GEN == 2
         // element j of step s of block r / 256 for octet parity h: word 2 s + (q & 1) of stream q / 2, q = j / 2
         const int s = static_cast<int>((r & 255) >> 4), h = static_cast<int>((r >> 3) & 1), q = j >> 1;
         uint32_t st[4];
@@ -849,11 +764,6 @@ template <int DIST> __global__ __launch_bounds__(256) void sketch_matrix_kernel(
         uint32_t w = 0;
         for (int k = 0; k <= 2 * s + (q & 1); ++k) w = xoshiro128pp(st);
         box_muller(w, z0, z1);
-#else
-        uint32_t w[4];
-        philox4x32<kGaussianRounds>(static_cast<uint32_t>(i), static_cast<uint32_t>(r >> 3), 0u, 1u, key, w);
-        box_muller(w[j >> 1], z0, z1);
-#endif
         v = (j & 1) ? z1 : z0;
         // rounded as the product kernel rounds its operand
         if (dtype == FEWBIT_F16) v = static_cast<float>(static_cast<_Float16>(v));
@@ -915,7 +825,7 @@ __device__ __forceinline__ void fragments_of_block(Key key, size_t b4, size_t rb
         uint32_t signs[4];
         philox4x32(srow, blk, 0u, 0u, key, signs);
 #pragma unroll
-        for (int st = 0; st < 16; ++st) frag_store(dst + st * 64, rademacher_fragment<DT>(signs, st));
+        for (int st = 0; st < 16; ++st) dst[st * 64] = rademacher_fragment<DT>(signs, st);
     } else {
         uint32_t g0[4], g1[4];
         philox4x32<kGaussianRounds>(srow, blk, 0u, 2u, key, g0);
@@ -927,14 +837,7 @@ __device__ __forceinline__ void fragments_of_block(Key key, size_t b4, size_t rb
             a[1] = gaussian_pair<DT>(xoshiro128pp(g0));
             a[2] = gaussian_pair<DT>(xoshiro128pp(g1));
             a[3] = gaussian_pair<DT>(xoshiro128pp(g1));
-#if FEWBIT_SKETCH_ABLATE_FRAGMENTS == 7        // (measurement builds: the same work and traffic, but the stored operand is +-1.0 -- the sign bits only -- or 0)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = (a[e] & 0x80008000u) | 0x3f803f80u;
-#elif FEWBIT_SKETCH_ABLATE_FRAGMENTS == 8
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = a[e] == 0x12345678u ? 1u : 0u;
-#endif
-            frag_store(dst + st * 64, a);
+            dst[st * 64] = a;
         }
     }
 }
@@ -943,17 +846,6 @@ __global__ __launch_bounds__(256) void sketch_fragments_kernel(Key key, const Ke
     if (key_dev != nullptr) key = *key_dev;
     fragments_of_block<DIST, DT>(key, blockIdx.x, blockIdx.y, nblocks, out);
 }
-// (Tried and not kept, round 5: the fp32 -> bf16 pass of an fp32 input and S's fragments prepared by ONE launch whose workgroups were
-// interleaved in proportion, on the idea that one job is bound by memory and the other by VALU issue: 16384 x 768 fp32, p = 3276:
-// 132.7 against 130.1 us as two launches, 3072 wide 386.0 against 393.9, RoBERTa-base fp32 1.080x against 1.077x -- the generator's
-// 107 MB of stores and the conversion's 75 MB already share the memory system; profiles/r05_sketch_prepare_ab.txt.)
-
-// (measurement builds 5 / 6: ~50 us of nothing between the fragment launch and the product kernel -- one wave watching the 100 MHz clock)
-__global__ void sketch_pause_kernel(unsigned ticks) {
-    const uint64_t t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-
 // ---- seeds drawn on the device ----------------------------------------------------------------------------------------------
 // A launch recorded in a hipGraph replays its kernel ARGUMENTS: a seed passed by value would give every replay the same S.
 // There the seed comes from device memory instead: `next_seed_kernel` (also recorded) bumps a counter and derives the seed of
@@ -1193,21 +1085,14 @@ constexpr size_t kWorkspaceAlign = 256;
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // S in memory first?  The Gaussian sketch (a fragment costs ~100 issue slots; Rademacher's 8 are not worth a byte of traffic) when
-// at least two column tiles would otherwise regenerate it and its fragments (bf16, rows of S padded to 256, rows of M to 256) stay
-// under 1 GiB -- for a 16-bit INPUT always, for fp32 input that is rounded to bf16 first only on layers at least kWideLayer
-// features wide.  Stand-alone it is 5-15 % faster on narrow fp32 layers too (16384 x 768, p = 3276: 130 against 142 us), but
-// inside an fp32 model every other kernel of the step, the fp32 GEMMs first, then ran 5-9 % longer on most boxes: the same GPU
-// cycles and L2 traffic at a lower shader clock (rocprofv3 --pmc, profiles/r05_insitu_pmc_roberta.txt), well under the package
-// power cap, on some physical GPUs of the pool and not on others (the same on every lease of a unit: profiles/r05_roberta_ab_units.txt).  RoBERTa-base fp32,
-// arms interleaved in one process, seven leases (profiles/r05_roberta_ab_width.txt): every from-memory product costs the rest of
-// the step 40-70 us there (it is the operand: the same kernels on fragments of zeros cost nothing, on +-1 half --
-// profiles/r05_roberta_ab_variants.txt: the matrix pipe at its highest duty on full-entropy operands, and the clock goes down
-// behind it) -- more than a 768-wide product gains (S from memory on those 120 of the step's 144 products only:
-// 1.07-1.18x vanilla against 1.084-1.096x fused), less than a 3072-wide one gains (71 us; on those 24 only: 1.065-1.088x, ahead
-// of the fused kernel by 0.7-1.8 % on all seven).  bf16 models gained on every box (1.53-1.56x against 1.63-1.68x);
-// DESIGN.md 5.1.  tune: 0 never, 1 whenever possible (any fp32 input included), -1 this policy, 2 the policy with the width rule
-// of fp32 input inverted (the measurement arm "narrow layers only").
+// at least two column tiles would otherwise regenerate it (features > 256) and its fragments (bf16, rows of S padded to 256, rows
+// of M to 256) stay under 1 GiB -- for a 16-bit INPUT always, for fp32 input that is rounded to bf16 first only on layers at least
+// kWideLayer features wide: stand-alone it is 5-15 % faster on narrow fp32 layers too, but inside an fp32 model every from-memory
+// product slowed the REST of the step (full-entropy operands at the matrix pipe's highest duty pull the shader clock down) by more
+// than a 768-wide product gains and less than a 3072-wide one gains (profiles/r05_roberta_ab_width.txt; EXPERIMENTS.md).
+// tune "sketch_materialise": 0 never, -1 this policy, 1 the policy without the width rule of fp32 input (the caps stay).
 constexpr size_t kWideLayer = 2048;
+constexpr size_t kMaxFragmentBytes = 1ull << 30;
 FEWBIT_HIDDEN std::atomic<long long> g_forced_materialise{-1};
 size_t fragment_blocks(size_t rows) { return (rows + 255) / 256; }                  // 256-row blocks of M = 16 MFMA steps each
 size_t fragment_row_blocks(size_t proj) { return (proj + 255) / 256 * 8; }          // 32-row blocks of S, padded to whole 256-row tiles
@@ -1216,9 +1101,8 @@ bool materialises(int dist, int operand_dtype, bool converted, size_t rows, size
     if (dist != FEWBIT_SKETCH_GAUSSIAN || operand_dtype == FEWBIT_F32 || rows == 0) return false;
     const long long forced = g_forced_materialise.load(std::memory_order_relaxed);
     if (forced == 0 || fragment_row_blocks(proj) > 65535) return false;
-    if (forced == 1) return true;
-    const bool wide = features >= kWideLayer;
-    return (!converted || (forced == 2 ? !wide : wide)) && features > BN && fragment_bytes(rows, proj) <= (1ull << 30);
+    if (features <= BN || fragment_bytes(rows, proj) > kMaxFragmentBytes) return false;      // (also when forced: the path exists to SAVE time and memory)
+    return forced == 1 || !converted || features >= kWideLayer;
 }
 
 // the workspace of one call: [partial sums][bf16 copy of an fp32 M][A fragments of S], each part aligned to kWorkspaceAlign
@@ -1234,12 +1118,37 @@ Layout layout(int dist, int dtype, size_t rows, size_t features, size_t proj) {
                           ? static_cast<size_t>(p.gz) * proj * features * (partial16(L.operand_dtype, dtype, p.gz) ? sizeof(uint16_t) : sizeof(float)) : 0;
     size_t end = L.partial_bytes;
     if (L.converted) { L.copy_off = round_up(end, kWorkspaceAlign); L.copy_bytes = rows * features * sizeof(uint16_t); end = L.copy_off + L.copy_bytes; }
-    if (L.materialised) { L.frag_off = round_up(end, kWorkspaceAlign); L.frag_bytes = fragment_bytes(rows, proj) * (FEWBIT_SKETCH_ABLATE_FRAGMENTS >= 3 && FEWBIT_SKETCH_ABLATE_FRAGMENTS <= 6 ? 2 : 1);   /* (two regions in the measurement builds) */ end = L.frag_off + L.frag_bytes; }
+    if (L.materialised) { L.frag_off = round_up(end, kWorkspaceAlign); L.frag_bytes = fragment_bytes(rows, proj); end = L.frag_off + L.frag_bytes; }
     L.total = end;
     return L;
 }
 
 }  // namespace sketch
+}  // namespace fewbit_hip
+
+namespace fewbit_hip {
+// the keys of fewbit_hip_tune (fewbit_kernels.hip) that belong to this unit; *known = false for any other key
+FEWBIT_HIDDEN int sketch_tune(const char *key, long long value, bool *known) {
+    using namespace sketch;
+    struct Spec { const char *key; std::atomic<long long> *slot; bool (*valid)(long long); const char *what; };
+    static const Spec specs[] = {
+        {"sketch_slices", &g_forced_slices, [](long long v) { return v == -1 || v > 0; }, "the number of row slices (> 0), -1 = policy"},
+        {"sketch_waves", &g_forced_waves, [](long long v) { return v == -1 || v == 4 || v == 8; }, "waves per workgroup: 4 (128-row tile), 8 (256-row tile), -1 = policy"},
+        {"sketch_halves", &g_forced_halves, [](long long v) { return v == -1 || v == 1 || v == 2; }, "column halves per workgroup: 1, 2 (the 128 x 512 tile), -1 = policy"},
+        {"sketch_convert", &g_forced_convert, [](long long v) { return v >= -1 && v <= 1; }, "fp32 input rounded to bf16 in one pass first: 0 never, 1 always, -1 = policy"},
+        {"sketch_partials", &g_forced_partial16, [](long long v) { return v >= -1 && v <= 2; }, "bf16 partial sums: 0 never, 2 for bf16 results only, 1 / -1 = policy"},
+        {"sketch_materialise", &g_forced_materialise, [](long long v) { return v >= -1 && v <= 1; }, "Gaussian S through memory: 0 never, 1 also on narrow fp32 layers, -1 = policy"},
+    };
+    *known = false;
+    for (const Spec &sp : specs) {
+        if (strcmp(key, sp.key) != 0) continue;
+        *known = true;
+        if (!sp.valid(value)) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "tune: %s = %lld; expected %s", key, value, sp.what);
+        sp.slot->store(value, std::memory_order_relaxed);
+        return FEWBIT_OK;
+    }
+    return FEWBIT_OK;
+}
 }  // namespace fewbit_hip
 
 using namespace fewbit_hip;
@@ -1270,23 +1179,13 @@ static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t 
     if (L.total != 0 && (workspace == nullptr || workspace_bytes < L.total))
         return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: workspace of %zu bytes needed (fewbit_hip_sketch_workspace), got %zu", L.total, workspace_bytes);
     uint8_t *ws = static_cast<uint8_t *>(workspace);
-    // (measurement builds 3 / 4: two fragment regions; the product kernel reads the one this call did NOT write -- 3: the one the
-    // previous call wrote, 4: one that is never written)
-    size_t write_off = L.frag_off, read_off = L.frag_off;
-    if (FEWBIT_SKETCH_ABLATE_FRAGMENTS >= 3 && FEWBIT_SKETCH_ABLATE_FRAGMENTS <= 6 && L.materialised) {
-        static std::atomic<unsigned> calls{0};
-        const unsigned parity = FEWBIT_SKETCH_ABLATE_FRAGMENTS == 3 ? (calls.fetch_add(1) & 1u) : 0u;
-        write_off = L.frag_off + parity * (L.frag_bytes / 2);
-        read_off = FEWBIT_SKETCH_ABLATE_FRAGMENTS == 5 ? write_off : L.frag_off + (1u - parity) * (L.frag_bytes / 2);
-    }
     auto launch_fragments = [&]() {
         const size_t nblocks = fragment_blocks(rows);
         const dim3 grid(static_cast<unsigned>((nblocks + 3) / 4), static_cast<unsigned>(fragment_row_blocks(proj)));
-        u32x4 *frag = reinterpret_cast<u32x4 *>(ws + write_off);
+        u32x4 *frag = reinterpret_cast<u32x4 *>(ws + L.frag_off);
         if (L.operand_dtype == FEWBIT_F16) hipLaunchKernelGGL((sketch_fragments_kernel<FEWBIT_SKETCH_GAUSSIAN, FEWBIT_F16>), grid, dim3(256), 0, s, key.value, key.device, nblocks, frag);
         else hipLaunchKernelGGL((sketch_fragments_kernel<FEWBIT_SKETCH_GAUSSIAN, FEWBIT_BF16>), grid, dim3(256), 0, s, key.value, key.device, nblocks, frag);
     };
-    if (FEWBIT_FRAG_FIRST != 0 && L.materialised && FEWBIT_SKETCH_ABLATE_FRAGMENTS != 1) launch_fragments();
     if (L.converted) {                                // fp32 input, many row tiles: rounded to bf16 once
         uint16_t *copy = reinterpret_cast<uint16_t *>(ws + L.copy_off);
         const size_t pieces = rows * ((features + 7) / 8);
@@ -1297,12 +1196,8 @@ static int sketch_entry(int dist, int dtype, const void *m, size_t rows, size_t 
     const float fscale = static_cast<float>(scale);
     if (L.materialised) {                             // S once, as A fragments; then the product kernel that reads them
         const size_t nblocks = fragment_blocks(rows);
-        u32x4 *frag = reinterpret_cast<u32x4 *>(ws + read_off);
-        if (FEWBIT_FRAG_FIRST == 0 && FEWBIT_SKETCH_ABLATE_FRAGMENTS != 1) launch_fragments();
-        if (FEWBIT_SKETCH_ABLATE_FRAGMENTS == 5 || FEWBIT_SKETCH_ABLATE_FRAGMENTS == 6) hipLaunchKernelGGL(sketch_pause_kernel, dim3(1), dim3(64), 0, s, 5000u);
-#if FEWBIT_SKETCH_ABLATE_FRAGMENTS == 2
-        return launch_dtype<FEWBIT_SKETCH_GAUSSIAN>(L.operand_dtype, m, rows, features, ld, proj, key, fscale, out, dtype, workspace, L.partial_bytes, Frags{nullptr, 0}, s);
-#endif
+        u32x4 *frag = reinterpret_cast<u32x4 *>(ws + L.frag_off);
+        launch_fragments();       // (behind the conversion pass of an fp32 input: in front of it measured the same)
         // (the kFragAhead steps of padding behind the last fragment are read, never used: any bytes will do)
         return launch_dtype<kFromMemory>(L.operand_dtype, m, rows, features, ld, proj, key, fscale, out, dtype, workspace, L.partial_bytes, Frags{frag, nblocks * 16}, s);
     }
@@ -1374,47 +1269,6 @@ void fewbit_hip_xoshiro128pp(uint32_t state[4], uint32_t *out, size_t n) {
     uint32_t s[4] = {state[0], state[1], state[2], state[3]};
     for (size_t i = 0; i < n; ++i) out[i] = xoshiro128pp(s);
     for (int i = 0; i < 4; ++i) state[i] = s[i];
-}
-
-#ifdef FEWBIT_SKETCH_TRACE
-int fewbit_hip_sketch_debug_trace(unsigned long long *host, size_t count) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sketch_trace), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-#endif
-
-int fewbit_hip_sketch_tune_slices(long long slices) {
-    g_forced_slices.store(slices, std::memory_order_relaxed);
-    return FEWBIT_OK;
-}
-
-int fewbit_hip_sketch_tune_partials(long long bf16_partials) {
-    if (bf16_partials < -1 || bf16_partials > 2) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: bf16 partial sums are 0 (never), 2 (bf16 results only), 1 / -1 (the policy), got %lld", bf16_partials);
-    g_forced_partial16.store(bf16_partials, std::memory_order_relaxed);
-    return FEWBIT_OK;
-}
-
-int fewbit_hip_sketch_tune_materialise(long long materialise) {
-    if (materialise < -1 || materialise > 2) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: materialise is 0 (never), 1 (whenever possible), -1 (policy) or 2 (fp32 input: narrow layers instead of wide ones), got %lld", materialise);
-    g_forced_materialise.store(materialise, std::memory_order_relaxed);
-    return FEWBIT_OK;
-}
-
-int fewbit_hip_sketch_tune_convert(long long convert) {
-    if (convert < -1 || convert > 1) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: convert is 0 (never), 1 (always) or -1 (policy), got %lld", convert);
-    g_forced_convert.store(convert, std::memory_order_relaxed);
-    return FEWBIT_OK;
-}
-
-int fewbit_hip_sketch_tune_halves(long long halves) {
-    if (halves != -1 && halves != 1 && halves != 2) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: column halves per workgroup is 1 or 2 (or -1), got %lld", halves);
-    g_forced_halves.store(halves, std::memory_order_relaxed);
-    return FEWBIT_OK;
-}
-
-int fewbit_hip_sketch_tune_waves(long long waves) {
-    if (waves != -1 && waves != 4 && waves != 8) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sketch: waves per workgroup is 4 or 8 (or -1), got %lld", waves);
-    g_forced_waves.store(waves, std::memory_order_relaxed);
-    return FEWBIT_OK;
 }
 
 }  // extern "C"

@@ -153,6 +153,19 @@ def _replay_counter(device: torch.device) -> torch.Tensor:
     return counter
 
 
+_WARNED_CAPTURE_GENERATOR = False
+
+
+def _warn_device_generator_in_capture() -> None:
+    global _WARNED_CAPTURE_GENERATOR
+    if not _WARNED_CAPTURE_GENERATOR:
+        _WARNED_CAPTURE_GENERATOR = True
+        import warnings
+        warnings.warn('fewbit.linear_grp: a device generator passed while the stream is being captured into a graph only contributes its '
+                      'initial seed -- its offset is not advanced, and replays draw from (that seed, the per-device replay counter); '
+                      'eager and captured runs with the same generator therefore see different sketches', RuntimeWarning, stacklevel=4)
+
+
 def _sketch_seed(generator: Optional[torch.Generator], device: torch.device):
     """Seed of one sketch: an int drawn on the host -- or, while the stream is being captured into a hipGraph, a device word
     that a recorded kernel re-derives from (a host draw made at capture time, the replay counter) on every replay, so that a
@@ -161,13 +174,17 @@ def _sketch_seed(generator: Optional[torch.Generator], device: torch.device):
     if not torch.cuda.is_current_stream_capturing():
         return _draw_seed(generator)
     from . import cabi
-    # (while capturing, a DEVICE generator is not touched: reading or moving its offset belongs to the graph machinery of
-    # torch.cuda -- the base of the recorded seed kernel comes from the host's default generator instead; a host generator is
-    # used as given.  The counter is one word per device shared by every captured graph: graphs replayed one after the other
+    # (while capturing, a DEVICE generator's offset is not touched: reading or moving it belongs to the graph machinery of
+    # torch.cuda; a host generator is used as given.  The counter is one word per device shared by every captured graph: graphs replayed one after the other
     # see consecutive counts (reproducible), graphs replayed CONCURRENTLY on several streams still get distinct counts -- the
     # bump is an atomic add -- but which graph gets which is then up to the hardware.)
-    host_gen = generator if generator is None or generator.device.type == 'cpu' else None
-    return cabi.next_sketch_seed(counter, _draw_seed(host_gen))
+    if generator is not None and generator.device.type != 'cpu':
+        # the user's generator still determines the stream: the base of the recorded seed kernel is derived from its initial seed
+        # (a host-side read; its offset is neither read nor moved) and the per-device replay counter, so two captures with
+        # generators of different seeds draw different matrices, and the host's global RNG state is left alone
+        _warn_device_generator_in_capture()
+        return cabi.next_sketch_seed(counter, _mix64(generator.initial_seed(), 0x6361707475726564))
+    return cabi.next_sketch_seed(counter, _draw_seed(generator))
 
 
 def _native_sketch(kind: str, mat: torch.Tensor, p: int, seed, scale: float) -> torch.Tensor:
@@ -210,6 +227,11 @@ def _dense_sketch(kind: str, p: int, rows: int, like: torch.Tensor, gen: torch.G
 
 def _sampled_rows(p: int, rows: int, like: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
     return torch.randint(0, rows, (p, ), generator=gen, device=gen.device).to(like.device)
+
+
+def sampled_transform_path(kind: str, mat: torch.Tensor) -> str:
+    """Which code computes the sampled transform ``kind`` ('dct' / 'dft') of ``mat`` (what bench.py prints beside its time)."""
+    return 'torch.fft (rocFFT on the GPU): full transform along dim 0 in fp32, then the gather of the sampled rows'
 
 
 def _sketch(kind: str, mat: torch.Tensor, p: int, gen: torch.Generator, sketch_dtype=None, draw_dtype=None) -> torch.Tensor:

@@ -52,10 +52,15 @@
 extern "C" {
 #endif
 
-/* 1: the quantized-activation path.  2: + fewbit_hip_describe_*, fewbit_hip_tune (added in round 3 without a bump) and the
- * random-projection entry points fewbit_hip_sketch* (round 4).  3: + seeds in device memory (fewbit_hip_sketch_device_seed,
- * fewbit_hip_sketch_next_seed, fewbit_hip_sketch_mix_seed).  Bindings check it and refuse an older library by name. */
-#define FEWBIT_HIP_ABI_VERSION 4
+/* Version history.  Bindings check it and refuse an older library by name.
+ *   1: the quantized-activation path.
+ *   2: + fewbit_hip_describe_*, fewbit_hip_tune and the random-projection entry points fewbit_hip_sketch*.
+ *   3: + seeds in device memory (fewbit_hip_sketch_device_seed, fewbit_hip_sketch_next_seed, fewbit_hip_sketch_mix_seed).
+ *   4: + fewbit_hip_xoshiro128pp; the Gaussian S redefined on xoshiro128++ streams (the same seed gives another matrix than under 3).
+ *   5: FROZEN.  The six fewbit_hip_sketch_tune_* measurement hooks of versions 2-4 are gone from the interface: their settings are
+ *      keys of the one remaining hook, fewbit_hip_tune ("sketch_slices", ...).  Nothing else changed; what is declared below is
+ *      what a binding needs (tests/test_api.py pins the exported symbol list). */
+#define FEWBIT_HIP_ABI_VERSION 5
 
 typedef enum fewbit_status {
     FEWBIT_OK = 0,
@@ -149,10 +154,15 @@ int fewbit_hip_describe_stepwise1_forward(int fn, int dtype, size_t n, char *buf
 int fewbit_hip_describe_stepwise1_backward(int fn, int dtype, size_t n, char *buf, size_t len);
 
 /*
- * Launch-shape tuning at run time (measurement scripts; not needed for correctness -- every setting computes the same
- * bytes).  Keys: "waves_per_cu", "chunk", "lut_chunk", "lut_blocks_per_cu", "lut_min", "lut_block", "u_fwd", "u_bwd",
- * "u_lut", "u_step1"; value -1 restores the built-in policy.  The same keys are read once from the environment
- * (FEWBIT_HIP_<KEY in upper case>) at the first launch.
+ * The one tuning hook (tests and measurement scripts; never needed for correctness): value -1 restores the built-in policy.
+ *   activation kernels -- every setting computes the same bytes: "waves_per_cu", "chunk", "lut_chunk", "lut_blocks_per_cu",
+ *     "lut_min", "u_fwd", "u_bwd", "u_step1" (also read once from the environment, FEWBIT_HIP_<KEY in upper case>, at the first launch);
+ *   random-projection kernels -- every setting computes the same sums up to the fp32 association across row slices and the
+ *     rounding of bf16 partial sums: "sketch_slices" (> 0), "sketch_waves" (4 | 8), "sketch_halves" (1 | 2), "sketch_convert"
+ *     (0 | 1: fp32 input rounded to bf16 in one pass first), "sketch_partials" (0 | 1 | 2: bf16 partial sums never / policy / for
+ *     bf16 results only), "sketch_materialise" (0 | 1: Gaussian S never through memory / also on narrow fp32 layers);
+ *     fewbit_hip_sketch_workspace and fewbit_hip_sketch_describe follow the settings.
+ * Unknown keys and values outside a key's set return FEWBIT_ERR_INVALID_ARGUMENT.
  */
 int fewbit_hip_tune(const char *key, long long value);
 
@@ -166,13 +176,14 @@ int fewbit_hip_unpack_codes(const uint8_t *state, int32_t *codes, size_t n, int 
  *             fewbit/functional/linear.py:133-146 (forward) and :195-208 (backward, which re-draws the same matrix
  *             from the saved generator state)
  *   S    proj x rows, a pure function of (seed, row, column) in the operand layout of the matrix cores (definition:
- *        fewbit_amd/csrc/fewbit_sketch.hip header; host model: tests/sketch_reference.py): evaluated in registers inside the product
- *        kernel, or (Gaussian, 16-bit input wider than 256 features) written once per call into the workspace as MFMA fragments and
- *        read back -- never kept.  Forward and backward pass the same seed and get the same S.
+ *        fewbit_amd/csrc/fewbit_sketch.hip header; host model: tests/sketch_reference.py).  Rademacher: evaluated in registers inside
+ *        the product kernel, never in memory.  Gaussian, operand wider than 256 features: written ONCE PER CALL into the workspace as
+ *        MFMA fragments and read back by the product kernel (fewbit_hip_sketch_describe reports the bytes as "s_fragment_bytes";
+ *        0 = generated in registers); never kept beyond the call.  Forward and backward pass the same seed and get the same S.
  *   m    rows x features, row-major with leading dimension `ld` (elements), dtype F32 / F16 / BF16; fp32 is rounded to bf16
- *        (while it is staged, or for many row tiles in one pass beforehand) -- the products run on the bf16 matrix pipe and are
- *        accumulated in fp32; when the rows are sliced and the operands are bf16, each slice's sum crosses the workspace rounded to
- *        bf16 and the slices are added in fp32 (fewbit_hip_sketch_tune_partials)
+ *        (while it is staged, or for many row tiles in one pass beforehand) -- BF16 OPERANDS: the products run on the bf16 matrix
+ *        pipe and are accumulated in fp32 (the reference multiplies fp32 by fp32); when the rows are sliced and the operands are
+ *        bf16, each slice's sum crosses the workspace rounded to bf16 and the slices are added in fp32 (tune key "sketch_partials")
  *   out  proj x features, contiguous, the dtype of m
  *   workspace  fewbit_hip_sketch_workspace(dist, dtype, rows, features, proj) bytes of device memory (0 for small unsliced calls, a few
  *        hundred MB for a large Gaussian one); contents are scratch.  The result is deterministic: the same arguments give the same bits.
@@ -194,35 +205,12 @@ int fewbit_hip_sketch_device_seed(int dist, int dtype, const void *m, size_t row
                                   void *stream);
 int fewbit_hip_sketch_next_seed(uint64_t *counter_device, uint64_t base, uint64_t *seed_device, void *stream);
 uint64_t fewbit_hip_sketch_mix_seed(uint64_t base, uint64_t count);    /* host evaluation of the same function */
-/* S[row0 .. row0+nrows) x [col0 .. col0+ncols) itself as fp32 (rounded as the product kernel rounds its operand for
- * `dtype`) -- test seam and debugging aid; the product path never materialises S */
+/* S[row0 .. row0+nrows) x [col0 .. col0+ncols) itself as fp32, row-major (rounded as the product kernel rounds its operand for
+ * `dtype`) -- test seam and debugging aid; the product path never calls it (its own S is in registers or in fragment order) */
 int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, size_t col0, size_t nrows, size_t ncols, float *out,
                              void *stream);
 /* launch shape a fewbit_hip_sketch call would use, as JSON: {"kernel", "grid": [x, y, z], "threads", "k_slice", ...} */
 int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features, size_t proj, char *buf, size_t len);
-/* measurement hooks: force the number of row slices (> 0) / the waves per workgroup (4: 128-row tile, 8: 256-row tile) / the
- * column halves per workgroup (2: the 128 x 512 tile whose wave pairs share their A fragments through LDS, the Gaussian
- * sketch's default for wide layers in a 16-bit dtype); -1 = built-in policy.  Every setting computes the same sums (up to fp32
- * re-association across slices). */
-int fewbit_hip_sketch_tune_slices(long long slices);
-int fewbit_hip_sketch_tune_waves(long long waves);
-int fewbit_hip_sketch_tune_halves(long long halves);
-/* fp32 input with many row tiles (p > 1280) is rounded to bf16 ONCE into the workspace and multiplied by the bf16-input kernel
- * (the result stays fp32, from the fp32 sums; the numbers are the ones the in-kernel conversion gives): 0 never, 1 always,
- * -1 that policy.  fewbit_hip_sketch_workspace already counts the copy. */
-int fewbit_hip_sketch_tune_convert(long long convert);
-/* Sliced rows, bf16 operands (a bf16 input, or an fp32 input that was rounded to bf16 first): the slices' partial sums make their
- * round trip through the workspace in bf16 instead of fp32 (half the bytes; each slice's sum is rounded once, the slices are added
- * in fp32 in a fixed order; the result is bf16 or fp32 as before): 0 never, 2 for bf16 results only, 1 or -1 the policy (both).
- * fewbit_hip_sketch_workspace follows the setting. */
-int fewbit_hip_sketch_tune_partials(long long bf16_partials);
-/* Gaussian sketch of a layer wider than one 256-feature tile: S is generated ONCE, by a VALU-only kernel, into the workspace as the
- * bf16 / fp16 A fragments of the matrix pipe, and the product kernel reads them back (instead of every column tile regenerating
- * its rows of S beside its MFMAs): 0 never (always the fused kernel), 1 whenever possible, -1 the policy (features > 256 and the
- * fragments <= 1 GiB; fp32 input that is rounded to bf16 first only on layers of 2048 features or more: inside fp32 models every
- * fragment launch slowed the rest of the step by more than a narrower product gains, on most boxes), 2 that policy with the width
- * rule of fp32 input inverted (a measurement arm).  The same S either way.  fewbit_hip_sketch_workspace follows the setting. */
-int fewbit_hip_sketch_tune_materialise(long long materialise);
 /* Philox4x32-10 on the HOST (the generator behind S; known-answer tests run it without a GPU) */
 void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 /* xoshiro128++ 1.0 on the HOST (Blackman & Vigna; the stream generator of the Gaussian sketch, seeded by a Philox call per

@@ -33,12 +33,58 @@ def test_native_libraries_load_and_export_the_abi():
     # pure host helpers of the ABI may be called without a GPU
     L = cabi.lib()
     header_version = int(re.search(r"#define FEWBIT_HIP_ABI_VERSION (\d+)", header).group(1))
-    assert L.fewbit_hip_abi_version() == header_version == cabi.ABI_VERSION == 4
+    assert L.fewbit_hip_abi_version() == header_version == cabi.ABI_VERSION == 5
     assert [L.fewbit_hip_bitwidth(v) for v in (2, 3, 4, 5, 8, 9, 16, 256)] == [1, 2, 2, 3, 3, 4, 4, 8]
     assert L.fewbit_hip_state_nbytes(16777216, 3) == 6291456 and L.fewbit_hip_state_nbytes(9, 3) == 6
     assert fewbit_amd.native_loaded(), fewbit_amd.native_error()
     for name in fewbit.functional.STEPWISE + fewbit.functional.CONTINOUS + ('quantize', 'quantize_backward'):
         assert hasattr(torch.ops.fewbit, name), name
+
+
+# the frozen C-ABI (FEWBIT_HIP_ABI_VERSION 5): what `nm -D` must list for libfewbit_hip.so -- exactly this, nothing else
+FROZEN_ABI = '''
+fewbit_hip_abi_version fewbit_hip_last_error fewbit_hip_bitwidth fewbit_hip_state_nbytes
+fewbit_hip_quantize_forward fewbit_hip_quantize_backward fewbit_hip_stepwise1_forward fewbit_hip_stepwise1_backward
+fewbit_hip_pack_codes fewbit_hip_unpack_codes
+fewbit_hip_describe_quantize_forward fewbit_hip_describe_quantize_backward fewbit_hip_describe_stepwise1_forward
+fewbit_hip_describe_stepwise1_backward fewbit_hip_tune
+fewbit_hip_sketch_workspace fewbit_hip_sketch fewbit_hip_sketch_device_seed fewbit_hip_sketch_next_seed fewbit_hip_sketch_mix_seed
+fewbit_hip_sketch_matrix fewbit_hip_sketch_describe fewbit_hip_philox4x32 fewbit_hip_xoshiro128pp
+'''.split()
+
+
+def test_exported_symbol_list_is_the_frozen_abi():
+    """`nm -D --defined-only libfewbit_hip.so` lists the frozen interface and nothing else: no measurement hook, no kernel stub, no
+    template instantiation (fewbit_amd/csrc/fewbit_hip.map).  A new entry point means a new FEWBIT_HIP_ABI_VERSION and a new list here."""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', str(cabi.LIB_PATH)], check=True, capture_output=True, text=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == sorted(FROZEN_ABI), sorted(set(exported) ^ set(FROZEN_ABI))
+    assert sorted(cabi.SYMBOLS) == sorted(FROZEN_ABI)
+    header = (ROOT / 'include' / 'fewbit_hip.h').read_text()
+    assert 'sketch_tune_' not in header.split('#define FEWBIT_HIP_ABI_VERSION')[1]      # (the version history may name them)
+
+
+def test_tune_is_the_single_hook_and_validates_its_keys():
+    """host-only: the six random-projection settings are keys of fewbit_hip_tune; unknown keys and bad values are refused by name"""
+    for key in ('sketch_slices', 'sketch_waves', 'sketch_halves', 'sketch_convert', 'sketch_partials', 'sketch_materialise'):
+        cabi.tune(**{key: -1})
+    for key, bad in (('sketch_waves', 5), ('sketch_halves', 3), ('sketch_slices', 0), ('sketch_convert', 2), ('sketch_partials', 3),
+                     ('sketch_materialise', 2), ('no_such_key', 1), ('u_lut', 1), ('lut_block', 512)):
+        with pytest.raises(cabi.FewbitHipError, match=key):
+            cabi.tune(**{key: bad})
+    # "whenever possible" keeps the caps: a 4 GiB S is not written to memory even when asked for (rows 2^21, proj 2^10 would need ~4 GiB)
+    try:
+        ws = cabi.lib().fewbit_hip_sketch_workspace
+        shapes = ((1 << 21, 1024, 1 << 10), (16384, 256, 3276))      # a ~4 GiB S; one column tile (nothing to share: stays fused)
+        cabi.tune(sketch_materialise=1)
+        asked = [ws(1, 2, *shape) for shape in shapes] + [ws(1, 2, 16384, 3072, 3276)]
+        cabi.tune(sketch_materialise=0)
+        never = [ws(1, 2, *shape) for shape in shapes] + [ws(1, 2, 16384, 3072, 3276)]
+        assert asked[:2] == never[:2] and asked[0] < (1 << 30)
+        assert asked[2] - never[2] >= 3276 * 16384 * 2                # (where the path applies the fragments are in the workspace)
+    finally:
+        cabi.tune(sketch_materialise=-1)
 
 
 def test_operator_schemas_match_reference():

@@ -34,14 +34,14 @@ def offset_copy(t, off_elems, extra=16):
     return view
 
 
-TUNE_KEYS = ('waves_per_cu', 'chunk', 'lut_chunk', 'u_fwd', 'u_bwd', 'u_lut', 'u_step1')
+TUNE_KEYS = ('waves_per_cu', 'chunk', 'lut_chunk', 'u_fwd', 'u_bwd', 'u_step1')
 
 
 def random_launch_shape(rng):
     """groups per lane per stage, resident blocks per CU and resident / chunked shape picked per case (fewbit_hip_tune):
     every kernel instantiation the size policy can choose is reached at the small sizes of this file too"""
     u = int(rng.choice([-1, 1, 2]))
-    cabi.tune(u_fwd=u, u_bwd=int(rng.choice([-1, 1, 2])), u_lut=u, u_step1=int(rng.choice([-1, 1, 2])),
+    cabi.tune(u_fwd=u, u_bwd=int(rng.choice([-1, 1, 2])), u_step1=int(rng.choice([-1, 1, 2])),
               waves_per_cu=int(rng.choice([-1, 8, 16, 32])), chunk=int(rng.choice([-1, 0, 1, 3])), lut_chunk=int(rng.choice([-1, 0, 2])))
 
 

@@ -649,51 +649,81 @@ def test_c_abi_validation_mode():
     assert r.returncode == 0 and 'validated' in r.stdout, r.stdout + r.stderr
 
 
-def test_concurrent_streams_and_threads():
-    """The library keeps no per-call global state: launches from several host threads on several streams at once (first
-    use of the per-device launch-geometry caches included, when this test runs alone) give the same bytes as serial
-    launches."""
+def test_concurrent_streams_and_threads_one_process_many_devices():
+    """SURVEY 8(e), first form: ONE process driving every device of the box with per-device streams.  Host thread i works on
+    device i % device_count() (all of them on the one device of a 1-GPU box) on its own stream: the activation path (per-device
+    launch-geometry and occupancy caches, first use included when this test runs alone) and a random-projection product whose
+    kernel needs the per-device opt-in to more than 64 KiB of LDS.  The library keeps no per-call global state, so every thread
+    must get the bytes of the serial run on the first device, whichever device it ran on."""
     import threading
     from fewbit_amd import cabi
     from fewbit_amd.store import store
+    ndev = torch.cuda.device_count()
+    devices = [torch.device('cuda', i % ndev) for i in range(4)]
+    first = devices[0]
     sizes = (8 * 1024 * 1024 + 13, 1_000_003, 4096, 6 * 1024 * 1024 + 512)
-    work = []
+    host = []
     for i, n in enumerate(sizes):
         dtype = (torch.bfloat16, torch.float32, torch.float16, torch.bfloat16)[i]
         g = torch.Generator().manual_seed(100 + i)
-        x = (torch.randn(n, generator=g) * 1.5).to(dtype).to(DEV)
-        gy = torch.randn(n, generator=g).to(dtype).to(DEV)
-        b, l = store.get('gelu', 3, DEV, dtype)
-        work.append((x, gy, b[1:-1].contiguous(), l))
+        host.append(((torch.randn(n, generator=g) * 1.5).to(dtype), torch.randn(n, generator=g).to(dtype), dtype))
+    m_host = torch.randn(2048, 1024, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16)
+
+    def tables(dtype, dev):
+        b, l = store.get('gelu', 3, dev, dtype)
+        return b[1:-1].contiguous(), l
+
+    def sketch_on(dev, stream=None):
+        # Gaussian, 1024 features, S generated in the product kernel: the 128 x 512 tile, 160 KiB of LDS (hipFuncSetAttribute per device)
+        plan = cabi.describe_sketch('gaussian', 2048, 1024, 300, torch.bfloat16, device=dev)
+        assert plan['lds_bytes'] > 65536 and plan['s_fragment_bytes'] == 0, plan
+        return cabi.sketch('gaussian', m_host.to(dev), 300, 77, 1.0 / 300, stream=stream)
+
     serial = []
-    for x, gy, b, l in work:
-        y, st = cabi.quantize_forward('gelu', x, b)
-        serial.append((y, st, cabi.quantize_backward(gy, st, l)))
-    torch.cuda.synchronize()
-    out, errors = [None] * len(work), []
+    cabi.tune(sketch_materialise=0)
+    try:
+        for x, gy, dtype in host:
+            b, l = tables(dtype, first)
+            y, st = cabi.quantize_forward('gelu', x.to(first), b)
+            serial.append((y.cpu(), st.cpu(), cabi.quantize_backward(gy.to(first), st, l).cpu()))
+        serial_sketch = sketch_on(first).cpu()
+        torch.cuda.synchronize(first)
+        out, errors, ran_on = [None] * len(host), [], [None] * len(host)
 
-    def run(i):
-        try:
-            s = torch.cuda.Stream(device=DEV)
-            x, gy, b, l = work[i]
-            with torch.cuda.stream(s):
-                for _ in range(20):
-                    y, st = cabi.quantize_forward('gelu', x, b, stream=s.cuda_stream)
-                    gx = cabi.quantize_backward(gy, st, l, stream=s.cuda_stream)
-            s.synchronize()
-            out[i] = (y, st, gx)
-        except Exception as e:  # noqa: BLE001
-            errors.append(e)
+        def run(i):
+            try:
+                dev = devices[i]
+                s = torch.cuda.Stream(device=dev)
+                x, gy, dtype = host[i]
+                x, gy = x.to(dev), gy.to(dev)
+                b, l = tables(dtype, dev)
+                with torch.cuda.stream(s):
+                    for _ in range(20):
+                        y, st = cabi.quantize_forward('gelu', x, b, stream=s.cuda_stream)
+                        gx = cabi.quantize_backward(gy, st, l, stream=s.cuda_stream)
+                    p = sketch_on(dev, stream=s.cuda_stream)
+                s.synchronize()
+                assert y.device == dev and p.device == dev
+                # the plan the library reports for THIS device is the one it used there (geometry cached per device index)
+                assert cabi.describe_forward('gelu', dtype, x.numel(), 7, device=dev)['blocks'] > 0
+                ran_on[i] = dev.index
+                out[i] = (y.cpu(), st.cpu(), gx.cpu(), p.cpu())
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
 
-    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(work))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(host))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        cabi.tune(sketch_materialise=-1)
     assert not errors, errors
-    for (y0, s0, g0), (y1, s1, g1) in zip(serial, out):
+    assert ran_on == [d.index for d in devices] and (ndev == 1 or any(ran_on)), ran_on      # a non-zero device index whenever one exists
+    for (y0, s0, g0), (y1, s1, g1, p1) in zip(serial, out):
         assert torch.equal(s0, s1)
         assert torch.equal(y0.view(torch.uint8), y1.view(torch.uint8)) and torch.equal(g0.view(torch.uint8), g1.view(torch.uint8))
+        assert torch.equal(serial_sketch.view(torch.uint8), p1.view(torch.uint8))
 
 
 def test_autocast_and_activation_checkpointing():

@@ -120,7 +120,9 @@ def test_fp32_forward_in_raw_ulps_against_the_reference_run(qref):
     except OSError:
         pass
     print(doc)
-    assert int(d.max()) <= 6 and float((d <= 1).float().mean()) >= 0.97, doc
+    # vs the reference run: 3 ULP at most and >= 97 % within 1 ULP -- the measured values (profiles/r04_fp32_ulp.json), explained by ATen's own
+    # distance from the correctly rounded result (up to 3 ULP, `context` above); a regression to 4 ULP fails here
+    assert int(d.max()) <= 3 and float((d <= 1).float().mean()) >= 0.97, doc
     assert int(de.max()) <= 2 and float((de <= 1).float().mean()) >= 0.99, doc
     assert neg_ok == neg_n, doc
 
@@ -284,7 +286,7 @@ def test_custom_tables_any_size(nlevels):
             inner = torch.linspace(-3, 3, nlevels - 1).to(dtype)
         levels = torch.randn(nlevels, generator=g).to(dtype)
         x, gy = make_x(5003, dtype, inner, nlevels)
-        y_o, s_o, k = oracle.quantize('identity' if False else 'tanh', x, inner)
+        y_o, s_o, k = oracle.quantize('tanh', x, inner)
         _, st = cabi.quantize_forward('tanh', x.to(DEV), inner.to(DEV))
         assert st.numel() == k * ((5003 + 7) // 8)
         assert_bit_equal(st.cpu(), s_o, f'custom {nlevels} state')
@@ -677,10 +679,9 @@ def test_every_launch_shape_and_tile_width_gives_the_same_bytes():
     1-bit family.  Tile widths: the SHIPPED library holds U = 1, 2 for the backward, the 1-bit kernels and the fp32 search
     forward, and U = 1 only for the 16-bit search forward and the pattern-table forward (UList<> in fewbit_kernels.hip; a
     requested U the build does not hold runs the list's first entry, U = 1) -- what each call really used is read back from
-    fewbit_hip_describe_* and asserted, so this test cannot claim coverage of a width that never ran (U = 4 and the
-    table kernel's U = 2 exist only in the -DFEWBIT_SWEEP measurement build, swept by scratch/shape_sweep.py)."""
+    fewbit_hip_describe_* and asserted, so this test cannot claim coverage of a width that never ran."""
     import json
-    keys = ('waves_per_cu', 'chunk', 'lut_chunk', 'lut_blocks_per_cu', 'lut_min', 'u_fwd', 'u_bwd', 'u_lut', 'u_step1')
+    keys = ('waves_per_cu', 'chunk', 'lut_chunk', 'lut_blocks_per_cu', 'lut_min', 'u_fwd', 'u_bwd', 'u_step1')
     try:
         for dt, n in (('bf16', 64 * 8 * 4 * 37 + 13), ('f32', 64 * 8 * 4 * 19 + 5), ('bf16', 7 * 1024 * 1024 + 3)):
             dtype = DTYPES[dt]
@@ -699,7 +700,7 @@ def test_every_launch_shape_and_tile_width_gives_the_same_bytes():
             for u in (1, 2, 4):
                 for wpc, chunk in ((-1, -1), (8, 0), (16, 1), (32, 3)):
                     for lut_min in (0, 1 << 60):
-                        cabi.tune(u_fwd=u, u_bwd=u, u_lut=u, u_step1=u, waves_per_cu=wpc, chunk=chunk, lut_chunk=chunk, lut_min=lut_min)
+                        cabi.tune(u_fwd=u, u_bwd=u, u_step1=u, waves_per_cu=wpc, chunk=chunk, lut_chunk=chunk, lut_min=lut_min)
                         db = cabi.describe_backward(dtype, n, 8)
                         df = cabi.describe_forward('gelu', dtype, n, 7)
                         seen.add(json.dumps(db, sort_keys=True))

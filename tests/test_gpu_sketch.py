@@ -570,3 +570,42 @@ def test_every_replay_of_a_captured_layer_step_draws_a_fresh_sketch(kind, monkey
     gw2, = torch.autograd.grad((lin(x) * wgt).sum(), lin.weight)
     want = cabi.sketch(kind, wgt, 96, base).T @ cabi.sketch(kind, x.detach(), 96, base, 1.0 / 96)
     assert torch.allclose(gw2, want, rtol=1e-4, atol=1e-3) and int(counter) == c0 + 3
+
+
+def test_a_device_generator_still_determines_a_captured_sketch():
+    """While the stream is capturing, a user-supplied DEVICE generator is not advanced (its offset belongs to torch's graph machinery), but it is
+    not ignored either: the recorded seed kernel's base is derived from its initial seed, so the replayed product is the eager product with
+    mix(base(initial_seed), counter), generators of different seeds give different matrices, the host's global RNG is untouched -- and the
+    caller is told once (RuntimeWarning)."""
+    import warnings
+    import fewbit
+    from fewbit_amd import linear
+    x = torch.randn(512, 64, device=DEV, requires_grad=True)
+    wgt = torch.randn(512, 32, device=DEV)
+    results = {}
+    linear._WARNED_CAPTURE_GENERATOR = False
+    for seed in (11, 12):
+        gen = torch.Generator(device=DEV).manual_seed(seed)
+        lin = fewbit.RandomizedLinear(64, 32, proj_dim=96, matmul='rademacher', bias=False, device=DEV, generator=gen)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            torch.autograd.grad((lin(x) * wgt).sum(), lin.weight)
+        torch.cuda.current_stream().wait_stream(side)
+        counter = linear._replay_counter(torch.device(DEV))
+        c0, offset, host_state = int(counter), gen.get_offset(), torch.random.get_rng_state()
+        g = torch.cuda.CUDAGraph()
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            with torch.cuda.graph(g):
+                gw, = torch.autograd.grad((lin(x) * wgt).sum(), lin.weight)
+        if seed == 11:
+            assert any(issubclass(w.category, RuntimeWarning) and 'device generator' in str(w.message) for w in caught)
+        assert gen.get_offset() == offset and torch.equal(torch.random.get_rng_state(), host_state)
+        g.replay()
+        torch.cuda.synchronize()
+        s = cabi.mix_sketch_seed(linear._mix64(seed, 0x6361707475726564), c0)
+        want = cabi.sketch('rademacher', wgt, 96, s).T @ cabi.sketch('rademacher', x.detach(), 96, s, 1.0 / 96)
+        assert torch.allclose(gw, want, rtol=1e-4, atol=1e-3), float((gw - want).abs().max())
+        results[seed] = gw.clone()
+    assert not torch.equal(results[11], results[12])

@@ -12,7 +12,7 @@
 #      micro-benchmark, host cost per call, clock-transient timeline, the fp32 ULP histogram written by the GPU test-suite
 #   6. RoBERTa-base step (both routes) and the rocprofv3 kernel stats of the few-bit kernels inside it
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
 export TMPDIR=/tmp
@@ -68,15 +68,14 @@ fi
 python3 scratch/hostcost.py > "$RAW/hostcost.log" 2>&1 && cp gpurun_out/hostcost.json "$OUT/${R}_hostcost.json"
 # 7. the random-projection kernel: TFLOP/s per shape against torch.randn/randint + torch.matmul, the README
 #    table of RoBERTa-base with the native and the torch sketches, rocprofv3 kernel stats + PMC of one shape
-python3 scratch/sketch_bench.py > "$RAW/sketch_bench.log" 2>&1 && cp gpurun_out/sketch_bench.json "$OUT/${R}_sketch_bench.json"
-for v in "fp32 gaussian" "fp32 gaussian --torch-sketch" "fp32 gaussian --torch-sketch --sketch-bf16" "fp32 rademacher" "bf16 gaussian" "bf16 gaussian --torch-sketch" "bf16 rademacher"; do
+python3 tools/sketch_bench.py > "$RAW/sketch_bench.log" 2>&1 && cp gpurun_out/sketch_bench.json "$OUT/${R}_sketch_bench.json"
+for v in "fp32 gaussian" "fp32 gaussian --torch-sketch" "fp32 gaussian --torch-sketch --sketch-bf16" "fp32 rademacher" "bf16 gaussian" "bf16 gaussian --torch-sketch" "bf16 rademacher" "fp32 dct" "bf16 dct" "fp32 dft" "bf16 dft"; do
     set -- $v; dt=$1; mm=$2; shift 2; tag=$(echo "$dt $mm $@" | tr " " "_" | tr -d "-" | sed 's/_$//')
     timeout 600 python3 tools/roberta_bench.py --table --dtype $dt --matmul $mm --steps 6 "$@" 2>> "$RAW/roberta.err" | tail -1 > "$OUT/${R}_roberta_table_$tag.json"
 done
-# the ratio the reference quotes (0.2: p = 3276 of 16384 rows), both layer widths of RoBERTa-base, both sketches
-for spec in "rademacher 3072" "gaussian 3072" "rademacher 768" "gaussian 768"; do set -- $spec
-    bash tools/profile_sketch.sh ${R}_$1_$2 $1 16384 $2 3276 bf16 10 2>&1 | cut -c1-1500 > "$OUT/${R}_sketch_rocprof_$1_16384x$2_p3276_bf16.txt"
-done
+# the ratio the reference quotes (0.2: p = 3276 of 16384 rows), both layer widths of RoBERTa-base, both sketches: >= 200 settled
+# dispatches each (writes gpurun_out/profiles_$R/${R}_sketch_rocprof_*_p3276_bf16.txt itself)
+bash tools/profile_sketch.sh $R > "$RAW/profile_sketch.log" 2>&1
 # the randomized RoBERTa step with the arms interleaved in ONE process (S from memory / fused / fp32 partial sums / Rademacher),
 # where its GPU time goes by kernel class, and the counters behind the in-situ forward
 for dt in fp32 bf16; do timeout 900 python3 scratch/roberta_ab.py $dt 3 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_roberta_ab_$dt.txt"; done

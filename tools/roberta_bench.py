@@ -129,7 +129,8 @@ def main():
     ap.add_argument('--row', type=int, default=None, choices=(0, 1, 2, 3), help='with --table: run only this row (profiling)')
     ap.add_argument('--linear-ratio', type=float, default=0.2, help='proj_dim_ratio of the randomized linear layers')
     ap.add_argument('--sketch-bf16', action='store_true', help='run the sketch GEMMs of fp32 layers in bf16')
-    ap.add_argument('--matmul', default='gaussian', choices=('gaussian', 'rademacher'), help='kind of dense sketch of the randomized layers')
+    ap.add_argument('--matmul', default='gaussian', choices=('gaussian', 'rademacher', 'dct', 'dft'),
+                    help="kind of sketch of the randomized layers: the dense ones, or the reference's sampled transforms (fewbit/functional/linear.py:113-131)")
     ap.add_argument('--torch-sketch', action='store_true',
                     help='draw S with torch.randn / randint and multiply with torch.matmul (what round 3 measured) instead of the '
                          'gfx950 sketch kernels (fewbit_amd/csrc/fewbit_sketch.hip)')
@@ -140,8 +141,8 @@ def main():
     ids = torch.randint(5, 50000, (args.batch, args.seq), generator=g).to(dev)
     labels = torch.randint(0, 2, (args.batch,), generator=g).to(dev)
 
+    import fewbit_amd.linear
     if args.torch_sketch:
-        import fewbit_amd.linear
         fewbit_amd.linear.use_native_sketch(False)
     if args.table:
         rows = []
@@ -162,7 +163,8 @@ def main():
             r['step_time_ratio'] = round(r['ms_per_step'] / rows[0]['ms_per_step'], 3)
         print(json.dumps({'config': f'RoBERTa-base (random init) batch {args.batch} x seq {args.seq}, {args.dtype}, '
                                     f'fwd+bwd+SGD step; randomized linear proj_dim_ratio={args.linear_ratio}'
-                                    + f', {args.matmul} sketch, ' + ('torch.randn/randint + torch.matmul' if args.torch_sketch else 'gfx950 sketch kernels (fewbit_hip_sketch)')
+                                    + f', {args.matmul} sketch, ' + (fewbit_amd.linear.sampled_transform_path(args.matmul, torch.empty(0, device=dev, dtype=dtype)) if args.matmul in ('dct', 'dft') else
+                                                                     'torch.randn/randint + torch.matmul' if args.torch_sketch else 'gfx950 sketch kernels (fewbit_hip_sketch)')
                                     + (', sketch GEMMs in bf16' if args.sketch_bf16 else ''),
                           'rows': rows}))
         return

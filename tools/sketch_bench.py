@@ -6,7 +6,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/ -> repository root
 sys.path.insert(0, ROOT)
 import torch
 from fewbit_amd import cabi
@@ -15,14 +15,25 @@ DEV = 'cuda'
 PEAK = 2500.0
 
 
-def timed(f, reps=20, warm=5, rounds=3):
-    """median over `rounds` of the average of `reps` back-to-back calls (HIP events on the launch stream), in us"""
+SETTLE_S = 0.04
+
+
+def timed(f, reps=100, warm=5, rounds=3, settle_s=SETTLE_S):
+    """median over `rounds` of the average of `reps` back-to-back calls (HIP events on the launch stream), in us, after the GPU
+    has been busy with the same call for `settle_s` (an idle GPU boosts, then dips for ~10 ms, then settles) -- the way bench.py
+    and tools/profile_sketch.sh settle, so that the three agree"""
     for _ in range(warm):
         f()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < settle_s:
+        for _ in range(10):
+            f()
+        torch.cuda.synchronize()
     out = []
     for _ in range(rounds):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f()
         e0.record()
         for _ in range(reps):
             f()
@@ -30,6 +41,20 @@ def timed(f, reps=20, warm=5, rounds=3):
         torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) * 1e3 / reps)
     return sorted(out)[len(out) // 2]
+
+
+def sampled_transforms(m, proj):
+    """the reference's O(n log n) estimators at this shape (fewbit/functional/linear.py:113-131): time of dct(M, dim=0)[idx] and
+    fft(M, dim=0)[idx] as fewbit_amd.linear runs them, beside the byte floor (read M once, write the sampled rows)"""
+    from fewbit_amd import linear
+    rows, features = m.shape
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    floor_bytes = (rows + proj) * features * m.element_size()
+    rec = {'byte_floor_bytes': floor_bytes, 'byte_floor_us_at_8TBs': round(floor_bytes / 8e6, 2)}
+    for kind in ('dct', 'dft'):
+        us = timed(lambda: linear._sketch(kind, m, proj, gen), reps=20)
+        rec[kind] = {'us': round(us, 1), 'x_byte_floor': round(us / (floor_bytes / 8e6), 1), 'path': linear.sampled_transform_path(kind, m)}
+    return rec
 
 
 def main():
@@ -75,7 +100,9 @@ def main():
             rec['torch_randint_plus_matmul_us'] = round(timed(torch_rad), 1)
             rec['torch_matmul_only_us'] = round(timed(lambda: S @ mo), 1)
             rec['torch_matmul_only_TFLOPs'] = round(flops / rec['torch_matmul_only_us'] / 1e6, 1)
-            rec['S_bytes_not_materialised'] = proj * rows * 2
+            rec['s_fragment_bytes'] = {dist: cabi.describe_sketch(dist, rows, features, proj, dtype)['s_fragment_bytes'] for dist in ('rademacher', 'gaussian')}
+            if rows * features <= 16384 * 3072:
+                rec['sampled_transform'] = sampled_transforms(m, proj)
             print(json.dumps(rec), flush=True)
             out.append(rec)
             del m, S, mo
