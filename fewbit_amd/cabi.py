@@ -16,7 +16,7 @@ __all__ = [
     'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError', 'describe_forward',
     'describe_backward', 'describe_stepwise1_forward', 'describe_stepwise1_backward', 'tune',
     'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'next_sketch_seed', 'mix_sketch_seed', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves', 'tune_sketch_halves', 'tune_sketch_convert', 'tune_sketch_partials', 'tune_sketch_materialise', 'xoshiro128pp',
-    'philox4x32',
+    'philox4x32', 'sampled_dct', 'sampled_dct_workspace_bytes',
 ]
 
 import os
@@ -40,6 +40,7 @@ SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwid
            'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune',
            'fewbit_hip_sketch_workspace', 'fewbit_hip_sketch', 'fewbit_hip_sketch_device_seed', 'fewbit_hip_sketch_next_seed',
            'fewbit_hip_sketch_mix_seed', 'fewbit_hip_sketch_matrix', 'fewbit_hip_sketch_describe',
+           'fewbit_hip_sampled_dct_workspace', 'fewbit_hip_sampled_dct',
            'fewbit_hip_philox4x32', 'fewbit_hip_xoshiro128pp')
 
 
@@ -108,6 +109,10 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_sketch_matrix.argtypes = [i32, i32, u64, sz, sz, sz, sz, vp, vp]
         L.fewbit_hip_sketch_describe.restype = i32
         L.fewbit_hip_sketch_describe.argtypes = [i32, i32, sz, sz, sz, cp, sz]
+        L.fewbit_hip_sampled_dct_workspace.restype = sz
+        L.fewbit_hip_sampled_dct_workspace.argtypes = [i32, sz, sz, sz]
+        L.fewbit_hip_sampled_dct.restype = i32
+        L.fewbit_hip_sampled_dct.argtypes = [i32, vp, sz, sz, sz, vp, sz, dbl, vp, vp, sz, vp]
         L.fewbit_hip_philox4x32.restype = None
         L.fewbit_hip_philox4x32.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
         L.fewbit_hip_xoshiro128pp.restype = None
@@ -478,6 +483,47 @@ def tune_sketch_materialise(materialise: int) -> None:
     """Gaussian S written to the workspace once as MFMA fragments and read back by the product kernel also on narrow fp32 layers (1),
     always regenerated inside the product kernel (0)"""
     tune(sketch_materialise=materialise)
+
+
+# ---- sampled cosine transform (fewbit_amd/csrc/fewbit_dct.hip): out = scale * dct(m, dim=0, norm='ortho')[idx] -------------------
+def sampled_dct_workspace_bytes(rows: int, features: int, proj: int, dtype: torch.dtype = torch.bfloat16) -> int:
+    """bytes of scratch a ``sampled_dct`` call needs; 0 = this shape has no kernel (rows not a power of two in [256, 16384])"""
+    if dtype not in DTYPES:
+        return 0
+    return lib().fewbit_hip_sampled_dct_workspace(DTYPES[dtype], rows, features, proj)
+
+
+def sampled_dct(m: torch.Tensor, idx: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None,
+                workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    """``scale * dct(m, dim=0, norm='ortho')[idx]`` (DCT-II along the rows, orthonormal; the reference's 'dct' sketch) for a 2-D
+    ``m`` (rows x features, unit stride along the features) whose row count is a power of two in [256, 16384]; ``idx``: int64 row
+    numbers on the device of ``m``.  fp32 arithmetic, result in the dtype of ``m``."""
+    if m.device.type != 'cuda':
+        raise FewbitHipError(f'm must live on the GPU (got {m.device})')
+    if m.dim() != 2 or (m.shape[1] > 1 and m.stride(1) != 1):
+        raise FewbitHipError('m must be 2-D with unit stride along its last dimension')
+    if m.dtype not in DTYPES:
+        raise FewbitHipError(f'unsupported dtype {m.dtype}')
+    if idx.dtype != torch.int64 or idx.dim() != 1 or idx.device != m.device or not idx.is_contiguous():
+        raise FewbitHipError('idx must be a contiguous 1-D int64 tensor on the device of m')
+    rows, features = m.shape
+    proj = idx.numel()
+    ld = m.stride(0) if rows > 1 else features
+    need = sampled_dct_workspace_bytes(rows, features, proj, m.dtype)
+    if need == 0 and proj and features:
+        raise FewbitHipError(f'sampled_dct: no kernel for {rows} rows (a power of two in [256, 16384] is needed)')
+    with _on(m.device):
+        if out is None:
+            out = torch.empty((proj, features), dtype=m.dtype, device=m.device)
+        elif out.shape != (proj, features) or out.dtype != m.dtype or not out.is_contiguous():
+            raise FewbitHipError('out must be a contiguous proj x features tensor of the dtype of m')
+        if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+            workspace = torch.empty(need, dtype=torch.uint8, device=m.device)
+        _same_device(m, out, idx, *(() if workspace is None else (workspace, )))
+        _check(lib().fewbit_hip_sampled_dct(DTYPES[m.dtype], m.data_ptr(), rows, features, ld, idx.data_ptr(), proj, scale, out.data_ptr(),
+                                            0 if workspace is None else workspace.data_ptr(),
+                                            0 if workspace is None else workspace.numel() * workspace.element_size(), _stream(stream, m.device)))
+    return out
 
 
 def xoshiro128pp(state, n: int):

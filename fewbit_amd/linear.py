@@ -39,7 +39,9 @@ constructor / call signatures; the implementation is this repository's own:
   (``_sketch_seed``), so a replayed training step draws a fresh ``S`` each time -- a seed recorded by value would repeat
   one matrix for ever.  (The reference reads the generator state back in forward and cannot be captured.)
 
-The sampled transforms ('dct', 'dft') are PyTorch-level code (FFT-bound).  SURVEY section 8f, row 4.
+The sampled transforms: 'dct' on 2-D GPU tensors of 2^8 .. 2^14 rows runs on this package's kernel pair (``fewbit_hip_sampled_dct``,
+``fewbit_amd/csrc/fewbit_dct.hip``: a four-step fp32 FFT in LDS that writes only the sampled rows -- the torch.fft formulation costs
+110-120 x the bytes of the result, profiles/r06_sketch_bench.json); other shapes and 'dft' are PyTorch-level code.  SURVEY section 8f, row 4.
 """
 import contextlib
 import os
@@ -229,24 +231,46 @@ def _sampled_rows(p: int, rows: int, like: torch.Tensor, gen: torch.Generator) -
     return torch.randint(0, rows, (p, ), generator=gen, device=gen.device).to(like.device)
 
 
+def _native_dct_applies(mat: torch.Tensor) -> bool:
+    """The gfx950 sampled-DCT kernel pair (fewbit_amd/csrc/fewbit_dct.hip) takes 2-D fp32 / fp16 / bf16 GPU tensors whose row count is
+    a power of two in [256, 16384] (RoBERTa's 128 x 128 tokens = 16384); everything else keeps the torch.fft formulation."""
+    if not (_NATIVE_SKETCH and mat.device.type == 'cuda' and mat.dim() == 2 and mat.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+        return False
+    rows = mat.shape[0]
+    return 256 <= rows <= 16384 and rows & (rows - 1) == 0 and mat.shape[1] > 0
+
+
 def sampled_transform_path(kind: str, mat: torch.Tensor) -> str:
     """Which code computes the sampled transform ``kind`` ('dct' / 'dft') of ``mat`` (what bench.py prints beside its time)."""
+    if kind == 'dct' and _native_dct_applies(mat):
+        return 'gfx950 kernel pair fewbit_hip_sampled_dct (four-step fp32 FFT in LDS, only the sampled rows are written)'
     return 'torch.fft (rocFFT on the GPU): full transform along dim 0 in fp32, then the gather of the sampled rows'
 
 
-def _sketch(kind: str, mat: torch.Tensor, p: int, gen: torch.Generator, sketch_dtype=None, draw_dtype=None) -> torch.Tensor:
-    """``S @ mat`` for the unscaled sketch (``E[S^T S] = p * I`` dense, ``(p / rows) * I`` for sampled transforms)."""
+def _sketch(kind: str, mat: torch.Tensor, p: int, gen: torch.Generator, sketch_dtype=None, draw_dtype=None, scale: float = 1.0) -> torch.Tensor:
+    """``scale * S @ mat`` (``E[S^T S] = p * I`` for the dense sketches, ``(p / rows) * I`` for the sampled transforms)."""
     rows = mat.shape[0]
     if kind in ('gaussian', 'rademacher'):
         if sketch_dtype is not None and sketch_dtype != mat.dtype:
             low = mat.to(sketch_dtype)
-            return (_dense_sketch(kind, p, rows, low, gen, draw_dtype) @ low).to(mat.dtype)
-        return _dense_sketch(kind, p, rows, mat, gen, draw_dtype) @ mat
+            out = (_dense_sketch(kind, p, rows, low, gen, draw_dtype) @ low).to(mat.dtype)
+        else:
+            out = _dense_sketch(kind, p, rows, mat, gen, draw_dtype) @ mat
+        return out if scale == 1.0 else out * scale
     idx = _sampled_rows(p, rows, mat, gen)
     if kind == 'dct':
-        return dct(mat, dim=0, norm='ortho')[idx]
+        if _native_dct_applies(mat):
+            # this package's kernel pair: M is read once, one fp32 intermediate goes out and back, only the p sampled rows are
+            # written (the torch formulation below materialises the whole rows x features transform in fp32 first)
+            from . import cabi
+            if mat.stride(1) != 1 or mat.stride(0) < mat.shape[1]:
+                mat = mat.contiguous()
+            return cabi.sampled_dct(mat, idx, scale)
+        out = dct(mat, dim=0, norm='ortho')[idx]
+        return out if scale == 1.0 else out * scale
     work = mat if mat.dtype in (torch.float32, torch.float64) else mat.float()
-    return torch.fft.fft(work, dim=0, norm='ortho')[idx]                        # complex
+    out = torch.fft.fft(work, dim=0, norm='ortho')[idx]                         # complex
+    return out if scale == 1.0 else out * scale
 
 
 class _LinearGRP(torch.autograd.Function):
@@ -272,7 +296,7 @@ class _LinearGRP(torch.autograd.Function):
         token, gen = _capture_rng(generator, input.device)
         scale = 1.0 / p if kind in ('gaussian', 'rademacher') else rows / p
         draw_dtype = sketch_dtype or flat.dtype
-        sketch = _sketch(kind, flat.detach(), p, gen, sketch_dtype, draw_dtype) * scale
+        sketch = _sketch(kind, flat.detach(), p, gen, sketch_dtype, draw_dtype, scale)
         ctx.save_for_backward(sketch, weight)
         ctx.token, ctx.p, ctx.kind, ctx.sketch_dtype, ctx.draw_dtype = token, p, kind, sketch_dtype, draw_dtype
         ctx.has_bias = bias is not None

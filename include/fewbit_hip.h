@@ -58,8 +58,8 @@ extern "C" {
  *   3: + seeds in device memory (fewbit_hip_sketch_device_seed, fewbit_hip_sketch_next_seed, fewbit_hip_sketch_mix_seed).
  *   4: + fewbit_hip_xoshiro128pp; the Gaussian S redefined on xoshiro128++ streams (the same seed gives another matrix than under 3).
  *   5: FROZEN.  The six fewbit_hip_sketch_tune_* measurement hooks of versions 2-4 are gone from the interface: their settings are
- *      keys of the one remaining hook, fewbit_hip_tune ("sketch_slices", ...).  Nothing else changed; what is declared below is
- *      what a binding needs (tests/test_api.py pins the exported symbol list). */
+ *      keys of the one remaining hook, fewbit_hip_tune ("sketch_slices", ...); + fewbit_hip_sampled_dct (the reference's 'dct'
+ *      estimator).  What is declared below is what a binding needs (tests/test_api.py pins the exported symbol list). */
 #define FEWBIT_HIP_ABI_VERSION 5
 
 typedef enum fewbit_status {
@@ -211,6 +211,20 @@ int fewbit_hip_sketch_matrix(int dist, int dtype, uint64_t seed, size_t row0, si
                              void *stream);
 /* launch shape a fewbit_hip_sketch call would use, as JSON: {"kernel", "grid": [x, y, z], "threads", "k_slice", ...} */
 int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features, size_t proj, char *buf, size_t len);
+/* ------------------------------------------------------------------------------------------------------------------
+ * Sampled cosine transform of the randomized linear layers:  out[j][:] = scale * DCT-II_ortho(M along its rows)[idx[j]][:]
+ *   replaces  `dct(input_view, dim=0, norm='ortho')[proj, ...]`, fewbit/functional/linear.py:113-122 (forward) and :174-183
+ *             (backward), with dct = fewbit/fft.py:10-43 -- a full fp32 transform through the FFT library, then a gather
+ *   m    rows x features, row-major with leading dimension `ld` (elements), dtype F32 / F16 / BF16; rows a power of two in
+ *        [256, 16384] (anything else: FEWBIT_ERR_UNSUPPORTED, and fewbit_hip_sampled_dct_workspace returns 0 -- the caller
+ *        keeps the library formulation for those); arithmetic and the intermediate are fp32 whatever the dtype
+ *   idx  proj row numbers in [0, rows) as int64 in DEVICE memory (drawn with replacement: duplicates are served one by one)
+ *   out  proj x features, contiguous, the dtype of m (fully written)
+ *   workspace  fewbit_hip_sampled_dct_workspace(...) = ceil(features / 64) * rows * 256 bytes, 16-byte aligned; contents are scratch
+ * Two launches on `stream` (fewbit_amd/csrc/fewbit_dct.hip); deterministic. */
+size_t fewbit_hip_sampled_dct_workspace(int dtype, size_t rows, size_t features, size_t proj);
+int fewbit_hip_sampled_dct(int dtype, const void *m, size_t rows, size_t features, size_t ld, const int64_t *idx, size_t proj, double scale,
+                           void *out, void *workspace, size_t workspace_bytes, void *stream);
 /* Philox4x32-10 on the HOST (the generator behind S; known-answer tests run it without a GPU) */
 void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 /* xoshiro128++ 1.0 on the HOST (Blackman & Vigna; the stream generator of the Gaussian sketch, seeded by a Philox call per
