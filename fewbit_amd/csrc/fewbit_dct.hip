@@ -23,16 +23,17 @@
 //
 // ---- tiling ------------------------------------------------------------------------------------------------------------------
 //   tile        2 rows-of-transforms x L points x 32 complex columns (64 features) of fp32 complex = 64 KiB of LDS at L = 128, two
-//               workgroups per CU.  Lanes run along the columns: every LDS access of a half-wave is 256 contiguous bytes (all 64
-//               banks once, ds_read/write_b64: conflict-free), every twiddle is half-wave-uniform (an LDS broadcast).
-//   FFT         in place, decimation in frequency, radix 4 (one radix-2 stage when log2 L is odd), one barrier per stage; the result
-//               stands in digit-reversed positions (pos_to_freq / freq_to_pos), which costs nothing: both passes address their
-//               outputs through the map.
+//               workgroups of 512 threads per CU.  Lanes run along the columns: every LDS access of a half-wave is 256 contiguous
+//               bytes (all 64 banks once, ds_read/write_b64: conflict-free), every twiddle is half-wave-uniform (an LDS broadcast).
+//   FFT         in place, decimation in frequency, TWO stages at L = 128 (radix 16 then radix 8, each butterfly entirely in the
+//               registers of one thread; 64 = 8 x 8, 32 = 8 x 4, 16 = 16), one barrier per stage; the result stands in digit-reversed
+//               positions (pos_to_freq / freq_to_pos), which costs nothing: both passes address their outputs through the map.
 //   pass A      workgroup (b, t): n2 in {2b, 2b+1}, column tile t.  Loads 2 N1 row segments of 64 features (128 B of bf16: full cache
 //               lines, 16 B per lane), converts to fp32, transforms along n1, multiplies by W_N^{n2 k1} (two table lookups and one
 //               complex multiply) and writes the intermediate as [tile][k1][n2][32 columns]: 512 contiguous bytes per k1.
-//   pass B      workgroup (u, t): residues k1 = u and N1 - u.  Reads two contiguous N2 x 256 B blocks, transforms along n2, then every
-//               wave scans idx with a ballot and serves its matches two at a time (one per half-wave, lanes along the columns).
+//   pass B      workgroup (u, t): residues k1 = u and N1 - u.  Reads two contiguous N2 x 256 B blocks (and, in the same breath, its share
+//               of idx), transforms along n2, collects the samples of its two residue classes in an LDS list and serves them 16 at a
+//               time (one per half-wave, lanes along the columns; e^{-i pi k / 2N} from two small tables, no transcendental per sample).
 //   traffic     M once + 2 x rows x features x 4 B of intermediate + the p sampled rows: 16384 x 768 bf16, p = 3276: 25 + 2 x 50 + 5 MB.
 // Roofline class: HBM / Infinity Cache bandwidth (5 N log2 N flops per column: 0.9 GFLOP for 16384 x 768).
 #include <hip/hip_runtime.h>
@@ -40,6 +41,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <type_traits>
 
 #include "fewbit_hip.h"
 
@@ -52,7 +54,7 @@ FEWBIT_HIDDEN int fail(int code, const char *fmt, ...) __attribute__((format(pri
 
 namespace dct {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
 constexpr int C = 32;                       // complex columns of a tile = 64 features
 constexpr int kFeatures = 2 * C;
 constexpr int kSlots = kThreads / C;        // butterflies of one column in flight per stage pass
@@ -62,6 +64,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) { return f32x2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ f32x2 mul_mi(f32x2 a) { return f32x2{a.y, -a.x}; }                                   // a * (-i)
 // e^{-2 pi i num / den}, den a power of two (num / den is exact in fp32)
 __device__ __forceinline__ f32x2 unit(int num, int den) {
     float s, c;
@@ -69,68 +72,125 @@ __device__ __forceinline__ f32x2 unit(int num, int den) {
     return f32x2{c, s};
 }
 
-// radix schedule of a length-L transform: radix 4 while at least two bits remain, then one radix 2
-constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
+// ---- small transforms in registers, natural order in and out: x[q] <- sum_j x[j] e^{-2 pi i j q / R} ------------------------------
+constexpr float kR2 = 0.70710678118654752f;                   // sqrt(1/2)
+constexpr float kC8 = 0.92387953251128674f, kS8 = 0.38268343236508977f;      // cos, sin of pi / 8
+__device__ __forceinline__ void dft2(f32x2 &a, f32x2 &b) {
+    const f32x2 s = a + b, d = a - b;
+    a = s;
+    b = d;
+}
+__device__ __forceinline__ void dft4(f32x2 &a0, f32x2 &a1, f32x2 &a2, f32x2 &a3) {
+    const f32x2 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mi(a1 - a3);
+    a0 = t0 + t2;
+    a1 = t1 + t3;
+    a2 = t0 - t2;
+    a3 = t1 - t3;
+}
+template <int R> __device__ __forceinline__ void dft(f32x2 (&x)[R]) {
+    if constexpr (R == 2) {
+        dft2(x[0], x[1]);
+    } else if constexpr (R == 4) {
+        dft4(x[0], x[1], x[2], x[3]);
+    } else if constexpr (R == 8) {
+        // j = 2a + b, q = p + 4 q':  y[p + 4 q'] = sum_b W8^{bp} (-1)^{b q'} sum_a x[2a + b] W4^{ap}
+        dft4(x[0], x[2], x[4], x[6]);
+        dft4(x[1], x[3], x[5], x[7]);
+        const f32x2 u1 = x[3], u2 = x[5], u3 = x[7];
+        const f32x2 t0 = x[1];
+        const f32x2 t1 = f32x2{(u1.x + u1.y) * kR2, (u1.y - u1.x) * kR2};             // * W8^1 = sqrt(1/2) (1 - i)
+        const f32x2 t2 = mul_mi(u2);                                                   // * W8^2
+        const f32x2 t3 = f32x2{(u3.y - u3.x) * kR2, -(u3.x + u3.y) * kR2};            // * W8^3 = -sqrt(1/2) (1 + i)
+        const f32x2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+        x[0] = e0 + t0; x[4] = e0 - t0;
+        x[1] = e1 + t1; x[5] = e1 - t1;
+        x[2] = e2 + t2; x[6] = e2 - t2;
+        x[3] = e3 + t3; x[7] = e3 - t3;
+    } else {
+        static_assert(R == 16, "radix 2, 4, 8 or 16");
+        // j = 4a + b, q = p + 4 q':  y[p + 4 q'] = sum_b W16^{bp} W4^{b q'} sum_a x[4a + b] W4^{ap}
+        dft4(x[0], x[4], x[8], x[12]);
+        dft4(x[1], x[5], x[9], x[13]);
+        dft4(x[2], x[6], x[10], x[14]);
+        dft4(x[3], x[7], x[11], x[15]);
+        // u[b][p] = x[4p + b]; twiddle W16^{bp}
+        x[5] = cmul(x[5], f32x2{kC8, -kS8});                                           // b = 1, p = 1: W16^1
+        x[9] = f32x2{(x[9].x + x[9].y) * kR2, (x[9].y - x[9].x) * kR2};               // b = 1, p = 2: W16^2 = W8^1
+        x[13] = cmul(x[13], f32x2{kS8, -kC8});                                         // b = 1, p = 3: W16^3
+        x[6] = f32x2{(x[6].x + x[6].y) * kR2, (x[6].y - x[6].x) * kR2};               // b = 2, p = 1: W16^2
+        x[10] = mul_mi(x[10]);                                                         // b = 2, p = 2: W16^4 = -i
+        x[14] = f32x2{(x[14].y - x[14].x) * kR2, -(x[14].x + x[14].y) * kR2};         // b = 2, p = 3: W16^6 = W8^3
+        x[7] = cmul(x[7], f32x2{kS8, -kC8});                                           // b = 3, p = 1: W16^3
+        x[11] = f32x2{(x[11].y - x[11].x) * kR2, -(x[11].x + x[11].y) * kR2};         // b = 3, p = 2: W16^6
+        x[15] = cmul(x[15], f32x2{-kC8, kS8});                                         // b = 3, p = 3: W16^9
+        // outer transforms over b for each p; result q' of group p is output p + 4 q' -- which is where dft4 leaves it when the
+        // group is (x[4p], x[4p+1], x[4p+2], x[4p+3]) and the outputs are then transposed: y[p + 4q'] = group_p[q']
+        dft4(x[0], x[1], x[2], x[3]);
+        dft4(x[4], x[5], x[6], x[7]);
+        dft4(x[8], x[9], x[10], x[11]);
+        dft4(x[12], x[13], x[14], x[15]);
+        f32x2 y[16];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[p + 4 * q] = x[4 * p + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = y[q];
+    }
+}
+
+// radix of the first stage of a block of length `len`: 128 = 16 x 8, 64 = 8 x 8, 32 = 8 x 4, 16 = 16
+__host__ __device__ constexpr int first_radix(int len) { return len >= 128 ? 16 : len == 64 ? 8 : len == 32 ? 8 : len == 16 ? 16 : len == 8 ? 8 : len == 4 ? 4 : 2; }
+
 // position P (after the in-place DIF stages) -> frequency k.  Stage i with radix r_i on blocks of length L_i leaves digit q_i
 // (k = q_1 + r_1 q_2 + r_1 r_2 q_3 + ...) in sub-block q_i: P = sum q_i L_i / r_i.
-template <int L> __host__ __device__ __forceinline__ int pos_to_freq(int p) {
-    int k = 0, mult = 1, len = L;
-#pragma unroll
-    for (int bits = ilog2(L); bits > 0;) {
-        const int r = bits >= 2 ? 4 : 2, s = len / r, q = p / s;
-        p -= q * s;
-        k += q * mult;
-        mult *= r;
-        len = s;
-        bits -= bits >= 2 ? 2 : 1;
+template <int LEN> __host__ __device__ __forceinline__ int pos_to_freq(int p) {
+    if constexpr (LEN <= 1) {
+        return 0;
+    } else {
+        constexpr int r = first_radix(LEN), s = LEN / r;
+        return p / s + r * pos_to_freq<s>(p % s);
     }
-    return k;
 }
-template <int L> __host__ __device__ __forceinline__ int freq_to_pos(int k) {
-    int p = 0, len = L;
-#pragma unroll
-    for (int bits = ilog2(L); bits > 0;) {
-        const int r = bits >= 2 ? 4 : 2, s = len / r, q = k % r;
-        k /= r;
-        p += q * s;
-        len = s;
-        bits -= bits >= 2 ? 2 : 1;
+template <int LEN> __host__ __device__ __forceinline__ int freq_to_pos(int k) {
+    if constexpr (LEN <= 1) {
+        return 0;
+    } else {
+        constexpr int r = first_radix(LEN), s = LEN / r;
+        return (k % r) * s + freq_to_pos<s>(k / r);
     }
-    return p;
 }
 
 // One stage of the in-place transform of the tile [2][L][C] along its middle axis: blocks of length LEN, radix R, twiddles
-// tw[m] = W_L^m.  Thread (c = tid % 32, slot = tid / 32) takes the butterflies slot, slot + 8, ... of column c of both rows.
+// tw[m] = W_L^m.  Thread (c = tid % 32, slot = tid / 32) takes the butterflies slot, slot + 16, ... of column c of both rows; a
+// butterfly is R loads, the transform in registers, the twiddles W_LEN^{ss q} (none in the last stage) and R stores.
 template <int L, int LEN, int R> __device__ __forceinline__ void stage(f32x2 *tile, const f32x2 *tw, int c, int slot) {
     constexpr int S = LEN / R, kPerRow = L / R;
 #pragma unroll
-    for (int bid = slot; bid < 2 * kPerRow; bid += kSlots) {
+    for (int bid0 = 0; bid0 < 2 * kPerRow; bid0 += kSlots) {
+        const int bid = bid0 + slot;
+        if (2 * kPerRow % kSlots != 0 && bid >= 2 * kPerRow) break;
         const int row = bid / kPerRow, b = bid % kPerRow, block = b / S, ss = b % S;
         f32x2 *p = tile + (row * L + block * LEN + ss) * C + c;
-        if constexpr (R == 4) {
-            const f32x2 a0 = p[0], a1 = p[S * C], a2 = p[2 * S * C], a3 = p[3 * S * C];
-            const f32x2 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
-            const f32x2 t3 = f32x2{d.y, -d.x};                                  // -i (a1 - a3)
-            const f32x2 w1 = tw[(L / LEN) * ss], w2 = tw[(L / LEN) * ss * 2], w3 = tw[(L / LEN) * ss * 3];
-            p[0] = t0 + t2;
-            p[S * C] = cmul(t1 + t3, w1);
-            p[2 * S * C] = cmul(t0 - t2, w2);
-            p[3 * S * C] = cmul(t1 - t3, w3);
-        } else {
-            const f32x2 a0 = p[0], a1 = p[S * C];
-            p[0] = a0 + a1;
-            p[S * C] = cmul(a0 - a1, tw[(L / LEN) * ss]);
+        f32x2 x[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) x[j] = p[j * S * C];
+        dft<R>(x);
+        if constexpr (S > 1) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) x[q] = cmul(x[q], tw[(L / LEN) * ss * q]);
         }
+#pragma unroll
+        for (int q = 0; q < R; ++q) p[q * S * C] = x[q];
     }
     __syncthreads();
 }
 
 template <int L, int LEN = L> __device__ __forceinline__ void fft_tile(f32x2 *tile, const f32x2 *tw, int c, int slot) {
-    if constexpr (LEN >= 4) {
-        stage<L, LEN, 4>(tile, tw, c, slot);
-        fft_tile<L, LEN / 4>(tile, tw, c, slot);
-    } else if constexpr (LEN == 2) {
-        stage<L, LEN, 2>(tile, tw, c, slot);
+    if constexpr (LEN > 1) {
+        constexpr int R = first_radix(LEN);
+        stage<L, LEN, R>(tile, tw, c, slot);
+        fft_tile<L, LEN / R>(tile, tw, c, slot);
     }
 }
 
@@ -144,45 +204,62 @@ __device__ __forceinline__ float half_to_float(uint32_t h, int dt) {
     return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(h)));
 }
 
-// the piece `piece` of the 64-feature segment of row `row` that starts at feature f0, as fp32 (zeros beyond `features`)
-template <int DT> __device__ __forceinline__ void load_piece(const void *x, size_t row, size_t ld, size_t f0, int piece, size_t features, float (&v)[In<DT>::kPieceFeatures]) {
+// the piece `piece` of the 64-feature segment of row `row` that starts at feature f0, raw (16 bytes: 8 features of a 16-bit dtype or
+// 4 of fp32).  FULL: the whole tile lies inside the matrix (a workgroup-uniform fact): one unguarded 16-byte load -- a load under a
+// lane-divergent guard makes hipcc wait for it on the spot, which serialised the tile's loads; otherwise zeros beyond `features`,
+// element by element.  The conversion to fp32 happens when the piece is written to LDS (unpack), after the latency has been used.
+template <int DT, bool FULL> __device__ __forceinline__ u32x4 load_piece(const void *x, size_t row, size_t ld, size_t f0, int piece, size_t features) {
     constexpr int PF = In<DT>::kPieceFeatures;
     const size_t f = f0 + static_cast<size_t>(piece) * PF;
     if constexpr (DT == FEWBIT_F32) {
-        const float *p = static_cast<const float *>(x) + row * ld + f;
-        if (f + PF <= features) {
-            typedef f32x4 __attribute__((aligned(4))) f32x4u;
-            const f32x4 q = *reinterpret_cast<const f32x4u *>(p);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = q[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = f + e < features ? p[e] : 0.0f;
+        const uint32_t *p = static_cast<const uint32_t *>(x) + row * ld + f;
+        if (FULL || f + PF <= features) {
+            typedef u32x4 __attribute__((aligned(4))) u32x4u;
+            return *reinterpret_cast<const u32x4u *>(p);
         }
+        u32x4 q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = f + e < features ? p[e] : 0u;
+        return q;
     } else {
         const uint16_t *p = static_cast<const uint16_t *>(x) + row * ld + f;
-        if (f + PF <= features) {
+        if (FULL || f + PF <= features) {
             typedef u32x4 __attribute__((aligned(2))) u32x4u;
-            const u32x4 q = *reinterpret_cast<const u32x4u *>(p);
+            return *reinterpret_cast<const u32x4u *>(p);
+        }
+        u32x4 q = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[2 * e] = half_to_float(q[e] & 0xffffu, DT);
-                v[2 * e + 1] = half_to_float(q[e] >> 16, DT);
-            }
-        } else {
+        for (int e = 0; e < 8; ++e) q[e >> 1] |= (f + e < features ? static_cast<uint32_t>(p[e]) : 0u) << (16 * (e & 1));
+        return q;
+    }
+}
+template <int DT> __device__ __forceinline__ void unpack_piece(u32x4 q, float (&v)[In<DT>::kPieceFeatures]) {
+    if constexpr (DT == FEWBIT_F32) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = f + e < features ? half_to_float(p[e], DT) : 0.0f;
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t w = q[e];              // (a scalar first: __builtin_bit_cast applied to the element expression q[e] itself
+            v[e] = __builtin_bit_cast(float, w);  //  reads the vector's first element for every e -- observed with hipcc 7.2)
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = half_to_float(q[e] & 0xffffu, DT);
+            v[2 * e + 1] = half_to_float(q[e] >> 16, DT);
         }
     }
 }
 
-constexpr int kFine = 128;                  // W_N^e = fine[e % 128] * coarse[e / 128]
+constexpr int kFine = 128;                  // W_D^e = fine[e % 128] * coarse[e / 128] (two tables of at most 128 entries for e < 16384)
+constexpr int coarse_entries(int n) { return n / kFine > 0 ? n / kFine : 1; }
+__device__ __forceinline__ f32x2 table_unit(const f32x2 *fine, const f32x2 *coarse, int e, bool has_coarse) {
+    return has_coarse ? cmul(fine[e % kFine], coarse[e / kFine]) : fine[e % kFine];
+}
 
 // ---- pass A -----------------------------------------------------------------------------------------------------------------
 // grid (N2 / 2, column tiles).  inter: [tile][k1][n2][C] complex fp32.
 template <int DT, int N1, int N2>
-__global__ __launch_bounds__(kThreads, 2) void dct_pass_a_kernel(const void *__restrict__ x, size_t features, size_t ld, f32x2 *__restrict__ inter) {
-    constexpr int N = N1 * N2, kCoarse = N / kFine > 0 ? N / kFine : 1;
+__global__ __launch_bounds__(kThreads, 4) void dct_pass_a_kernel(const void *__restrict__ x, size_t features, size_t ld, f32x2 *__restrict__ inter) {
+    constexpr int N = N1 * N2, kCoarse = coarse_entries(N);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     f32x2 *tile = reinterpret_cast<f32x2 *>(lds_raw);                 // [2][N1][C]
     f32x2 *tw = tile + 2 * N1 * C;                                    // W_N1^m, m < N1
@@ -192,37 +269,47 @@ __global__ __launch_bounds__(kThreads, 2) void dct_pass_a_kernel(const void *__r
     const size_t t = blockIdx.y, f0 = t * kFeatures;
 
     // ---- loads first (all in flight), tables while they travel
-    constexpr int PF = In<DT>::kPieceFeatures, PPS = In<DT>::kPiecesPerSegment, kPieces = 2 * N1 * PPS / kThreads;
-    static_assert(2 * N1 * PPS % kThreads == 0, "whole pieces per thread");
-    float v[kPieces][PF];
+    constexpr int PF = In<DT>::kPieceFeatures, PPS = In<DT>::kPiecesPerSegment, kTotal = 2 * N1 * PPS, kPieces = (kTotal + kThreads - 1) / kThreads;
+    // (one body per case, FULL tile or edge tile, each with its own registers from the loads to the LDS writes: were the two
+    // cases to meet in one set of registers in between, the copies at the join would wait for the loads right behind their issue)
+    auto fill_tile = [&](auto full) __attribute__((always_inline)) {
+        u32x4 raw[kPieces];
 #pragma unroll
-    for (int i = 0; i < kPieces; ++i) {
-        const int pid = tid + kThreads * i, seg = pid / PPS, piece = pid % PPS, n1 = seg >> 1, r = seg & 1;
-        const int n = N2 * n1 + 2 * b + r;                              // index into the reordered sequence v
-        const size_t row = n < N / 2 ? 2 * static_cast<size_t>(n) : 2 * static_cast<size_t>(N - 1 - n) + 1;
-        load_piece<DT>(x, row, ld, f0, piece, features, v[i]);
-    }
-    for (int m = tid; m < N1; m += kThreads) tw[m] = unit(m, N1);
-    for (int m = tid; m < kFine; m += kThreads) fine[m] = unit(m, N);
-    for (int m = tid; m < kCoarse; m += kThreads) coarse[m] = unit(m * kFine, N);
+        for (int i = 0; i < kPieces; ++i) {
+            const int pid = tid + kThreads * i, seg = pid / PPS, piece = pid % PPS, n1 = seg >> 1, r = seg & 1;
+            if (kTotal % kThreads != 0 && pid >= kTotal) break;
+            const int n = N2 * n1 + 2 * b + r;                          // index into the reordered sequence v
+            const size_t row = n < N / 2 ? 2 * static_cast<size_t>(n) : 2 * static_cast<size_t>(N - 1 - n) + 1;
+            raw[i] = load_piece<DT, decltype(full)::value>(x, row, ld, f0, piece, features);
+        }
+        for (int m = tid; m < N1; m += kThreads) tw[m] = unit(m, N1);
+        for (int m = tid; m < kFine; m += kThreads) fine[m] = unit(m, N);
+        for (int m = tid; m < kCoarse; m += kThreads) coarse[m] = unit(m * kFine, N);
 #pragma unroll
-    for (int i = 0; i < kPieces; ++i) {
-        const int pid = tid + kThreads * i, seg = pid / PPS, piece = pid % PPS, n1 = seg >> 1, r = seg & 1;
-        f32x4 *dst = reinterpret_cast<f32x4 *>(tile + (r * N1 + n1) * C + piece * (PF / 2));
+        for (int i = 0; i < kPieces; ++i) {
+            const int pid = tid + kThreads * i, seg = pid / PPS, piece = pid % PPS, n1 = seg >> 1, r = seg & 1;
+            if (kTotal % kThreads != 0 && pid >= kTotal) break;
+            float v[PF];
+            unpack_piece<DT>(raw[i], v);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(tile + (r * N1 + n1) * C + piece * (PF / 2));
 #pragma unroll
-        for (int e = 0; e < PF / 4; ++e) dst[e] = f32x4{v[i][4 * e], v[i][4 * e + 1], v[i][4 * e + 2], v[i][4 * e + 3]};
-    }
+            for (int e = 0; e < PF / 4; ++e) dst[e] = f32x4{v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]};
+        }
+    };
+    if (f0 + kFeatures <= features) fill_tile(std::true_type{});       // (workgroup-uniform)
+    else fill_tile(std::false_type{});
     __syncthreads();
 
     fft_tile<N1>(tile, tw, c, slot);
 
     // ---- twiddle + store: unit = two complex columns (16 B) of one (P, r); 32 consecutive lanes = the 512 contiguous bytes of one k1
-    constexpr int kUnits = 2 * N1 * (C / 2) / kThreads;
-#pragma unroll 4
+    constexpr int kUnitsTotal = 2 * N1 * (C / 2), kUnits = (kUnitsTotal + kThreads - 1) / kThreads;
+#pragma unroll
     for (int i = 0; i < kUnits; ++i) {
         const int uid = tid + kThreads * i, c2 = uid % (C / 2), r = (uid / (C / 2)) & 1, p = uid / C;
+        if (kUnitsTotal % kThreads != 0 && uid >= kUnitsTotal) break;
         const int k1 = pos_to_freq<N1>(p), e = (2 * b + r) * k1;
-        const f32x2 w = kCoarse > 1 ? cmul(fine[e % kFine], coarse[e / kFine]) : fine[e % kFine];
+        const f32x2 w = table_unit(fine, coarse, e, kCoarse > 1);
         const f32x4 z = *reinterpret_cast<const f32x4 *>(tile + (r * N1 + p) * C + 2 * c2);
         const f32x2 a = cmul(f32x2{z[0], z[1]}, w), bb = cmul(f32x2{z[2], z[3]}, w);
         f32x4 *dst = reinterpret_cast<f32x4 *>(inter + ((t * N1 + k1) * N2 + 2 * b + r) * C + 2 * c2);
@@ -232,43 +319,115 @@ __global__ __launch_bounds__(kThreads, 2) void dct_pass_a_kernel(const void *__r
 
 // ---- pass B -----------------------------------------------------------------------------------------------------------------
 // grid (N1 / 2 + 1, column tiles): residues k1 = u and (N1 - u) % N1.
+constexpr int kListCap = 1024;              // samples a workgroup serves from its LDS list (more: the wave-by-wave fallback)
+constexpr int kAhead = 8;                   // idx entries per thread requested together with the tile: all of idx for p <= 4096
+
 template <int DT, int N1, int N2>
-__global__ __launch_bounds__(kThreads, 2) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, const int64_t *__restrict__ idx, size_t proj, size_t features,
+__global__ __launch_bounds__(kThreads, 4) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, const int64_t *__restrict__ idx, size_t proj, size_t features,
                                                                   float scale, void *__restrict__ out) {
-    constexpr int N = N1 * N2;
+    constexpr int N = N1 * N2, kCoarse = coarse_entries(N);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     f32x2 *tile = reinterpret_cast<f32x2 *>(lds_raw);                 // [2][N2][C]
     f32x2 *tw = tile + 2 * N2 * C;                                    // W_N2^m
+    f32x2 *fine = tw + N2, *coarse = fine + kFine;                    // W_4N^m (m < 128), W_4N^{128 m}: e^{-i pi k / 2N} = W_4N^k
+    int *list_k = reinterpret_cast<int *>(coarse + kCoarse), *list_j = list_k + kListCap, *count = list_j + kListCap;
     const int tid = threadIdx.x, c = tid % C, slot = tid / C, lane = tid & 63, half = lane >> 5;
     const int u = blockIdx.x, k1a = u, k1b = (N1 - u) % N1;
     const size_t t = blockIdx.y, f0 = t * kFeatures;
 
-    constexpr int kPieces = 2 * N2 * (C / 2) / kThreads;              // 16-byte pieces (two complex) per thread
+    // the row numbers this thread will test go out FIRST (vmcnt counts in order: looking at them later does not wait for the tile).
+    // Unconditional loads -- the index is clamped, the verdict is a select -- so that hipcc issues them back to back instead of one
+    // per branch with a wait each (6 us of a 22 us launch); the low dword of an int64 in [0, N) is the number
+    const int *idx_lo = reinterpret_cast<const int *>(idx);
+    auto raw = [&](size_t i) -> int { return idx_lo[2 * (i < proj ? i : proj - 1)]; };
+    int kraw[kAhead];
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) kraw[a] = raw(static_cast<size_t>(a) * kThreads + tid);
+    constexpr int kTotal = 2 * N2 * (C / 2), kPieces = (kTotal + kThreads - 1) / kThreads;       // 16-byte pieces (two complex)
     f32x4 v[kPieces];
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
         const int pid = tid + kThreads * i, r = pid / (N2 * (C / 2)), rest = pid % (N2 * (C / 2));
+        if (kTotal % kThreads != 0 && pid >= kTotal) break;
         const f32x2 *src = inter + (t * N1 + (r == 0 ? k1a : k1b)) * static_cast<size_t>(N2) * C;
         v[i] = reinterpret_cast<const f32x4 *>(src)[rest];
     }
+    // a sample belongs to this workgroup when its residue k % N1 is one of the two it holds; -1 = not ours
+    auto mine = [&](int word, size_t i) -> int {
+        const int kk = word & (N - 1), k1 = kk % N1;
+        return (i < proj && (k1 == k1a || k1 == k1b)) ? kk : -1;
+    };
     for (int m = tid; m < N2; m += kThreads) tw[m] = unit(m, N2);
+    for (int m = tid; m < kFine; m += kThreads) fine[m] = unit(m, 4 * N);
+    for (int m = tid; m < kCoarse; m += kThreads) coarse[m] = unit(m * kFine, 4 * N);
+    if (tid == 0) *count = 0;
 #pragma unroll
-    for (int i = 0; i < kPieces; ++i) reinterpret_cast<f32x4 *>(tile)[tid + kThreads * i] = v[i];
+    for (int i = 0; i < kPieces; ++i) {
+        if (kTotal % kThreads != 0 && tid + kThreads * i >= kTotal) break;
+        reinterpret_cast<f32x4 *>(tile)[tid + kThreads * i] = v[i];
+    }
     __syncthreads();
-
-    fft_tile<N2>(tile, tw, c, slot);
-
-    // ---- the sampled rows of this workgroup's two residue classes.  Every wave scans its share of idx; matches are served two
-    // at a time, one per half-wave, lanes along the 32 complex columns.
-    const float base = scale * __builtin_sqrtf(0.5f / static_cast<float>(N));          // ortho: sqrt(1 / 2N) (k > 0), sqrt(1 / 4N) (k = 0)
-    for (size_t i0 = 0; i0 < proj; i0 += kThreads) {
-        const size_t i = i0 + tid;
-        int k = -1;
-        if (i < proj) {
-            const int kk = static_cast<int>(idx[i]) & (N - 1);
-            const int k1 = kk % N1;
-            if (k1 == k1a || k1 == k1b) k = kk;
+    // the workgroup's samples -> LDS list (order does not matter: every sample writes its own row of the result)
+    auto enlist = [&](int k, size_t j) {
+        if (k >= 0) {
+            const int pos = atomicAdd(count, 1);
+            if (pos < kListCap) {
+                list_k[pos] = k;
+                list_j[pos] = static_cast<int>(j);
+            }
         }
+    };
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) enlist(mine(kraw[a], static_cast<size_t>(a) * kThreads + tid), static_cast<size_t>(a) * kThreads + tid);
+    for (size_t i0 = static_cast<size_t>(kAhead) * kThreads; i0 < proj; i0 += kThreads) enlist(mine(raw(i0 + tid), i0 + tid), i0 + tid);
+
+    fft_tile<N2>(tile, tw, c, slot);                                   // (ends with a barrier: the list is complete behind it)
+
+    // ---- the sampled rows of this workgroup's two residue classes: one per half-wave at a time, lanes along the 32 complex columns
+    const float base = scale * __builtin_sqrtf(0.5f / static_cast<float>(N));          // ortho: sqrt(1 / 2N) (k > 0), sqrt(1 / 4N) (k = 0)
+    auto write_row = [&](int km, size_t j) __attribute__((always_inline)) {
+        const int k1 = km % N1, k2 = km / N1;
+        const int r = k1 == k1a ? 0 : 1;
+        const int k2m = k1 == 0 ? (N2 - k2) % N2 : N2 - 1 - k2;         // N - k = (N1 - k1) + N1 k2m
+        const f32x2 zk = tile[(r * N2 + freq_to_pos<N2>(k2)) * C + c];
+        f32x2 zm = tile[((1 - r) * N2 + freq_to_pos<N2>(k2m)) * C + c];
+        zm.y = -zm.y;                                                   // conj Z[N - k]
+        const f32x2 va = (zk + zm) * 0.5f, d = (zk - zm) * 0.5f, vb = mul_mi(d);
+        const f32x2 w = table_unit(fine, coarse, km, kCoarse > 1);      // e^{-i pi k / 2N}
+        const float f = (km == 0 ? kR2 : 1.0f) * 2.0f * base;
+        const float ya = (w.x * va.x - w.y * va.y) * f, yb = (w.x * vb.x - w.y * vb.y) * f;       // Re(w V)
+        const size_t fa = f0 + 2 * c;
+        if constexpr (DT == FEWBIT_F32) {
+            float *o = static_cast<float *>(out) + j * features + fa;
+            if (fa + 1 < features) *reinterpret_cast<f32x2 *>(o) = f32x2{ya, yb};
+            else if (fa < features) o[0] = ya;
+        } else {
+            uint16_t *o = static_cast<uint16_t *>(out) + j * features + fa;
+            uint16_t ha, hb;
+            if constexpr (DT == FEWBIT_BF16) {
+                ha = __builtin_bit_cast(uint16_t, static_cast<__bf16>(ya));
+                hb = __builtin_bit_cast(uint16_t, static_cast<__bf16>(yb));
+            } else {
+                ha = __builtin_bit_cast(uint16_t, static_cast<_Float16>(ya));
+                hb = __builtin_bit_cast(uint16_t, static_cast<_Float16>(yb));
+            }
+            if (fa + 1 < features) {
+                typedef uint32_t __attribute__((aligned(2))) u32u;
+                *reinterpret_cast<u32u *>(o) = static_cast<uint32_t>(ha) | (static_cast<uint32_t>(hb) << 16);
+            } else if (fa < features) {
+                o[0] = ha;
+            }
+        }
+    };
+    const int total = *count;                                          // block-uniform
+    if (total <= kListCap) {
+        for (int e = slot; e < total; e += kSlots) write_row(list_k[e], static_cast<size_t>(list_j[e]));
+        return;
+    }
+    // more samples in these two classes than the list holds (p in the tens of thousands, or a skewed idx): every wave walks idx
+    // itself and serves its matches two at a time
+    for (size_t i0 = 0; i0 < proj; i0 += kThreads) {
+        const int k = mine(raw(i0 + tid), i0 + tid);
         unsigned long long mask = __ballot(k >= 0);
         while (mask != 0) {                                             // wave-uniform
             const int l0 = __builtin_ctzll(mask);
@@ -281,40 +440,7 @@ __global__ __launch_bounds__(kThreads, 2) void dct_pass_b_kernel(const f32x2 *__
             const int src = half ? l1 : l0;
             const int km = __shfl(k, src);                              // (every lane takes part in the exchange, then an odd match out idles the upper half)
             if (half == 1 && l1 == l0) continue;
-            const size_t j = i0 + (tid & ~63) + src;                    // the sample this half-wave serves
-            const int k1 = km % N1, k2 = km / N1;
-            const int r = k1 == k1a ? 0 : 1;
-            const int k2m = k1 == 0 ? (N2 - k2) % N2 : N2 - 1 - k2;     // N - k = (N1 - k1) + N1 k2m
-            const f32x2 zk = tile[(r * N2 + freq_to_pos<N2>(k2)) * C + c];
-            f32x2 zm = tile[((1 - r) * N2 + freq_to_pos<N2>(k2m)) * C + c];
-            zm.y = -zm.y;                                               // conj Z[N - k]
-            const f32x2 va = (zk + zm) * 0.5f, d = (zk - zm) * 0.5f, vb = f32x2{d.y, -d.x};
-            float sn, cs;
-            sincospif(static_cast<float>(km) / static_cast<float>(2 * N), &sn, &cs);
-            const float f = (km == 0 ? 0.70710678118654752f : 1.0f) * 2.0f * base;
-            const float ya = (cs * va.x + sn * va.y) * f, yb = (cs * vb.x + sn * vb.y) * f;     // Re(e^{-i theta} V)
-            const size_t fa = f0 + 2 * c;
-            if constexpr (DT == FEWBIT_F32) {
-                float *o = static_cast<float *>(out) + j * features + fa;
-                if (fa + 1 < features) *reinterpret_cast<f32x2 *>(o) = f32x2{ya, yb};
-                else if (fa < features) o[0] = ya;
-            } else {
-                uint16_t *o = static_cast<uint16_t *>(out) + j * features + fa;
-                uint16_t ha, hb;
-                if constexpr (DT == FEWBIT_BF16) {
-                    ha = __builtin_bit_cast(uint16_t, static_cast<__bf16>(ya));
-                    hb = __builtin_bit_cast(uint16_t, static_cast<__bf16>(yb));
-                } else {
-                    ha = __builtin_bit_cast(uint16_t, static_cast<_Float16>(ya));
-                    hb = __builtin_bit_cast(uint16_t, static_cast<_Float16>(yb));
-                }
-                if (fa + 1 < features) {
-                    typedef uint32_t __attribute__((aligned(2))) u32u;
-                    *reinterpret_cast<u32u *>(o) = static_cast<uint32_t>(ha) | (static_cast<uint32_t>(hb) << 16);
-                } else if (fa < features) {
-                    o[0] = ha;
-                }
-            }
+            write_row(km, i0 + (tid & ~63) + src);
         }
     }
 }
@@ -333,8 +459,8 @@ bool split_rows(size_t rows, Split &s) {
 size_t tiles_of(size_t features) { return (features + kFeatures - 1) / kFeatures; }
 size_t inter_bytes(size_t rows, size_t features) { return tiles_of(features) * rows * C * sizeof(f32x2); }
 
-template <int L> constexpr size_t lds_bytes_a(size_t n) { return (2 * L * C + L + kFine + (n / kFine > 0 ? n / kFine : 1)) * sizeof(f32x2); }
-template <int L> constexpr size_t lds_bytes_b() { return (2 * L * C + L) * sizeof(f32x2); }
+template <int L> constexpr size_t lds_bytes_a(int n) { return (2 * L * C + L + kFine + coarse_entries(n)) * sizeof(f32x2); }
+template <int L> constexpr size_t lds_bytes_b(int n) { return (2 * L * C + L + kFine + coarse_entries(n)) * sizeof(f32x2) + (2 * kListCap + 4) * sizeof(int); }
 
 template <typename K> int opt_in(K kern, size_t lds, std::atomic<unsigned long long> &done) {
     if (lds <= 65536) return FEWBIT_OK;
@@ -354,7 +480,7 @@ template <typename K> int opt_in(K kern, size_t lds, std::atomic<unsigned long l
 template <int DT, int N1, int N2>
 int launch(const void *m, size_t features, size_t ld, const int64_t *idx, size_t proj, float scale, void *out, f32x2 *inter, hipStream_t s) {
     static std::atomic<unsigned long long> done_a{0}, done_b{0};
-    constexpr size_t la = lds_bytes_a<N1>(static_cast<size_t>(N1) * N2), lb = lds_bytes_b<N2>();
+    constexpr size_t la = lds_bytes_a<N1>(N1 * N2), lb = lds_bytes_b<N2>(N1 * N2);
     if (const int rc = opt_in(dct_pass_a_kernel<DT, N1, N2>, la, done_a)) return rc;
     if (const int rc = opt_in(dct_pass_b_kernel<DT, N1, N2>, lb, done_b)) return rc;
     const unsigned tiles = static_cast<unsigned>(tiles_of(features));

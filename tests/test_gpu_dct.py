@@ -111,5 +111,3 @@ def test_the_dct_layer_on_the_kernel_equals_the_layer_on_torch_fft(dtype):
     gw_n, gw_t = grads[True][3], grads[False][3]
     rel = float((gw_n - gw_t).abs().max() / gw_t.abs().max())
     assert rel <= (2e-5 if dtype == torch.float32 else 3e-2), rel          # bf16: both paths round the sampled rows to 8 bits, at different points
-    exact = gy.reshape(-1, 24).float().T @ x.reshape(-1, 40).float()
-    assert float(torch.linalg.norm(gw_n - exact) / torch.linalg.norm(exact)) < 1.5    # an estimate of the right thing (one draw, ratio 0.25)
