@@ -76,9 +76,11 @@ done
 # the ratio the reference quotes (0.2: p = 3276 of 16384 rows), both layer widths of RoBERTa-base, both sketches: >= 200 settled
 # dispatches each (writes gpurun_out/profiles_$R/${R}_sketch_rocprof_*_p3276_bf16.txt itself)
 bash tools/profile_sketch.sh $R > "$RAW/profile_sketch.log" 2>&1
+# the sampled cosine transform (fewbit_hip_sampled_dct) at the same shapes: settled kernel durations and PMC traffic
+bash tools/profile_dct.sh $R > "$RAW/profile_dct.log" 2>&1
 # the randomized RoBERTa step with the arms interleaved in ONE process (S from memory / fused / fp32 partial sums / Rademacher),
 # where its GPU time goes by kernel class, and the counters behind the in-situ forward
-for dt in fp32 bf16; do timeout 900 python3 scratch/roberta_ab.py $dt 3 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_roberta_ab_$dt.txt"; done
+for dt in fp32 bf16; do timeout 900 python3 tools/roberta_ab.py $dt 3 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_roberta_ab_$dt.txt"; done
 bash tools/profile_insitu_sketch.sh $R > "$RAW/insitu_sketch.log" 2>&1 && cp gpurun_out/${R}_roberta_randomized_insitu.json "$OUT/"
 [ -x scratch/bin/gen_bench ] && scratch/bin/gen_bench > "$OUT/${R}_gen_bench.txt" 2>&1
 python3 scratch/timeline.py 0.0 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_clock_transient_timeline.txt"

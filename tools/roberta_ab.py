@@ -1,7 +1,7 @@
 """RoBERTa-base, every encoder Linear randomized (ratio 0.2): ONE process, the arms interleaved round by round on the same
 box -- vanilla model | Gaussian sketch by the library's policy | with S written to memory once (tune_materialise 1) | generated
-inside the product kernel (0) | the same with fp32 partial sums (round 4's data path) | Rademacher.  Step time per arm.
-   python scratch/roberta_ab.py fp32|bf16 [rounds]"""
+inside the product kernel (0) | the same with fp32 partial sums (round 4's data path) | Rademacher | the sampled DCT.  Step time per arm.
+   python tools/roberta_ab.py fp32|bf16 [rounds]"""
 import os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import torch
@@ -53,6 +53,7 @@ arms = {'vanilla': lambda: steps(vanilla),
         'gaussian, fused (forced)': lambda: arm('gaussian', 0, -1),
         'gaussian, fused, fp32 partial sums (round 4\'s data path)': lambda: arm('gaussian', 0, 0),
         'rademacher': lambda: arm('rademacher', -1, -1),
+        "dct (the reference's sampled transform on the kernel pair fewbit_hip_sampled_dct)": lambda: arm('dct', -1, -1),
         'rademacher, fp32 partial sums (round 4\'s data path)': lambda: arm('rademacher', -1, 0)}
 res = {k: [] for k in arms}
 for r in range(rounds):

@@ -163,7 +163,7 @@ def main():
             r['step_time_ratio'] = round(r['ms_per_step'] / rows[0]['ms_per_step'], 3)
         print(json.dumps({'config': f'RoBERTa-base (random init) batch {args.batch} x seq {args.seq}, {args.dtype}, '
                                     f'fwd+bwd+SGD step; randomized linear proj_dim_ratio={args.linear_ratio}'
-                                    + f', {args.matmul} sketch, ' + (fewbit_amd.linear.sampled_transform_path(args.matmul, torch.empty(0, device=dev, dtype=dtype)) if args.matmul in ('dct', 'dft') else
+                                    + f', {args.matmul} sketch, ' + (fewbit_amd.linear.sampled_transform_path(args.matmul, torch.empty(args.batch * args.seq, 8, device=dev, dtype=dtype)) if args.matmul in ('dct', 'dft') else
                                                                      'torch.randn/randint + torch.matmul' if args.torch_sketch else 'gfx950 sketch kernels (fewbit_hip_sketch)')
                                     + (', sketch GEMMs in bf16' if args.sketch_bf16 else ''),
                           'rows': rows}))
