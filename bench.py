@@ -422,7 +422,7 @@ def measure_sketch(device):
                                     device, rows, features, 3276, dt, out['ratio_0.2'][f'16384x{features}']['rademacher']['us'] if dt == torch.bfloat16 else
                                     out['ratio_0.2'][f'16384x{features}'].get('fp32_input', {}).get('rademacher', {}).get('us')))
                                 for features in (768, 3072) for name, dt in (('bf16', torch.bfloat16), ('fp32', torch.float32))}
-    out['evidence'] = 'profiles/r06_sketch_bench.json, profiles/r06_sketch_rocprof_*_p3276_bf16.txt (tools/profile_sketch.sh), DESIGN.md section 5'
+    out['evidence'] = 'profiles/r06_sketch_bench.json, profiles/r06_sketch_rocprof_*_p3276_bf16.txt (tools/profile_sketch.sh), DESIGN.md section 7.3'
     return out
 
 

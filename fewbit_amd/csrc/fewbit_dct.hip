@@ -22,19 +22,24 @@
 //      two classes in LDS, scans idx for the samples that fall into them and writes just those rows of the result.
 //
 // ---- tiling ------------------------------------------------------------------------------------------------------------------
-//   tile        2 rows-of-transforms x L points x 32 complex columns (64 features) of fp32 complex = 64 KiB of LDS at L = 128, two
-//               workgroups of 512 threads per CU.  Lanes run along the columns: every LDS access of a half-wave is 256 contiguous
-//               bytes (all 64 banks once, ds_read/write_b64: conflict-free), every twiddle is half-wave-uniform (an LDS broadcast).
+//   tile        L points x 32 complex fp32 entries = 32 KiB of LDS at L = 128 (+ 3-7 KiB of tables): FOUR 256-thread workgroups per CU.
+//               Lanes run along the 32 entries of a point: every LDS access of a half-wave is 256 contiguous bytes (all 64 banks once,
+//               ds_read/write_b64: conflict-free), every twiddle is half-wave-uniform (an LDS broadcast).
 //   FFT         in place, decimation in frequency, TWO stages at L = 128 (radix 16 then radix 8, each butterfly entirely in the
 //               registers of one thread; 64 = 8 x 8, 32 = 8 x 4, 16 = 16), one barrier per stage; the result stands in digit-reversed
 //               positions (pos_to_freq / freq_to_pos), which costs nothing: both passes address their outputs through the map.
-//   pass A      workgroup (b, t): n2 in {2b, 2b+1}, column tile t.  Loads 2 N1 row segments of 64 features (128 B of bf16: full cache
-//               lines, 16 B per lane), converts to fp32, transforms along n1, multiplies by W_N^{n2 k1} (two table lookups and one
-//               complex multiply) and writes the intermediate as [tile][k1][n2][32 columns]: 512 contiguous bytes per k1.
-//   pass B      workgroup (u, t): residues k1 = u and N1 - u.  Reads two contiguous N2 x 256 B blocks (and, in the same breath, its share
-//               of idx), transforms along n2, collects the samples of its two residue classes in an LDS list and serves them 16 at a
-//               time (one per half-wave, lanes along the columns; e^{-i pi k / 2N} from two small tables, no transcendental per sample).
+//   pass A      workgroup (b, t): the rows n = N2 n1 + b of column tile t (32 complex columns = 64 features).  Loads N1 row segments
+//               (128 B of bf16: full cache lines, 16 B per lane, issued back to back), converts to fp32, transforms along n1,
+//               multiplies by W_N^{n2 k1} (two table lookups, one complex multiply) and writes the intermediate per HALF tile,
+//               [half tile][k1][n2][16 columns]: 128 contiguous bytes per (k1, half).
+//   pass B      workgroup (u, t): residues k1 = u and N1 - u of half tile t (16 complex columns).  Its 32 entries per point are the two
+//               residue rows side by side, so one butterfly serves both.  Reads two contiguous N2 x 128 B blocks -- its share of idx is
+//               requested first, unconditionally, so that testing it never waits --, transforms along n2, collects the samples of its
+//               two residue classes in an LDS list (one atomic per thread) and serves them 16 at a time (one per group of 16 lanes;
+//               e^{-i pi k / 2N} from two small tables, no transcendental per sample).
 //   traffic     M once + 2 x rows x features x 4 B of intermediate + the p sampled rows: 16384 x 768 bf16, p = 3276: 25 + 2 x 50 + 5 MB.
+// Measured and not kept (round 6, profiles/r06_dct_variants.txt): 64 KiB tiles with 512-thread workgroups (same time); persistent
+// workgroups that request the next tile before transforming the current one (the radix-16 butterfly leaves no registers for it: spills).
 // Roofline class: HBM / Infinity Cache bandwidth (5 N log2 N flops per column: 0.9 GFLOP for 16384 x 768).
 #include <hip/hip_runtime.h>
 
@@ -54,10 +59,12 @@ FEWBIT_HIDDEN int fail(int code, const char *fmt, ...) __attribute__((format(pri
 
 namespace dct {
 
-constexpr int kThreads = 512;
 constexpr int C = 32;                       // complex columns of a tile = 64 features
 constexpr int kFeatures = 2 * C;
-constexpr int kSlots = kThreads / C;        // butterflies of one column in flight per stage pass
+// Both passes: a 32 KiB tile + tables per 256-thread workgroup, four workgroups per CU, each in its own phase (loading, transforming,
+// storing): pass A one row of transforms x 32 complex columns; pass B the two rows of a residue pair x 16 complex columns
+constexpr int kThreadsA = 256, kRowsA = 1;
+constexpr int kThreadsB = 256, CB = C / 2;  // pass B: 16 complex columns x the two rows of a residue pair
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -161,15 +168,15 @@ template <int LEN> __host__ __device__ __forceinline__ int freq_to_pos(int k) {
     }
 }
 
-// One stage of the in-place transform of the tile [2][L][C] along its middle axis: blocks of length LEN, radix R, twiddles
-// tw[m] = W_L^m.  Thread (c = tid % 32, slot = tid / 32) takes the butterflies slot, slot + 16, ... of column c of both rows; a
-// butterfly is R loads, the transform in registers, the twiddles W_LEN^{ss q} (none in the last stage) and R stores.
-template <int L, int LEN, int R> __device__ __forceinline__ void stage(f32x2 *tile, const f32x2 *tw, int c, int slot) {
+// One stage of the in-place transform of the tile [TR][L][C] along its middle axis: blocks of length LEN, radix R, twiddles
+// tw[m] = W_L^m.  Thread (c = tid % 32, slot = tid / 32 of SLOTS) takes the butterflies slot, slot + SLOTS, ... of column c of all
+// TR rows; a butterfly is R loads, the transform in registers, the twiddles W_LEN^{ss q} (none in the last stage) and R stores.
+template <int L, int LEN, int R, int TR, int SLOTS> __device__ __forceinline__ void stage(f32x2 *tile, const f32x2 *tw, int c, int slot) {
     constexpr int S = LEN / R, kPerRow = L / R;
 #pragma unroll
-    for (int bid0 = 0; bid0 < 2 * kPerRow; bid0 += kSlots) {
+    for (int bid0 = 0; bid0 < TR * kPerRow; bid0 += SLOTS) {
         const int bid = bid0 + slot;
-        if (2 * kPerRow % kSlots != 0 && bid >= 2 * kPerRow) break;
+        if (TR * kPerRow % SLOTS != 0 && bid >= TR * kPerRow) break;
         const int row = bid / kPerRow, b = bid % kPerRow, block = b / S, ss = b % S;
         f32x2 *p = tile + (row * L + block * LEN + ss) * C + c;
         f32x2 x[R];
@@ -186,11 +193,11 @@ template <int L, int LEN, int R> __device__ __forceinline__ void stage(f32x2 *ti
     __syncthreads();
 }
 
-template <int L, int LEN = L> __device__ __forceinline__ void fft_tile(f32x2 *tile, const f32x2 *tw, int c, int slot) {
+template <int L, int TR, int SLOTS, int LEN = L> __device__ __forceinline__ void fft_tile(f32x2 *tile, const f32x2 *tw, int c, int slot) {
     if constexpr (LEN > 1) {
         constexpr int R = first_radix(LEN);
-        stage<L, LEN, R>(tile, tw, c, slot);
-        fft_tile<L, LEN / R>(tile, tw, c, slot);
+        stage<L, LEN, R, TR, SLOTS>(tile, tw, c, slot);
+        fft_tile<L, TR, SLOTS, LEN / R>(tile, tw, c, slot);
     }
 }
 
@@ -256,29 +263,30 @@ __device__ __forceinline__ f32x2 table_unit(const f32x2 *fine, const f32x2 *coar
 }
 
 // ---- pass A -----------------------------------------------------------------------------------------------------------------
-// grid (N2 / 2, column tiles).  inter: [tile][k1][n2][C] complex fp32.
+// grid (N2, column tiles): workgroup (b, t) transforms the rows n = N2 n1 + b of column tile t.  inter: [half tile][k1][n2][16] complex fp32.
 template <int DT, int N1, int N2>
-__global__ __launch_bounds__(kThreads, 4) void dct_pass_a_kernel(const void *__restrict__ x, size_t features, size_t ld, f32x2 *__restrict__ inter) {
-    constexpr int N = N1 * N2, kCoarse = coarse_entries(N);
+__global__ __launch_bounds__(kThreadsA, 4) void dct_pass_a_kernel(const void *__restrict__ x, size_t features, size_t ld, f32x2 *__restrict__ inter) {
+    constexpr int N = N1 * N2, kCoarse = coarse_entries(N), kThreads = kThreadsA, kSlots = kThreads / C;
+    static_assert(kRowsA == 1, "one n2 per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    f32x2 *tile = reinterpret_cast<f32x2 *>(lds_raw);                 // [2][N1][C]
-    f32x2 *tw = tile + 2 * N1 * C;                                    // W_N1^m, m < N1
+    f32x2 *tile = reinterpret_cast<f32x2 *>(lds_raw);                 // [N1][C]
+    f32x2 *tw = tile + N1 * C;                                        // W_N1^m, m < N1
     f32x2 *fine = tw + N1, *coarse = fine + kFine;                    // W_N^m (m < 128), W_N^{128 m}
     const int tid = threadIdx.x, c = tid % C, slot = tid / C;
     const int b = blockIdx.x;
     const size_t t = blockIdx.y, f0 = t * kFeatures;
 
-    // ---- loads first (all in flight), tables while they travel
-    constexpr int PF = In<DT>::kPieceFeatures, PPS = In<DT>::kPiecesPerSegment, kTotal = 2 * N1 * PPS, kPieces = (kTotal + kThreads - 1) / kThreads;
+    // ---- loads first (all in flight), tables while they travel, then registers -> LDS
+    constexpr int PF = In<DT>::kPieceFeatures, PPS = In<DT>::kPiecesPerSegment, kTotal = N1 * PPS, kPieces = (kTotal + kThreads - 1) / kThreads;
     // (one body per case, FULL tile or edge tile, each with its own registers from the loads to the LDS writes: were the two
     // cases to meet in one set of registers in between, the copies at the join would wait for the loads right behind their issue)
     auto fill_tile = [&](auto full) __attribute__((always_inline)) {
         u32x4 raw[kPieces];
 #pragma unroll
         for (int i = 0; i < kPieces; ++i) {
-            const int pid = tid + kThreads * i, seg = pid / PPS, piece = pid % PPS, n1 = seg >> 1, r = seg & 1;
+            const int pid = tid + kThreads * i, n1 = pid / PPS, piece = pid % PPS;
             if (kTotal % kThreads != 0 && pid >= kTotal) break;
-            const int n = N2 * n1 + 2 * b + r;                          // index into the reordered sequence v
+            const int n = N2 * n1 + b;                                  // index into the reordered sequence v
             const size_t row = n < N / 2 ? 2 * static_cast<size_t>(n) : 2 * static_cast<size_t>(N - 1 - n) + 1;
             raw[i] = load_piece<DT, decltype(full)::value>(x, row, ld, f0, piece, features);
         }
@@ -287,11 +295,11 @@ __global__ __launch_bounds__(kThreads, 4) void dct_pass_a_kernel(const void *__r
         for (int m = tid; m < kCoarse; m += kThreads) coarse[m] = unit(m * kFine, N);
 #pragma unroll
         for (int i = 0; i < kPieces; ++i) {
-            const int pid = tid + kThreads * i, seg = pid / PPS, piece = pid % PPS, n1 = seg >> 1, r = seg & 1;
+            const int pid = tid + kThreads * i, n1 = pid / PPS, piece = pid % PPS;
             if (kTotal % kThreads != 0 && pid >= kTotal) break;
             float v[PF];
             unpack_piece<DT>(raw[i], v);
-            f32x4 *dst = reinterpret_cast<f32x4 *>(tile + (r * N1 + n1) * C + piece * (PF / 2));
+            f32x4 *dst = reinterpret_cast<f32x4 *>(tile + n1 * C + piece * (PF / 2));
 #pragma unroll
             for (int e = 0; e < PF / 4; ++e) dst[e] = f32x4{v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]};
         }
@@ -300,40 +308,43 @@ __global__ __launch_bounds__(kThreads, 4) void dct_pass_a_kernel(const void *__r
     else fill_tile(std::false_type{});
     __syncthreads();
 
-    fft_tile<N1>(tile, tw, c, slot);
+    fft_tile<N1, kRowsA, kSlots>(tile, tw, c, slot);
 
-    // ---- twiddle + store: unit = two complex columns (16 B) of one (P, r); 32 consecutive lanes = the 512 contiguous bytes of one k1
-    constexpr int kUnitsTotal = 2 * N1 * (C / 2), kUnits = (kUnitsTotal + kThreads - 1) / kThreads;
+    // ---- twiddle + store: unit = two complex columns (16 B) of one position P; 16 consecutive lanes = the 256 contiguous bytes of one k1
+    constexpr int kUnitsTotal = N1 * (C / 2), kUnits = (kUnitsTotal + kThreads - 1) / kThreads;
 #pragma unroll
     for (int i = 0; i < kUnits; ++i) {
-        const int uid = tid + kThreads * i, c2 = uid % (C / 2), r = (uid / (C / 2)) & 1, p = uid / C;
+        const int uid = tid + kThreads * i, c2 = uid % (C / 2), p = uid / (C / 2);
         if (kUnitsTotal % kThreads != 0 && uid >= kUnitsTotal) break;
-        const int k1 = pos_to_freq<N1>(p), e = (2 * b + r) * k1;
+        const int k1 = pos_to_freq<N1>(p), e = b * k1;
         const f32x2 w = table_unit(fine, coarse, e, kCoarse > 1);
-        const f32x4 z = *reinterpret_cast<const f32x4 *>(tile + (r * N1 + p) * C + 2 * c2);
+        const f32x4 z = *reinterpret_cast<const f32x4 *>(tile + p * C + 2 * c2);
         const f32x2 a = cmul(f32x2{z[0], z[1]}, w), bb = cmul(f32x2{z[2], z[3]}, w);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(inter + ((t * N1 + k1) * N2 + 2 * b + r) * C + 2 * c2);
+        // (the intermediate is kept per HALF tile of 16 complex columns -- what one pass-B workgroup reads: 128 contiguous bytes here)
+        f32x4 *dst = reinterpret_cast<f32x4 *>(inter + (((2 * t + c2 / (CB / 2)) * N1 + k1) * N2 + b) * CB + 2 * (c2 % (CB / 2)));
         *dst = f32x4{a.x, a.y, bb.x, bb.y};
     }
 }
 
 // ---- pass B -----------------------------------------------------------------------------------------------------------------
-// grid (N1 / 2 + 1, column tiles): residues k1 = u and (N1 - u) % N1.
-constexpr int kListCap = 1024;              // samples a workgroup serves from its LDS list (more: the wave-by-wave fallback)
-constexpr int kAhead = 8;                   // idx entries per thread requested together with the tile: all of idx for p <= 4096
+// grid (N1 / 2 + 1, half tiles of 16 complex columns): residues k1 = u and (N1 - u) % N1.  The LDS tile is [N2][2][16]: the two
+// residue rows sit side by side, so that a half-wave still touches 256 contiguous bytes per position and one butterfly serves
+// both rows -- to the transform it is one row of 32 columns.
+constexpr int kListCap = 512;               // samples a workgroup serves from its LDS list (more: the group-by-group fallback)
+constexpr int kAhead = 16;                  // idx entries per thread requested together with the tile: all of idx for p <= 4096
 
 template <int DT, int N1, int N2>
-__global__ __launch_bounds__(kThreads, 4) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, const int64_t *__restrict__ idx, size_t proj, size_t features,
+__global__ __launch_bounds__(kThreadsB, 4) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, const int64_t *__restrict__ idx, size_t proj, size_t features,
                                                                   float scale, void *__restrict__ out) {
-    constexpr int N = N1 * N2, kCoarse = coarse_entries(N);
+    constexpr int N = N1 * N2, kCoarse = coarse_entries(N), kThreads = kThreadsB, kSlots = kThreads / C, kGroups = kThreads / CB;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    f32x2 *tile = reinterpret_cast<f32x2 *>(lds_raw);                 // [2][N2][C]
-    f32x2 *tw = tile + 2 * N2 * C;                                    // W_N2^m
+    f32x2 *tile = reinterpret_cast<f32x2 *>(lds_raw);                 // [N2][2][CB]
+    f32x2 *tw = tile + N2 * 2 * CB;                                   // W_N2^m
     f32x2 *fine = tw + N2, *coarse = fine + kFine;                    // W_4N^m (m < 128), W_4N^{128 m}: e^{-i pi k / 2N} = W_4N^k
     int *list_k = reinterpret_cast<int *>(coarse + kCoarse), *list_j = list_k + kListCap, *count = list_j + kListCap;
-    const int tid = threadIdx.x, c = tid % C, slot = tid / C, lane = tid & 63, half = lane >> 5;
+    const int tid = threadIdx.x, c = tid % CB, group = tid / CB;
     const int u = blockIdx.x, k1a = u, k1b = (N1 - u) % N1;
-    const size_t t = blockIdx.y, f0 = t * kFeatures;
+    const size_t t = blockIdx.y, f0 = t * (2 * CB);
 
     // the row numbers this thread will test go out FIRST (vmcnt counts in order: looking at them later does not wait for the tile).
     // Unconditional loads -- the index is clamped, the verdict is a select -- so that hipcc issues them back to back instead of one
@@ -343,13 +354,13 @@ __global__ __launch_bounds__(kThreads, 4) void dct_pass_b_kernel(const f32x2 *__
     int kraw[kAhead];
 #pragma unroll
     for (int a = 0; a < kAhead; ++a) kraw[a] = raw(static_cast<size_t>(a) * kThreads + tid);
-    constexpr int kTotal = 2 * N2 * (C / 2), kPieces = (kTotal + kThreads - 1) / kThreads;       // 16-byte pieces (two complex)
+    constexpr int kPerRow = N2 * (CB / 2), kTotal = 2 * kPerRow, kPieces = (kTotal + kThreads - 1) / kThreads;     // 16-byte pieces (two complex)
     f32x4 v[kPieces];
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
-        const int pid = tid + kThreads * i, r = pid / (N2 * (C / 2)), rest = pid % (N2 * (C / 2));
+        const int pid = tid + kThreads * i, r = pid / kPerRow, rest = pid % kPerRow;
         if (kTotal % kThreads != 0 && pid >= kTotal) break;
-        const f32x2 *src = inter + (t * N1 + (r == 0 ? k1a : k1b)) * static_cast<size_t>(N2) * C;
+        const f32x2 *src = inter + (t * N1 + (r == 0 ? k1a : k1b)) * static_cast<size_t>(N2) * CB;
         v[i] = reinterpret_cast<const f32x4 *>(src)[rest];
     }
     // a sample belongs to this workgroup when its residue k % N1 is one of the two it holds; -1 = not ours
@@ -363,34 +374,54 @@ __global__ __launch_bounds__(kThreads, 4) void dct_pass_b_kernel(const f32x2 *__
     if (tid == 0) *count = 0;
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
-        if (kTotal % kThreads != 0 && tid + kThreads * i >= kTotal) break;
-        reinterpret_cast<f32x4 *>(tile)[tid + kThreads * i] = v[i];
+        const int pid = tid + kThreads * i, r = pid / kPerRow, rest = pid % kPerRow, n2 = rest / (CB / 2), c2 = rest % (CB / 2);
+        if (kTotal % kThreads != 0 && pid >= kTotal) break;
+        *reinterpret_cast<f32x4 *>(tile + (n2 * 2 + r) * CB + 2 * c2) = v[i];
     }
     __syncthreads();
-    // the workgroup's samples -> LDS list (order does not matter: every sample writes its own row of the result)
-    auto enlist = [&](int k, size_t j) {
+    // the workgroup's samples -> LDS list (order does not matter: every sample writes its own row of the result).  A thread first
+    // counts its own matches among the prefetched entries and reserves their places with ONE atomic (not one per entry: sixteen
+    // divergent branches each waiting for its returned value cost 1.9 us of a 18.7 us launch)
+    int verdict[kAhead], mine_count = 0;
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) {
+        verdict[a] = mine(kraw[a], static_cast<size_t>(a) * kThreads + tid);
+        mine_count += verdict[a] >= 0 ? 1 : 0;
+    }
+    if (mine_count > 0) {
+        int pos = atomicAdd(count, mine_count);
+#pragma unroll
+        for (int a = 0; a < kAhead; ++a) {
+            if (verdict[a] >= 0) {
+                if (pos < kListCap) {
+                    list_k[pos] = verdict[a];
+                    list_j[pos] = a * kThreads + tid;
+                }
+                ++pos;
+            }
+        }
+    }
+    for (size_t i0 = static_cast<size_t>(kAhead) * kThreads; i0 < proj; i0 += kThreads) {
+        const int k = mine(raw(i0 + tid), i0 + tid);
         if (k >= 0) {
             const int pos = atomicAdd(count, 1);
             if (pos < kListCap) {
                 list_k[pos] = k;
-                list_j[pos] = static_cast<int>(j);
+                list_j[pos] = static_cast<int>(i0 + tid);
             }
         }
-    };
-#pragma unroll
-    for (int a = 0; a < kAhead; ++a) enlist(mine(kraw[a], static_cast<size_t>(a) * kThreads + tid), static_cast<size_t>(a) * kThreads + tid);
-    for (size_t i0 = static_cast<size_t>(kAhead) * kThreads; i0 < proj; i0 += kThreads) enlist(mine(raw(i0 + tid), i0 + tid), i0 + tid);
+    }
 
-    fft_tile<N2>(tile, tw, c, slot);                                   // (ends with a barrier: the list is complete behind it)
+    fft_tile<N2, 1, kSlots>(tile, tw, tid % C, tid / C);               // (ends with a barrier: the list is complete behind it)
 
-    // ---- the sampled rows of this workgroup's two residue classes: one per half-wave at a time, lanes along the 32 complex columns
+    // ---- the sampled rows of this workgroup's two residue classes: one per group of 16 lanes at a time, lanes along the columns
     const float base = scale * __builtin_sqrtf(0.5f / static_cast<float>(N));          // ortho: sqrt(1 / 2N) (k > 0), sqrt(1 / 4N) (k = 0)
     auto write_row = [&](int km, size_t j) __attribute__((always_inline)) {
         const int k1 = km % N1, k2 = km / N1;
         const int r = k1 == k1a ? 0 : 1;
         const int k2m = k1 == 0 ? (N2 - k2) % N2 : N2 - 1 - k2;         // N - k = (N1 - k1) + N1 k2m
-        const f32x2 zk = tile[(r * N2 + freq_to_pos<N2>(k2)) * C + c];
-        f32x2 zm = tile[((1 - r) * N2 + freq_to_pos<N2>(k2m)) * C + c];
+        const f32x2 zk = tile[(freq_to_pos<N2>(k2) * 2 + r) * CB + c];
+        f32x2 zm = tile[(freq_to_pos<N2>(k2m) * 2 + (1 - r)) * CB + c];
         zm.y = -zm.y;                                                   // conj Z[N - k]
         const f32x2 va = (zk + zm) * 0.5f, d = (zk - zm) * 0.5f, vb = mul_mi(d);
         const f32x2 w = table_unit(fine, coarse, km, kCoarse > 1);      // e^{-i pi k / 2N}
@@ -421,27 +452,14 @@ __global__ __launch_bounds__(kThreads, 4) void dct_pass_b_kernel(const f32x2 *__
     };
     const int total = *count;                                          // block-uniform
     if (total <= kListCap) {
-        for (int e = slot; e < total; e += kSlots) write_row(list_k[e], static_cast<size_t>(list_j[e]));
+        for (int e = group; e < total; e += kGroups) write_row(list_k[e], static_cast<size_t>(list_j[e]));
         return;
     }
-    // more samples in these two classes than the list holds (p in the tens of thousands, or a skewed idx): every wave walks idx
-    // itself and serves its matches two at a time
-    for (size_t i0 = 0; i0 < proj; i0 += kThreads) {
-        const int k = mine(raw(i0 + tid), i0 + tid);
-        unsigned long long mask = __ballot(k >= 0);
-        while (mask != 0) {                                             // wave-uniform
-            const int l0 = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            int l1 = l0;
-            if (mask != 0) {
-                l1 = __builtin_ctzll(mask);
-                mask &= mask - 1;
-            }
-            const int src = half ? l1 : l0;
-            const int km = __shfl(k, src);                              // (every lane takes part in the exchange, then an odd match out idles the upper half)
-            if (half == 1 && l1 == l0) continue;
-            write_row(km, i0 + (tid & ~63) + src);
-        }
+    // more samples in these two classes than the list holds (p in the tens of thousands, or a skewed idx): every group of 16 lanes
+    // walks its share of idx by itself (all 16 lanes read the same word) and writes the rows that belong here
+    for (size_t i = group; i < proj; i += kGroups) {
+        const int k = mine(raw(i), i);
+        if (k >= 0) write_row(k, i);
     }
 }
 
@@ -459,8 +477,8 @@ bool split_rows(size_t rows, Split &s) {
 size_t tiles_of(size_t features) { return (features + kFeatures - 1) / kFeatures; }
 size_t inter_bytes(size_t rows, size_t features) { return tiles_of(features) * rows * C * sizeof(f32x2); }
 
-template <int L> constexpr size_t lds_bytes_a(int n) { return (2 * L * C + L + kFine + coarse_entries(n)) * sizeof(f32x2); }
-template <int L> constexpr size_t lds_bytes_b(int n) { return (2 * L * C + L + kFine + coarse_entries(n)) * sizeof(f32x2) + (2 * kListCap + 4) * sizeof(int); }
+template <int L> constexpr size_t lds_bytes_a(int n) { return (kRowsA * L * C + L + kFine + coarse_entries(n)) * sizeof(f32x2); }
+template <int L> constexpr size_t lds_bytes_b(int n) { return (2 * L * CB + L + kFine + coarse_entries(n)) * sizeof(f32x2) + (2 * kListCap + 4) * sizeof(int); }
 
 template <typename K> int opt_in(K kern, size_t lds, std::atomic<unsigned long long> &done) {
     if (lds <= 65536) return FEWBIT_OK;
@@ -484,8 +502,9 @@ int launch(const void *m, size_t features, size_t ld, const int64_t *idx, size_t
     if (const int rc = opt_in(dct_pass_a_kernel<DT, N1, N2>, la, done_a)) return rc;
     if (const int rc = opt_in(dct_pass_b_kernel<DT, N1, N2>, lb, done_b)) return rc;
     const unsigned tiles = static_cast<unsigned>(tiles_of(features));
-    hipLaunchKernelGGL((dct_pass_a_kernel<DT, N1, N2>), dim3(N2 / 2, tiles), dim3(kThreads), la, s, m, features, ld, inter);
-    hipLaunchKernelGGL((dct_pass_b_kernel<DT, N1, N2>), dim3(N1 / 2 + 1, tiles), dim3(kThreads), lb, s, inter, idx, proj, features, scale, out);
+    hipLaunchKernelGGL((dct_pass_a_kernel<DT, N1, N2>), dim3(N2, tiles), dim3(kThreadsA), la, s, m, features, ld, inter);
+    const unsigned half_tiles = static_cast<unsigned>((features + 2 * CB - 1) / (2 * CB));
+    hipLaunchKernelGGL((dct_pass_b_kernel<DT, N1, N2>), dim3(N1 / 2 + 1, half_tiles), dim3(kThreadsB), lb, s, inter, idx, proj, features, scale, out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sampled_dct: %s", hipGetErrorString(e));
     return FEWBIT_OK;

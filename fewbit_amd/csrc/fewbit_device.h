@@ -327,7 +327,7 @@ __device__ __forceinline__ void store_state_wide(uint8_t *state, size_t g, int n
         return;
     }
     // as few store instructions as the width allows (any address is fine on gfx950): 4 -> dword, 5 -> dword + byte,
-    // 6 -> dword + short, 7 -> dword + short + byte, 8 -> one 8-byte store (bf16 8-bit forward 20.7 -> see DESIGN.md)
+    // 6 -> dword + short, 7 -> dword + short + byte, 8 -> one 8-byte store (EXPERIMENTS.md section 3)
     if (nbits == 8) {
         store_as<false, 1>(p, w);
         return;
@@ -343,7 +343,7 @@ __device__ __forceinline__ void store_state_wide(uint8_t *state, size_t g, int n
 }
 
 // ------------------------------------------------------------------ activation math (fp32)
-// Two accuracy classes, chosen by the I/O dtype (see DESIGN.md "forward values"):
+// Two accuracy classes, chosen by the I/O dtype ("Activation math"; tolerances: section 6):
 //   precise : fp32 I/O.  GELU as ATen's x*0.5*(1+erf(x*sqrt(1/2))) with erf_precise (~1 ulp); ocml for the rest.
 //   fast    : fp16/bf16 I/O, where the result is rounded to 11/8 significant bits anyway.
 //             Branch-free, built from the cheap VALU class (v_fma/v_mul/v_add) plus the hardware

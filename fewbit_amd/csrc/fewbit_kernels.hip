@@ -136,7 +136,7 @@ __device__ __forceinline__ void pipeline2(const Span &s, Init &&init, Load &&loa
     // head: BOTH buffers are requested before init() (table build / LDS staging + barrier), so that the memory system
     // has two tiles per wave in flight while the block sets itself up (pattern-table forward 12.0 -> 11.2 us at
     // 4096x4096 bf16; bucketing the first tile by register search ahead of the barrier, or building the table with one
-    // barrier, did not help: DESIGN.md section 6).  Prefetches are unconditional (redirected to `hot` past the end, the data
+    // barrier, did not help: EXPERIMENTS.md section 6).  Prefetches are unconditional (redirected to `hot` past the end, the data
     // is then simply dropped): a load issued on only one path would make the s_waitcnt in front of process() count for
     // the shorter path and wait for the prefetch itself.
     size_t t1 = t + s.stride;
@@ -995,7 +995,7 @@ const char *dtype_name(int dt) { return dt == FEWBIT_F32 ? "f32" : dt == FEWBIT_
 // resident waves loop round-robin) or CHUNKED (chunk = T tiles per wave, block-contiguous, as many blocks as that takes).
 struct Shape { unsigned blocks; int chunk; };
 
-// Built-in policy (measured on MI355X, scratch/headvar.py with SIZES=...): the resident shape wins
+// Built-in policy (measured on MI355X, scratch/headvar.py with SIZES=..., EXPERIMENTS.md section 6): the resident shape wins
 // while a wave has only a few tiles (4096x4096 bf16: 11.2 vs 11.6 us), the chunked shape wins once the tensor is many
 // times the resident generation, where statically assigned waves drift apart and the launch waits for the slowest
 // (2^28 bf16 elements: backward 235 -> 197 us, pattern-table forward 224 -> 197 us; RoBERTa-size fp32, 5*10^7 elements:

@@ -80,7 +80,7 @@ constexpr int NT = BN / 32;                 // MFMA column blocks per wave
 //   W = 8, NH = 2 (the Gaussian sketch): 128 x 512 tile -- the eight waves are 4 row groups x 2 column halves, waves (g, 0) and
 //           (g, 1) need the SAME rows of S, so each generates half of the stage's A fragments and hands them to the other
 //           through LDS (16 KiB per stage): every element of S is generated once per 512 columns instead of once per 256, which
-//           halves the generator work per MFMA -- the Gaussian sketch is bound by instruction issue.
+//           halves the generator work per MFMA -- the Gaussian sketch is bound by instruction issue (EXPERIMENTS.md 3.1).
 //           Stages of 64 rows, 2 x 64 KiB (M) + 2 x 16 KiB (A fragments) = all 160 KiB of the CU.
 template <int W, int NH = 1> struct Tile {
     static constexpr int kThreads = 64 * W, RG = W / NH, BM = 32 * RG, BNT = BN * NH, BK = 16 * W / NH, kSteps = BK / 16;

@@ -699,7 +699,7 @@ template <Where W> Tensor tanhshrink(const Tensor &self, const Tensor &b, const 
 // Custom table on the identity.  The reference declares this schema without any kernel (fewbit/fewbit.cc:37,
 // NotImplementedError in fewbit/functional/activations.py:137-139; module fewbit/modules/activations.py:97-134:
 // "parity: whether stepwise function is odd or even under shift transformation; shift: shift of the origin").
-// Semantics defined here, with (sx, sy) = shift and the table (b', l') given on the half line
+// Semantics defined here (EXPERIMENTS.md section 8), with (sx, sy) = shift and the table (b', l') given on the half line
 // t = |x - sx| >= 0, as fewbit/approx.py:92-101 produces it for `parity=True, domain=(0, x_max)`:
 //   even  g(sx+t) = g(sx-t):            code = #{b' < |x - sx|}, level = l'[code]   -- folded inside the kernel, so
 //                                        k bits address 2^k half-line levels (twice the resolution of a plain table)

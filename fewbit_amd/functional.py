@@ -4,7 +4,7 @@ Mirror of the reference's functional layer (fewbit/functional/activations.py): t
 keyword interface (``bits`` xor ``borders``+``values``, default 3 bits), the same error types, and the same
 dispatch rule -- a GPU tensor goes to ``torch.ops.fewbit.<name>`` (the gfx950 kernels, in place on the input like
 the reference op), a host tensor to a plain-PyTorch autograd Function with unpacked codes.  What differs is
-listed in DESIGN.md ("defects not reproduced"): the host path computes the right forward, the 1-bit family works
+listed in DESIGN.md section 6 ("defects that are not reproduced"): the host path computes the right forward, the 1-bit family works
 on host tensors, modules may pass ``bits=`` to 1-bit functions, and a missing native library is an error for
 GPU tensors instead of a silent Python fallback.
 """

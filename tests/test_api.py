@@ -88,6 +88,21 @@ def test_tune_is_the_single_hook_and_validates_its_keys():
         cabi.tune(sketch_materialise=-1)
 
 
+def test_every_file_under_profiles_is_indexed():
+    """profiles/README.md is a generated table (file -> one line -> the DESIGN / EXPERIMENTS section that quotes it); a file without a row fails"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(ROOT / 'tools' / 'profiles_index.py'), '--check'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_design_document_stays_a_design():
+    """at most 400 lines of at most 160 characters (the experiment log lives in EXPERIMENTS.md)"""
+    lines = (ROOT / 'DESIGN.md').read_text().split('\n')
+    assert len(lines) <= 400, len(lines)
+    assert not [i + 1 for i, l in enumerate(lines) if len(l.encode()) > 160]
+
+
 def test_operator_schemas_match_reference():
     # fewbit/fewbit.cc:10-37
     want = {

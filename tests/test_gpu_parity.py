@@ -735,7 +735,7 @@ def test_describe_names_the_kernel_the_dispatch_takes():
     assert cabi.describe_forward('gelu', torch.float32, n2, 7)['kernel'].startswith('quantize_forward_kernel<gelu, f32')
     assert cabi.describe_forward('silu', torch.float16, n2, 200)['kernel'].startswith('quantize_forward_lut_wide_kernel')
     b2, b4 = cabi.describe_backward(torch.bfloat16, n2, 8), cabi.describe_backward(torch.bfloat16, n4, 8)
-    assert b2['u'] == 2 and b2['chunk'] == 0 and b4['u'] == 1 and b4['chunk'] == 1      # the measured policy, DESIGN.md section 3
+    assert b2['u'] == 2 and b2['chunk'] == 0 and b4['u'] == 1 and b4['chunk'] == 1      # the measured policy, DESIGN.md section 3.1
     assert cabi.describe_stepwise1_forward('relu', torch.float32, 1 << 20)['kernel'].startswith('stepwise1_forward_kernel<relu, f32')
 
 

@@ -34,7 +34,7 @@ def test_philox_known_answers_library_and_model():
 
 def test_model_round_loop_against_the_seven_round_vectors_too():
     """Random123 kat_vectors, philox4x32 with 7 rounds: a second published fixed point for the model's round function and key
-    schedule (the kernels use 10 rounds; DESIGN.md 3.1 records the 7-round experiment)"""
+    schedule (the kernels use 10 rounds; EXPERIMENTS.md 3.1 records the 7-round experiment)"""
     for ctr, key, want in (((0, 0, 0, 0), (0, 0), (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
                            ((0xffffffff, ) * 4, (0xffffffff, ) * 2, (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
                            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a))):
@@ -123,7 +123,7 @@ def _plan(dist, dtype, rows, features, proj):
 
 
 def test_data_path_policy_of_the_sketch_without_a_gpu():
-    """which of the data paths a call takes (DESIGN.md 3.1): Gaussian S from memory for 16-bit input wider than one tile and for fp32
+    """which of the data paths a call takes (DESIGN.md section 4): Gaussian S from memory for 16-bit input wider than one tile and for fp32
     input of 2048 features or more, the fused kernel for narrower fp32 input (FEWBIT_SKETCH_MATERIALISE=1 overrides) and for
     Rademacher; bf16 partial sums for sliced bf16 operands; the workspace is the sum of its parts"""
     g = _plan('gaussian', torch.bfloat16, 16384, 768, 3276)

@@ -27,7 +27,7 @@ timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$RAW/cfg_trace" -o 
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$RAW/cfg_fetch" -o cfg -- python3 tools/config_runs.py "$RAW/cfg_fetch/phases.json" 30 > /dev/null 2> "$RAW/cfg_fetch.err"
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$RAW/cfg_write" -o cfg -- python3 tools/config_runs.py "$RAW/cfg_write/phases.json" 30 > /dev/null 2> "$RAW/cfg_write.err"
 python3 tools/summarize_profiles.py "$R" "$RAW" "$OUT"
-# 5. the other driver-visible lines and the side measurements DESIGN.md quotes
+# 5. the other driver-visible lines and the side measurements DESIGN.md and EXPERIMENTS.md quote
 python3 bench.py --config c4 --no-cpu-baseline > "$OUT/${R}_bench_line_c4.json" 2>> "$RAW/bench.err"
 python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$OUT/${R}_bench_line_k20.json" 2>> "$RAW/bench.err"
 # N > 1 on the one GPU of this box (ranks SHARE it: validation of the launch paths, not a scaling point): bench.py starting
@@ -79,7 +79,7 @@ bash tools/profile_sketch.sh $R > "$RAW/profile_sketch.log" 2>&1
 # the sampled cosine transform (fewbit_hip_sampled_dct) at the same shapes: settled kernel durations and PMC traffic
 bash tools/profile_dct.sh $R > "$RAW/profile_dct.log" 2>&1
 # the randomized RoBERTa step with the arms interleaved in ONE process (S from memory / fused / fp32 partial sums / Rademacher),
-# where its GPU time goes by kernel class, and the counters behind the in-situ forward
+# where its GPU time goes by kernel class, and the counters behind the in-situ forward (EXPERIMENTS.md 5)
 for dt in fp32 bf16; do timeout 900 python3 tools/roberta_ab.py $dt 3 2>&1 | grep -v amdgpu.ids > "$OUT/${R}_roberta_ab_$dt.txt"; done
 bash tools/profile_insitu_sketch.sh $R > "$RAW/insitu_sketch.log" 2>&1 && cp gpurun_out/${R}_roberta_randomized_insitu.json "$OUT/"
 [ -x scratch/bin/gen_bench ] && scratch/bin/gen_bench > "$OUT/${R}_gen_bench.txt" 2>&1

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""markdown rows of DESIGN.md 5.1's table from tools/sketch_bench.py's JSON:  python tools/sketch_table.py profiles/r05_sketch_bench.json"""
+"""markdown rows of the estimator table (the full sweep: EXPERIMENTS.md 5.1) from tools/sketch_bench.py's JSON:  python tools/sketch_table.py profiles/r06_sketch_bench.json"""
 import json
 import sys
 
