@@ -15,14 +15,15 @@
 //      V = DFT_N(v):  DCT-II(x)[k] = Re(2 e^{-i pi k / 2N} V[k]).
 //   2. Two real columns per complex transform: M is row-major, so features (2c, 2c+1) of a row ARE a complex number in memory;
 //      Z = DFT_N(v_2c + i v_2c+1) gives V_2c[k] = (Z[k] + conj Z[N-k]) / 2 and V_2c+1[k] = (Z[k] - conj Z[N-k]) / 2i.
-//   3. Four-step DFT, N = N1 x N2 (each 16 .. 128; 16384 = 128 x 128), n = N2 n1 + n2, k = k1 + N1 k2:
+//   3. Four-step DFT, N = N1 x N2 (each 16 .. 256; 16384 = 128 x 128, 65536 = 256 x 256), n = N2 n1 + n2, k = k1 + N1 k2:
 //          pass A   for every n2:  A[k1][n2] = W_N^{n2 k1} * sum_{n1} z[N2 n1 + n2] W_N1^{n1 k1}        (length-N1 DFTs over rows N2 apart)
 //          pass B   for every k1:  Z[k1 + N1 k2] = sum_{n2} A[k1][n2] W_N2^{n2 k2}                       (length-N2 DFTs, contiguous)
 //      Pass B never writes Z: the workgroup that owns the residues k1 and N1 - k1 holds Z[k] AND Z[N-k] for every k of those
 //      two classes in LDS, scans idx for the samples that fall into them and writes just those rows of the result.
 //
 // ---- tiling ------------------------------------------------------------------------------------------------------------------
-//   tile        L points x 32 complex fp32 entries = 32 KiB of LDS at L = 128 (+ 3-7 KiB of tables): FOUR 256-thread workgroups per CU.
+//   tile        L points x 32 complex fp32 entries = 32 KiB of LDS at L = 128 (+ 3-7 KiB of tables): FOUR 256-thread workgroups per CU
+//               (L = 256, from 32768 rows on: 64 KiB, two per CU).
 //               Lanes run along the 32 entries of a point: every LDS access of a half-wave is 256 contiguous bytes (all 64 banks once,
 //               ds_read/write_b64: conflict-free), every twiddle is half-wave-uniform (an LDS broadcast).
 //   FFT         in place, decimation in frequency, TWO stages at L = 128 (radix 16 then radix 8, each butterfly entirely in the
@@ -146,7 +147,7 @@ template <int R> __device__ __forceinline__ void dft(f32x2 (&x)[R]) {
     }
 }
 
-// radix of the first stage of a block of length `len`: 128 = 16 x 8, 64 = 8 x 8, 32 = 8 x 4, 16 = 16
+// radix of the first stage of a block of length `len`: 256 = 16 x 16, 128 = 16 x 8, 64 = 8 x 8, 32 = 8 x 4, 16 = 16
 __host__ __device__ constexpr int first_radix(int len) { return len >= 128 ? 16 : len == 64 ? 8 : len == 32 ? 8 : len == 16 ? 16 : len == 8 ? 8 : len == 4 ? 4 : 2; }
 
 // position P (after the in-place DIF stages) -> frequency k.  Stage i with radix r_i on blocks of length L_i leaves digit q_i
@@ -265,7 +266,7 @@ __device__ __forceinline__ f32x2 table_unit(const f32x2 *fine, const f32x2 *coar
 // ---- pass A -----------------------------------------------------------------------------------------------------------------
 // grid (N2, column tiles): workgroup (b, t) transforms the rows n = N2 n1 + b of column tile t.  inter: [half tile][k1][n2][16] complex fp32.
 template <int DT, int N1, int N2>
-__global__ __launch_bounds__(kThreadsA, 4) void dct_pass_a_kernel(const void *__restrict__ x, size_t features, size_t ld, f32x2 *__restrict__ inter) {
+__global__ __launch_bounds__(kThreadsA, (N1 > 128 ? 2 : 4)) void dct_pass_a_kernel(const void *__restrict__ x, size_t features, size_t ld, f32x2 *__restrict__ inter) {
     constexpr int N = N1 * N2, kCoarse = coarse_entries(N), kThreads = kThreadsA, kSlots = kThreads / C;
     static_assert(kRowsA == 1, "one n2 per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -334,7 +335,7 @@ constexpr int kListCap = 512;               // samples a workgroup serves from i
 constexpr int kAhead = 16;                  // idx entries per thread requested together with the tile: all of idx for p <= 4096
 
 template <int DT, int N1, int N2>
-__global__ __launch_bounds__(kThreadsB, 4) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, const int64_t *__restrict__ idx, size_t proj, size_t features,
+__global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, const int64_t *__restrict__ idx, size_t proj, size_t features,
                                                                   float scale, void *__restrict__ out) {
     constexpr int N = N1 * N2, kCoarse = coarse_entries(N), kThreads = kThreadsB, kSlots = kThreads / C, kGroups = kThreads / CB;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -401,13 +402,21 @@ __global__ __launch_bounds__(kThreadsB, 4) void dct_pass_b_kernel(const f32x2 *_
             }
         }
     }
-    for (size_t i0 = static_cast<size_t>(kAhead) * kThreads; i0 < proj; i0 += kThreads) {
-        const int k = mine(raw(i0 + tid), i0 + tid);
-        if (k >= 0) {
-            const int pos = atomicAdd(count, 1);
-            if (pos < kListCap) {
-                list_k[pos] = k;
-                list_j[pos] = static_cast<int>(i0 + tid);
+    // (p > 4096: the rest of idx in batches of eight unconditional requests per thread -- eight latencies overlap instead of following one another)
+    for (size_t i0 = static_cast<size_t>(kAhead) * kThreads; i0 < proj; i0 += 8 * kThreads) {
+        int more[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) more[a] = raw(i0 + static_cast<size_t>(a) * kThreads + tid);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const size_t i = i0 + static_cast<size_t>(a) * kThreads + tid;
+            const int k = mine(more[a], i);
+            if (k >= 0) {
+                const int pos = atomicAdd(count, 1);
+                if (pos < kListCap) {
+                    list_k[pos] = k;
+                    list_j[pos] = static_cast<int>(i);
+                }
             }
         }
     }
@@ -465,9 +474,9 @@ __global__ __launch_bounds__(kThreadsB, 4) void dct_pass_b_kernel(const f32x2 *_
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 struct Split { int n1, n2; };
-// rows = N1 x N2 with 16 <= N2 <= N1 <= 128: 256 .. 16384 rows
+// rows = N1 x N2 with 16 <= N2 <= N1 <= 256: 256 .. 65536 rows
 bool split_rows(size_t rows, Split &s) {
-    if (rows < 256 || rows > 16384 || (rows & (rows - 1)) != 0) return false;
+    if (rows < 256 || rows > 65536 || (rows & (rows - 1)) != 0) return false;
     int bits = 0;
     while ((static_cast<size_t>(1) << bits) < rows) ++bits;
     s.n1 = 1 << ((bits + 1) / 2);
@@ -515,6 +524,7 @@ int launch_rows(Split sp, const void *m, size_t features, size_t ld, const int64
 #define FB_DCT_CASE(A, B) \
     if (sp.n1 == A && sp.n2 == B) return launch<DT, A, B>(m, features, ld, idx, proj, scale, out, inter, s);
     FB_DCT_CASE(16, 16) FB_DCT_CASE(32, 16) FB_DCT_CASE(32, 32) FB_DCT_CASE(64, 32) FB_DCT_CASE(64, 64) FB_DCT_CASE(128, 64) FB_DCT_CASE(128, 128)
+    FB_DCT_CASE(256, 128) FB_DCT_CASE(256, 256)
 #undef FB_DCT_CASE
     return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: no kernel for %d x %d rows", sp.n1, sp.n2);
 }
@@ -539,7 +549,7 @@ int fewbit_hip_sampled_dct(int dtype, const void *m, size_t rows, size_t feature
     if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: unknown dtype %d", dtype);
     if (proj == 0 || features == 0) return FEWBIT_OK;
     Split sp;
-    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is not a power of two in [256, 16384]", rows);
+    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is not a power of two in [256, 65536]", rows);
     if (m == nullptr || idx == nullptr || out == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: null pointer");
     if (ld < features) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: leading dimension %zu < features %zu", ld, features);
     const size_t need = inter_bytes(rows, features);

@@ -3,7 +3,7 @@
 tests/golden/sampled_dct_ref.npz (generator: tests/golden/gen_linear_golden.py dct).  Floating point, tolerance stated per check:
 the kernel computes in fp32 (four-step FFT, ~log2(rows) roundings), the reference call was float64, so
 
-    fp32 input   |err| <= 3e-6 * max|y|                              (single-precision FFT of up to 16384 points)
+    fp32 input   |err| <= 3e-6 * max|y|                              (single-precision FFT of up to 65536 points)
     bf16 / fp16  |err| <= 2^-8 |y| / 2^-11 |y| + 3e-6 * max|y|       (one rounding of the fp32 result to the 16-bit dtype)
 """
 import numpy as np
@@ -34,7 +34,7 @@ def close(got, want, dtype):
 
 @pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16, torch.float16))
 def test_sampled_rows_equal_the_reference_run(ref, dtype):
-    """7 shapes, 256 .. 16384 rows, ragged and odd feature counts, corner rows (0, rows/2, rows-1, the self-paired residue classes,
+    """9 shapes, 256 .. 65536 rows, ragged and odd feature counts, corner rows (0, rows/2, rows-1, the self-paired residue classes,
     duplicates): every dtype against the reference's float64 rows (the inputs are exact in all three dtypes)"""
     for i in range(int(ref['cases'])):
         x = torch.from_numpy(ref[f'case{i}_x_times_16'].astype(np.float32) / 16.0).to(dtype).to(DEV)
@@ -52,7 +52,7 @@ def test_every_row_of_the_transform_scale_strides_and_buffers():
     """p = rows (every k once, shuffled) against torch's float64 transform of the same data on the host; `scale`, a strided input
     (leading dimension > features), caller-provided out / workspace, and bit-identical repeats"""
     g = torch.Generator().manual_seed(12)
-    for rows, features in ((1024, 130), (256, 64), (16384, 66)):
+    for rows, features in ((1024, 130), (256, 64), (16384, 66), (32768, 34), (65536, 4)):
         wide = torch.randn(rows, features + 6, generator=g).to(DEV)
         x = wide[:, 3:3 + features]                                           # unit stride along the features, ld = features + 6
         assert not x.is_contiguous()
@@ -71,7 +71,7 @@ def test_every_row_of_the_transform_scale_strides_and_buffers():
 def test_shapes_without_a_kernel_are_refused_by_name_and_keep_the_library_path():
     assert cabi.sampled_dct_workspace_bytes(16384, 768, 3276) == 12 * 16384 * 256
     assert cabi.sampled_dct_workspace_bytes(16384, 70, 1) == 2 * 16384 * 256
-    for rows in (48, 128, 3000, 32768):
+    for rows in (48, 128, 3000, 131072):
         assert cabi.sampled_dct_workspace_bytes(rows, 64, 10) == 0
         x = torch.randn(rows, 8, device=DEV)
         idx = torch.zeros(4, dtype=torch.int64, device=DEV)

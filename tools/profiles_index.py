@@ -30,6 +30,7 @@ ROWS = [
     ('r0?_sketch_bench*.json', 'tools/sketch_bench.py: every estimator per shape against torch (round 6: settled, with the dct / dft columns; _torchfft_dct: before the DCT kernel existed)', f'{D} 7.3'),
     ('r0?_sketch_rocprof_*.txt', 'tools/profile_sketch.sh: rocprofv3 kernel durations (round 6: >= 200 settled dispatches) + PMC counters of the dense sketches', f'{D} 7.3'),
     ('r06_dct_rocprof_*.txt', 'tools/profile_dct.sh: settled kernel durations and PMC traffic of the sampled-DCT kernel pair', f'{D} 5, 7.3'),
+    ('r06_dct_large_rows.txt', 'the kernel pair and the torch.fft formulation at 32768 and 65536 rows', f'{D} 7.3'),
     ('r06_dct_variants.txt', 'the sampled-DCT variants measured in round 6, phases compiled out, per-workgroup timeline', f'{D} 7.5'),
     ('r0?_roberta_table_*.json', "tools/roberta_bench.py --table: the reference README's RoBERTa table per dtype and estimator", f'{D} 7.4'),
     ('r0?_roberta_ab_fp32.txt|r0?_roberta_ab_bf16.txt|r0?_roberta_randomized_insitu*.json', 'the randomized RoBERTa step, arms interleaved in one process; its GPU time by kernel class', f'{D} 7.4'),
