@@ -555,7 +555,8 @@ int fewbit_hip_sampled_dct(int dtype, const void *m, size_t rows, size_t feature
     const size_t need = inter_bytes(rows, features);
     if (workspace == nullptr || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
         return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: a 16-byte aligned workspace of %zu bytes is needed (fewbit_hip_sampled_dct_workspace), got %zu", need, workspace_bytes);
-    if (tiles_of(features) > 65535) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: more than 65535 column tiles");
+    if (tiles_of(features) > 32767) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: more than 32767 column tiles");
+    if (proj > 0x7fffffffull) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: more than 2^31 - 1 samples");
     hipStream_t s = static_cast<hipStream_t>(stream);
     f32x2 *inter = static_cast<f32x2 *>(workspace);
     const float fs = static_cast<float>(scale);

@@ -16,16 +16,13 @@ for a in sys.argv[5:]:
     path, _, own = spec.partition('@')
     lib = ctypes.CDLL(os.path.abspath(path))
     lib.fewbit_hip_sketch.argtypes = [i32, i32, vp, sz, sz, sz, sz, u64, dbl, vp, vp, sz, vp]
-    lib.fewbit_hip_sketch_tune_slices.argtypes = [ctypes.c_longlong]; lib.fewbit_hip_sketch_tune_waves.argtypes = [ctypes.c_longlong]; lib.fewbit_hip_sketch_tune_halves.argtypes = [ctypes.c_longlong]
-    if hasattr(lib, 'fewbit_hip_sketch_tune_partials'): lib.fewbit_hip_sketch_tune_partials.argtypes = [ctypes.c_longlong]
-    if hasattr(lib, 'fewbit_hip_sketch_tune_materialise'): lib.fewbit_hip_sketch_tune_materialise.argtypes = [ctypes.c_longlong]
+    lib.fewbit_hip_tune.argtypes = [ctypes.c_char_p, ctypes.c_longlong]       # (ABI 5: the sketch settings are keys of the one hook)
     arms[name] = (lib, dict(kv.split('=') for kv in own.split(',') if kv))
 stream = torch.cuda.current_stream().cuda_stream
 def run(name, reps):
     lib, st = arms[name]
-    lib.fewbit_hip_sketch_tune_slices(int(st.get('slices', -1))); lib.fewbit_hip_sketch_tune_waves(int(st.get('waves', -1))); lib.fewbit_hip_sketch_tune_halves(int(st.get('halves', -1)))
-    if hasattr(lib, 'fewbit_hip_sketch_tune_partials'): lib.fewbit_hip_sketch_tune_partials(int(st.get('partials', -1)))
-    if hasattr(lib, 'fewbit_hip_sketch_tune_materialise'): lib.fewbit_hip_sketch_tune_materialise(int(st.get('mem', -1)))
+    for key, name_ in (('slices', 'sketch_slices'), ('waves', 'sketch_waves'), ('halves', 'sketch_halves'), ('partials', 'sketch_partials'), ('mem', 'sketch_materialise')):
+        lib.fewbit_hip_tune(name_.encode(), int(st.get(key, -1)))
     args = (cabi.SKETCH_DISTS.index(dist), cabi.DTYPES[dtype], m.data_ptr(), rows, features, features, proj, 1234, 1.0 / proj, o.data_ptr(), ws.data_ptr(), ws.numel(), stream)
     for _ in range(2): assert lib.fewbit_hip_sketch(*args) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

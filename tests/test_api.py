@@ -88,6 +88,16 @@ def test_tune_is_the_single_hook_and_validates_its_keys():
         cabi.tune(sketch_materialise=-1)
 
 
+def test_sampled_dct_workspace_is_a_host_side_formula():
+    """no GPU needed: ceil(features / 64) * rows * 256 bytes for a power-of-two row count in [256, 65536], 0 = no kernel for this shape"""
+    assert cabi.sampled_dct_workspace_bytes(16384, 768, 3276) == 12 * 16384 * 256
+    assert cabi.sampled_dct_workspace_bytes(65536, 70, 1, torch.float32) == 2 * 65536 * 256
+    for rows in (0, 48, 128, 255, 3000, 131072):
+        assert cabi.sampled_dct_workspace_bytes(rows, 64, 10) == 0
+    assert cabi.sampled_dct_workspace_bytes(1024, 0, 10) == 0 == cabi.sampled_dct_workspace_bytes(1024, 64, 0)
+    assert cabi.sampled_dct_workspace_bytes(1024, 64, 10, torch.float64) == 0
+
+
 def test_every_file_under_profiles_is_indexed():
     """profiles/README.md is a generated table (file -> one line -> the DESIGN / EXPERIMENTS section that quotes it); a file without a row fails"""
     import subprocess
