@@ -111,3 +111,40 @@ def test_the_dct_layer_on_the_kernel_equals_the_layer_on_torch_fft(dtype):
     gw_n, gw_t = grads[True][3], grads[False][3]
     rel = float((gw_n - gw_t).abs().max() / gw_t.abs().max())
     assert rel <= (2e-5 if dtype == torch.float32 else 3e-2), rel          # bf16: both paths round the sampled rows to 8 bits, at different points
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        rows = 1 << int(rng.integers(8, 17))
+        features = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 63, 64, 65, 96, 127, 130, int(rng.integers(1, 200))]))
+        if rows * features > (1 << 24):
+            features = max(1, (1 << 24) // rows)
+        p = int(rng.choice([1, 2, 17, 300, int(rng.integers(1, 3000)), rows]))
+        dtype = (torch.float32, torch.bfloat16, torch.float16)[int(rng.integers(0, 3))]
+        pad = int(rng.choice([0, 0, 3, 8]))
+        yield rows, features, p, dtype, pad, float(rng.choice([1.0, 0.25, 5.0])), int(rng.integers(0, 2**31))
+
+
+def test_sampled_dct_fuzz_against_float64_on_the_device():
+    """40 random cases (FEWBIT_DCT_FUZZ_CASES=N widens the sweep): every supported row count, ragged / odd / tiny feature counts (edge
+    tiles, a last complex column with no partner), p from 1 to rows, all three dtypes, strided inputs, scales; expected = the float64
+    DCT-II of the same data computed by torch.fft on the device.  Plus the two list regimes of pass B forced on purpose: more samples of
+    one residue pair than the LDS list holds (the group-by-group fallback), and p > 4096 (the batched tail of idx)."""
+    import os
+    n = int(os.environ.get('FEWBIT_DCT_FUZZ_CASES', '40'))
+    cases = list(_fuzz_cases(n, 2026))
+    cases += [(256, 40, 9000, torch.float32, 0, 1.0, 1), (512, 66, 20000, torch.bfloat16, 2, 1.0, 2), (16384, 34, 16384, torch.float32, 0, 1.0, 3)]
+    for rows, features, p, dtype, pad, scale, seed in cases:
+        g = torch.Generator().manual_seed(seed)
+        wide = torch.randn(rows, features + pad, generator=g).to(dtype).to(DEV)
+        x = wide[:, :features]
+        idx = torch.randint(0, rows, (p, ), generator=g).to(DEV)
+        if seed == 1:
+            idx = (idx // 16) * 16                                           # every sample in ONE residue class of a 16 x 16 split: list overflow
+        got = cabi.sampled_dct(x, idx, scale)
+        want = fewbit.fft.dct(x.double(), dim=0, norm='ortho')[idx] * scale
+        err = (got.double() - want).abs()
+        tol = REL[dtype] * want.abs() + 3e-6 * float(want.abs().max()) + 1e-30
+        assert bool((err <= tol).all()), (rows, features, p, dtype, pad, float((err / tol).max()))
+        assert not torch.isnan(wide).any()

@@ -25,7 +25,7 @@ ROWS = [
     ('r0?_clock_transient_timeline.txt', 'step time against time since idle: the transient every settled figure waits out', f'{D} 7'),
     ('r0?_stream_bench_*MiB.txt', 'bare copy / read / write kernels and an empty kernel: the floors', f'{D} 7.1, 9'),
     ('r0?_fp32_ulp.json', 'ULP histogram of the fp32 GELU forward against the reference run and the exact value', f'{D} 6'),
-    ('r0?_soak_fuzz.txt|r0?_sketch_soak_fuzz.txt', 'one-off soak runs of the differential fuzz tests', f'{D} 6'),
+    ('r0?_soak_fuzz.txt|r0?_sketch_soak_fuzz.txt|r06_dct_soak_fuzz.txt', 'one-off soak runs of the differential fuzz tests', f'{D} 6'),
     # ---- estimators of the randomized layers
     ('r0?_sketch_bench*.json', 'tools/sketch_bench.py: every estimator per shape against torch (round 6: settled, with the dct / dft columns; _torchfft_dct: before the DCT kernel existed)', f'{D} 7.3'),
     ('r0?_sketch_rocprof_*.txt', 'tools/profile_sketch.sh: rocprofv3 kernel durations (round 6: >= 200 settled dispatches) + PMC counters of the dense sketches', f'{D} 7.3'),
