@@ -71,7 +71,10 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-__device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) { return f32x2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// complex product with two multiplies and two fused multiply-adds (the build has -ffp-contract=off: fusion is spelled out where wanted)
+__device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) {
+    return f32x2{__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
+}
 __device__ __forceinline__ f32x2 mul_mi(f32x2 a) { return f32x2{a.y, -a.x}; }                                   // a * (-i)
 // e^{-2 pi i num / den}, den a power of two (num / den is exact in fp32)
 __device__ __forceinline__ f32x2 unit(int num, int den) {
@@ -373,13 +376,7 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
     for (int m = tid; m < kFine; m += kThreads) fine[m] = unit(m, 4 * N);
     for (int m = tid; m < kCoarse; m += kThreads) coarse[m] = unit(m * kFine, 4 * N);
     if (tid == 0) *count = 0;
-#pragma unroll
-    for (int i = 0; i < kPieces; ++i) {
-        const int pid = tid + kThreads * i, r = pid / kPerRow, rest = pid % kPerRow, n2 = rest / (CB / 2), c2 = rest % (CB / 2);
-        if (kTotal % kThreads != 0 && pid >= kTotal) break;
-        *reinterpret_cast<f32x4 *>(tile + (n2 * 2 + r) * CB + 2 * c2) = v[i];
-    }
-    __syncthreads();
+    __syncthreads();                                                  // (the counter is zero for everybody; the tile is still on its way)
     // the workgroup's samples -> LDS list (order does not matter: every sample writes its own row of the result).  A thread first
     // counts its own matches among the prefetched entries and reserves their places with ONE atomic (not one per entry: sixteen
     // divergent branches each waiting for its returned value cost 1.9 us of a 18.7 us launch)
@@ -421,6 +418,14 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
         }
     }
 
+    // registers -> LDS only now: the list was built while the tile travelled (idx went out first, vmcnt counts in order)
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+        const int pid = tid + kThreads * i, r = pid / kPerRow, rest = pid % kPerRow, n2 = rest / (CB / 2), c2 = rest % (CB / 2);
+        if (kTotal % kThreads != 0 && pid >= kTotal) break;
+        *reinterpret_cast<f32x4 *>(tile + (n2 * 2 + r) * CB + 2 * c2) = v[i];
+    }
+    __syncthreads();
     fft_tile<N2, 1, kSlots>(tile, tw, tid % C, tid / C);               // (ends with a barrier: the list is complete behind it)
 
     // ---- the sampled rows of this workgroup's two residue classes: one per group of 16 lanes at a time, lanes along the columns
