@@ -260,7 +260,7 @@ template <int DT> __device__ __forceinline__ void unpack_piece(u32x4 q, float (&
     }
 }
 
-constexpr int kFine = 128;                  // W_D^e = fine[e % 128] * coarse[e / 128] (two tables of at most 128 entries for e < 16384)
+constexpr int kFine = 128;                  // W_D^e = fine[e % 128] * coarse[e / 128] for e < N (coarse: N / 128 entries, at most 512)
 constexpr int coarse_entries(int n) { return n / kFine > 0 ? n / kFine : 1; }
 __device__ __forceinline__ f32x2 table_unit(const f32x2 *fine, const f32x2 *coarse, int e, bool has_coarse) {
     return has_coarse ? cmul(fine[e % kFine], coarse[e / kFine]) : fine[e % kFine];
