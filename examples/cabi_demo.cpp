@@ -4,6 +4,7 @@
 //   quantize_backward : gx = levels[code] * gy
 //   sketch            : out = S . m with the Rademacher matrix S(seed) that exists only inside the kernel; the host rebuilds
 //                       S from the ABI's own host Philox (fewbit_hip_philox4x32) and the published bit order
+//   sampled_dct       : out = scale * DCT-II_ortho(m along its rows)[idx] (the reference's 'dct' estimator)
 // and a check against a scalar restatement on the host.  Build: make -C fewbit_amd/csrc demo
 #include <fewbit_hip.h>
 #include <hip/hip_runtime.h>
@@ -148,5 +149,42 @@ int main() {
     for (size_t i = 0; i < out.size(); ++i) bad_seed += out_dev[i] != out_val[i];
     std::printf("  seed in device memory (counter %llu -> %llu): differences from the seed by value %zu\n",
                 static_cast<unsigned long long>(counter0), static_cast<unsigned long long>(counter1), bad_seed);
-    return (bad_code || bad_gx || bad_y || bad_sketch || bad_seed) ? 1 : 0;
+    // ---- the sampled cosine transform (the reference's 'dct' estimator): out[j] = 2 * DCT-II_ortho(m along its rows)[idx[j]], against
+    //      the cosine sum itself in double precision on the host ----
+    const size_t drows = 256, dfeats = 6, dproj = 5;
+    const int64_t picks[dproj] = {0, 1, 128, 255, 77};
+    std::vector<float> dmat(drows * dfeats), dgot(dproj * dfeats);
+    for (size_t i = 0; i < dmat.size(); ++i) {
+        seed = seed * 1664525u + 1013904223u;
+        dmat[i] = static_cast<float>(seed >> 8) / 16777216.0f - 0.5f;
+    }
+    const size_t dct_ws_bytes = fewbit_hip_sampled_dct_workspace(FEWBIT_F32, drows, dfeats, dproj);
+    float *ddm, *ddout;
+    int64_t *didx;
+    void *ddws;
+    HIP_OK(hipMalloc(&ddm, dmat.size() * 4));
+    HIP_OK(hipMalloc(&ddout, dgot.size() * 4));
+    HIP_OK(hipMalloc(&didx, sizeof picks));
+    HIP_OK(hipMalloc(&ddws, dct_ws_bytes));
+    HIP_OK(hipMemcpyAsync(ddm, dmat.data(), dmat.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(didx, picks, sizeof picks, hipMemcpyHostToDevice, stream));
+    rc = fewbit_hip_sampled_dct(FEWBIT_F32, ddm, drows, dfeats, dfeats, didx, dproj, 2.0, ddout, ddws, dct_ws_bytes, stream);
+    if (rc != FEWBIT_OK) {
+        std::fprintf(stderr, "sampled_dct error %d: %s\n", rc, fewbit_hip_last_error());
+        return 3;
+    }
+    HIP_OK(hipMemcpyAsync(dgot.data(), ddout, dgot.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    size_t bad_dct = 0;
+    const double pi = 3.14159265358979323846;
+    for (size_t j = 0; j < dproj; ++j) {
+        for (size_t f = 0; f < dfeats; ++f) {
+            double acc = 0.0;
+            for (size_t r = 0; r < drows; ++r) acc += dmat[r * dfeats + f] * std::cos(pi * static_cast<double>(picks[j]) * (2.0 * r + 1.0) / (2.0 * drows));
+            const double want = 2.0 * acc * (picks[j] == 0 ? std::sqrt(1.0 / drows) : std::sqrt(2.0 / drows));
+            bad_dct += std::fabs(dgot[j * dfeats + f] - want) > 1e-5;
+        }
+    }
+    std::printf("  sampled DCT of %zu x %zu, %zu rows picked (workspace %zu bytes): mismatches %zu\n", drows, dfeats, dproj, dct_ws_bytes, bad_dct);
+    return (bad_code || bad_gx || bad_y || bad_sketch || bad_seed || bad_dct) ? 1 : 0;
 }

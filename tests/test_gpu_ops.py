@@ -516,7 +516,7 @@ def test_randomized_linear_on_gpu(matmul):
 
 def test_torch_free_host_program_on_the_c_abi():
     """examples/cabi_demo.cpp: plain C++ + the HIP runtime + libfewbit_hip.so (no torch, no python) -- forward and
-    backward of one million elements, and one random-projection product, checked on the host by the program itself."""
+    backward of one million elements, one random-projection product and one sampled cosine transform, checked on the host by the program itself."""
     import subprocess
     from helpers import ROOT
     exe = ROOT / 'examples' / 'cabi_demo'
@@ -526,6 +526,7 @@ def test_torch_free_host_program_on_the_c_abi():
     assert 'mismatches: codes 0, gradients 0, forward 0' in out.stdout
     assert '(Rademacher, seed 123456789abcdef): mismatches 0' in out.stdout      # the random-projection kernel, S rebuilt on the host
     assert 'seed in device memory (counter 6 -> 7): differences from the seed by value 0' in out.stdout
+    assert 'sampled DCT of 256 x 6, 5 rows picked' in out.stdout and out.stdout.rstrip().endswith('mismatches 0')   # vs the cosine sum in double
 
 
 def test_inference_mode_and_no_grad_run_the_kernels():
