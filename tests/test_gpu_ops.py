@@ -653,8 +653,8 @@ def test_c_abi_validation_mode():
 def test_concurrent_streams_and_threads_one_process_many_devices():
     """SURVEY 8(e), first form: ONE process driving every device of the box with per-device streams.  Host thread i works on
     device i % device_count() (all of them on the one device of a 1-GPU box) on its own stream: the activation path (per-device
-    launch-geometry and occupancy caches, first use included when this test runs alone) and a random-projection product whose
-    kernel needs the per-device opt-in to more than 64 KiB of LDS.  The library keeps no per-call global state, so every thread
+    launch-geometry and occupancy caches, first use included when this test runs alone), a random-projection product and a sampled
+    cosine transform of 32768 rows, whose kernels need the per-device opt-in to more than 64 KiB of LDS.  The library keeps no per-call global state, so every thread
     must get the bytes of the serial run on the first device, whichever device it ran on."""
     import threading
     from fewbit_amd import cabi
@@ -669,6 +669,8 @@ def test_concurrent_streams_and_threads_one_process_many_devices():
         g = torch.Generator().manual_seed(100 + i)
         host.append(((torch.randn(n, generator=g) * 1.5).to(dtype), torch.randn(n, generator=g).to(dtype), dtype))
     m_host = torch.randn(2048, 1024, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16)
+    d_host = torch.randn(32768, 40, generator=torch.Generator().manual_seed(10))
+    d_idx = torch.randint(0, 32768, (300, ), generator=torch.Generator().manual_seed(11))
 
     def tables(dtype, dev):
         b, l = store.get('gelu', 3, dev, dtype)
@@ -688,6 +690,7 @@ def test_concurrent_streams_and_threads_one_process_many_devices():
             y, st = cabi.quantize_forward('gelu', x.to(first), b)
             serial.append((y.cpu(), st.cpu(), cabi.quantize_backward(gy.to(first), st, l).cpu()))
         serial_sketch = sketch_on(first).cpu()
+        serial_dct = cabi.sampled_dct(d_host.to(first), d_idx.to(first)).cpu()
         torch.cuda.synchronize(first)
         out, errors, ran_on = [None] * len(host), [], [None] * len(host)
 
@@ -703,12 +706,13 @@ def test_concurrent_streams_and_threads_one_process_many_devices():
                         y, st = cabi.quantize_forward('gelu', x, b, stream=s.cuda_stream)
                         gx = cabi.quantize_backward(gy, st, l, stream=s.cuda_stream)
                     p = sketch_on(dev, stream=s.cuda_stream)
+                    dc = cabi.sampled_dct(d_host.to(dev), d_idx.to(dev), stream=s.cuda_stream)
                 s.synchronize()
-                assert y.device == dev and p.device == dev
+                assert y.device == dev and p.device == dev and dc.device == dev
                 # the plan the library reports for THIS device is the one it used there (geometry cached per device index)
                 assert cabi.describe_forward('gelu', dtype, x.numel(), 7, device=dev)['blocks'] > 0
                 ran_on[i] = dev.index
-                out[i] = (y.cpu(), st.cpu(), gx.cpu(), p.cpu())
+                out[i] = (y.cpu(), st.cpu(), gx.cpu(), p.cpu(), dc.cpu())
             except Exception as e:  # noqa: BLE001
                 errors.append(e)
 
@@ -721,10 +725,11 @@ def test_concurrent_streams_and_threads_one_process_many_devices():
         cabi.tune(sketch_materialise=-1)
     assert not errors, errors
     assert ran_on == [d.index for d in devices] and (ndev == 1 or any(ran_on)), ran_on      # a non-zero device index whenever one exists
-    for (y0, s0, g0), (y1, s1, g1, p1) in zip(serial, out):
+    for (y0, s0, g0), (y1, s1, g1, p1, dc1) in zip(serial, out):
         assert torch.equal(s0, s1)
         assert torch.equal(y0.view(torch.uint8), y1.view(torch.uint8)) and torch.equal(g0.view(torch.uint8), g1.view(torch.uint8))
         assert torch.equal(serial_sketch.view(torch.uint8), p1.view(torch.uint8))
+        assert torch.equal(serial_dct.view(torch.uint8), dc1.view(torch.uint8))
 
 
 def test_autocast_and_activation_checkpointing():
