@@ -8,7 +8,7 @@ cd "$ROOT"; export TMPDIR=/tmp
 RAW=$ROOT/gpurun_out/insitu_sketch_$R; rm -rf "$RAW"; mkdir -p "$RAW"
 OUT=$ROOT/gpurun_out/${R}_roberta_randomized_insitu.json
 echo "[" > "$OUT"; first=1
-for v in "bf16 0 rademacher" "bf16 2 rademacher" "bf16 2 gaussian" "fp32 0 gaussian" "fp32 2 gaussian" "fp32 2 rademacher"; do
+for v in "bf16 0 rademacher" "bf16 2 rademacher" "bf16 2 gaussian" "bf16 2 dct" "fp32 0 gaussian" "fp32 2 gaussian" "fp32 2 rademacher" "fp32 2 dct"; do
     set -- $v; tag=$1_row$2_$3
     timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/$tag" -o rob -- \
         python3 tools/roberta_bench.py --table --row $2 --dtype $1 --matmul $3 --steps 6 > "$RAW/$tag.json" 2> "$RAW/$tag.err"

@@ -34,6 +34,7 @@ ROWS = [
     ('r06_dct_variants.txt', 'the sampled-DCT variants measured in round 6, phases compiled out, per-workgroup timeline', f'{D} 7.5'),
     ('r0?_roberta_table_*.json', "tools/roberta_bench.py --table: the reference README's RoBERTa table per dtype and estimator", f'{D} 7.4'),
     ('r0?_roberta_ab_fp32.txt|r0?_roberta_ab_bf16.txt|r0?_roberta_randomized_insitu*.json', 'the randomized RoBERTa step, arms interleaved in one process; its GPU time by kernel class', f'{D} 7.4'),
+    ('r06_roberta_overlap_ab.txt', 'the estimators on a side stream beside the layer GEMMs: slower, not kept', f'{E} round 6'),
     ('r06_isa_identity.txt', 'tools/isa_digest.py: machine code of all 628 device functions before / after the round-6 source clean-up', f'{D} 9'),
     # ---- experiments (kept as records; the design quotes only their conclusions)
     ('r02_launch_shape_sweep_*.txt|r03_*shape_sweep*.txt|r03_backward_size_crossover.txt', 'launch shape, groups per lane and size crossovers of the activation kernels', f'{D} 3.1'),
