@@ -368,7 +368,7 @@ def measure_sampled_transform(device, rows, features, proj, dtype, dense_rademac
     rec = {'workload': f"dct(M, dim=0, norm='ortho')[idx], M {rows} x {features} {str(dtype).split('.')[-1]}, {proj} sampled rows",
            'byte_floor': {'bytes': floor_bytes, 'us_at_8TBs': round(floor_bytes / HBM_PEAK_GBS / 1e3, 2)}}
     for kind in ('dct', 'dft'):
-        us = settled_us(lambda: linear._sketch(kind, m, proj, gen), reps=20)
+        us = settled_us(lambda: linear.sampled_transform(kind, m, proj, gen), reps=20)
         rec[kind] = {'us': round(us, 1), 'x_byte_floor': round(us / (floor_bytes / HBM_PEAK_GBS / 1e3), 1), 'path': linear.sampled_transform_path(kind, m)}
         if kind == 'dct' and 'fewbit_hip_sampled_dct' in rec[kind]['path']:
             # the kernel pair's own roofline: the bytes its design moves (M once, the fp32 intermediate out and back, the sampled rows)

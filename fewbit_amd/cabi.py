@@ -16,7 +16,7 @@ __all__ = [
     'stepwise1_forward', 'stepwise1_backward', 'pack_codes', 'unpack_codes', 'FewbitHipError', 'describe_forward',
     'describe_backward', 'describe_stepwise1_forward', 'describe_stepwise1_backward', 'tune',
     'SKETCH_DISTS', 'ABI_VERSION', 'sketch', 'next_sketch_seed', 'mix_sketch_seed', 'sketch_matrix', 'sketch_workspace_bytes', 'describe_sketch', 'tune_sketch_slices', 'tune_sketch_waves', 'tune_sketch_halves', 'tune_sketch_convert', 'tune_sketch_partials', 'tune_sketch_materialise', 'xoshiro128pp',
-    'philox4x32', 'sampled_dct', 'sampled_dct_workspace_bytes',
+    'philox4x32', 'sampled_dct', 'sampled_dct_seeded', 'sampled_rows', 'sampled_dct_workspace_bytes',
 ]
 
 import os
@@ -40,7 +40,7 @@ SYMBOLS = ('fewbit_hip_abi_version', 'fewbit_hip_last_error', 'fewbit_hip_bitwid
            'fewbit_hip_describe_stepwise1_forward', 'fewbit_hip_describe_stepwise1_backward', 'fewbit_hip_tune',
            'fewbit_hip_sketch_workspace', 'fewbit_hip_sketch', 'fewbit_hip_sketch_device_seed', 'fewbit_hip_sketch_next_seed',
            'fewbit_hip_sketch_mix_seed', 'fewbit_hip_sketch_matrix', 'fewbit_hip_sketch_describe',
-           'fewbit_hip_sampled_dct_workspace', 'fewbit_hip_sampled_dct',
+           'fewbit_hip_sampled_dct_workspace', 'fewbit_hip_sampled_dct', 'fewbit_hip_sampled_dct_seeded', 'fewbit_hip_sampled_rows',
            'fewbit_hip_philox4x32', 'fewbit_hip_xoshiro128pp')
 
 
@@ -113,6 +113,10 @@ def lib() -> ctypes.CDLL:
         L.fewbit_hip_sampled_dct_workspace.argtypes = [i32, sz, sz, sz]
         L.fewbit_hip_sampled_dct.restype = i32
         L.fewbit_hip_sampled_dct.argtypes = [i32, vp, sz, sz, sz, vp, sz, dbl, vp, vp, sz, vp]
+        L.fewbit_hip_sampled_dct_seeded.restype = i32
+        L.fewbit_hip_sampled_dct_seeded.argtypes = [i32, vp, sz, sz, sz, ctypes.c_uint64, vp, sz, dbl, vp, vp, sz, vp]
+        L.fewbit_hip_sampled_rows.restype = i32
+        L.fewbit_hip_sampled_rows.argtypes = [ctypes.c_uint64, sz, sz, vp]
         L.fewbit_hip_philox4x32.restype = None
         L.fewbit_hip_philox4x32.argtypes = [ctypes.POINTER(ctypes.c_uint32)] * 3
         L.fewbit_hip_xoshiro128pp.restype = None
@@ -493,21 +497,14 @@ def sampled_dct_workspace_bytes(rows: int, features: int, proj: int, dtype: torc
     return lib().fewbit_hip_sampled_dct_workspace(DTYPES[dtype], rows, features, proj)
 
 
-def sampled_dct(m: torch.Tensor, idx: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None,
-                workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
-    """``scale * dct(m, dim=0, norm='ortho')[idx]`` (DCT-II along the rows, orthonormal; the reference's 'dct' sketch) for a 2-D
-    ``m`` (rows x features, unit stride along the features) whose row count is a power of two in [256, 65536]; ``idx``: int64 row
-    numbers on the device of ``m``.  fp32 arithmetic, result in the dtype of ``m``."""
+def _sampled_dct_call(m: torch.Tensor, proj: int, out: Optional[torch.Tensor], workspace: Optional[torch.Tensor], others, launch) -> torch.Tensor:
     if m.device.type != 'cuda':
         raise FewbitHipError(f'm must live on the GPU (got {m.device})')
     if m.dim() != 2 or (m.shape[1] > 1 and m.stride(1) != 1):
         raise FewbitHipError('m must be 2-D with unit stride along its last dimension')
     if m.dtype not in DTYPES:
         raise FewbitHipError(f'unsupported dtype {m.dtype}')
-    if idx.dtype != torch.int64 or idx.dim() != 1 or idx.device != m.device or not idx.is_contiguous():
-        raise FewbitHipError('idx must be a contiguous 1-D int64 tensor on the device of m')
     rows, features = m.shape
-    proj = idx.numel()
     ld = m.stride(0) if rows > 1 else features
     need = sampled_dct_workspace_bytes(rows, features, proj, m.dtype)
     if need == 0 and proj and features:
@@ -519,11 +516,43 @@ def sampled_dct(m: torch.Tensor, idx: torch.Tensor, scale: float = 1.0, out: Opt
             raise FewbitHipError('out must be a contiguous proj x features tensor of the dtype of m')
         if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
             workspace = torch.empty(need, dtype=torch.uint8, device=m.device)
-        _same_device(m, out, idx, *(() if workspace is None else (workspace, )))
-        _check(lib().fewbit_hip_sampled_dct(DTYPES[m.dtype], m.data_ptr(), rows, features, ld, idx.data_ptr(), proj, scale, out.data_ptr(),
-                                            0 if workspace is None else workspace.data_ptr(),
-                                            0 if workspace is None else workspace.numel() * workspace.element_size(), _stream(stream, m.device)))
+        _same_device(m, out, *others, *(() if workspace is None else (workspace, )))
+        _check(launch(DTYPES[m.dtype], m.data_ptr(), rows, features, ld, out.data_ptr(), 0 if workspace is None else workspace.data_ptr(),
+                      0 if workspace is None else workspace.numel() * workspace.element_size()))
     return out
+
+
+def sampled_dct(m: torch.Tensor, idx: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None,
+                workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    """``scale * dct(m, dim=0, norm='ortho')[idx]`` (DCT-II along the rows, orthonormal; the reference's 'dct' sketch) for a 2-D
+    ``m`` (rows x features, unit stride along the features) whose row count is a power of two in [256, 65536]; ``idx``: int64 row
+    numbers on the device of ``m``.  fp32 arithmetic, result in the dtype of ``m``."""
+    if idx.dtype != torch.int64 or idx.dim() != 1 or idx.device != m.device or not idx.is_contiguous():
+        raise FewbitHipError('idx must be a contiguous 1-D int64 tensor on the device of m')
+    proj = idx.numel()
+    return _sampled_dct_call(m, proj, out, workspace, (idx, ), lambda dt, mp, rows, features, ld, op, wp, wb: lib().fewbit_hip_sampled_dct(
+        dt, mp, rows, features, ld, idx.data_ptr(), proj, scale, op, wp, wb, _stream(stream, m.device)))
+
+
+def sampled_dct_seeded(m: torch.Tensor, proj: int, seed, scale: float = 1.0, out: Optional[torch.Tensor] = None,
+                       workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    """``sampled_dct(m, sampled_rows(seed, rows, proj))`` without the array of row numbers: the rows are a function of ``seed`` that the
+    kernel evaluates itself.  ``seed``: an int, or a one-element int64 tensor on the device of ``m`` whose value is read when the kernel
+    runs (``next_sketch_seed``: a launch recorded into a hipGraph then samples fresh rows on every replay)."""
+    if isinstance(seed, torch.Tensor):
+        _seed_word(seed, 'seed')
+        value, word, others = 0, seed.data_ptr(), (seed, )
+    else:
+        value, word, others = seed & 0xffffffffffffffff, 0, ()
+    return _sampled_dct_call(m, proj, out, workspace, others, lambda dt, mp, rows, features, ld, op, wp, wb: lib().fewbit_hip_sampled_dct_seeded(
+        dt, mp, rows, features, ld, value, word, proj, scale, op, wp, wb, _stream(stream, m.device)))
+
+
+def sampled_rows(seed: int, rows: int, proj: int) -> torch.Tensor:
+    """The row numbers ``sampled_dct_seeded`` samples for ``seed``: a host int64 tensor (evaluated on the host; no GPU needed)"""
+    idx = torch.empty(proj, dtype=torch.int64)
+    _check(lib().fewbit_hip_sampled_rows(seed & 0xffffffffffffffff, rows, proj, idx.data_ptr()))
+    return idx
 
 
 def xoshiro128pp(state, n: int):

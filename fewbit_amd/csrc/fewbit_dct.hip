@@ -50,6 +50,7 @@
 #include <type_traits>
 
 #include "fewbit_hip.h"
+#include "fewbit_philox.h"
 
 #define FEWBIT_HIDDEN __attribute__((visibility("hidden")))
 
@@ -337,8 +338,27 @@ __global__ __launch_bounds__(kThreadsA, (N1 > 128 ? 2 : 4)) void dct_pass_a_kern
 constexpr int kListCap = 512;               // samples a workgroup serves from its LDS list (more: the group-by-group fallback)
 constexpr int kAhead = 16;                  // idx entries per thread requested together with the tile: all of idx for p <= 4096
 
-template <int DT, int N1, int N2>
-__global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, const int64_t *__restrict__ idx, size_t proj, size_t features,
+// Where the sampled rows come from.  RowsInMemory: the caller's int64 array.  RowsOfSeed: a FUNCTION of a 64-bit seed,
+//     idx[j] = 16-bit half j % 8 of the 128 bits of Philox4x32-10(counter = (j / 8, 0, 0, 3), key = seed)  mod  rows      (rows <= 2^16)
+// (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of word h / 2; uniform, with replacement, like randint)
+// which every workgroup evaluates for itself while its tile travels: no array, no launch that draws one, nothing to keep for backward but
+// the seed -- and, with the seed read from device memory, a recorded launch draws fresh rows on every replay (fewbit_sketch.hip, same scheme).
+constexpr uint32_t kRowsDomain = 3u;        // counter word 3 (0 and 2: the dense sketches)
+constexpr int kPerDraw = 8;                 // row numbers per Philox call
+static_assert(kAhead % kPerDraw == 0 && 8 % kPerDraw == 0, "whole Philox calls per batch");
+__host__ __device__ __forceinline__ int half_of(const uint32_t (&w)[4], int h) { return static_cast<int>((w[h / 2] >> (16 * (h % 2))) & 0xffffu); }
+struct RowsInMemory {
+    static constexpr bool kSeeded = false;
+    const int64_t *idx;
+};
+struct RowsOfSeed {
+    static constexpr bool kSeeded = true;
+    sketch::Key value;
+    const sketch::Key *device;              // != nullptr: the key is read from there when the kernel runs
+};
+
+template <int DT, int N1, int N2, typename ROWS>
+__global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, ROWS rows, size_t proj, size_t features,
                                                                   float scale, void *__restrict__ out) {
     constexpr int N = N1 * N2, kCoarse = coarse_entries(N), kThreads = kThreadsB, kSlots = kThreads / C, kGroups = kThreads / CB;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -353,11 +373,25 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
     // the row numbers this thread will test go out FIRST (vmcnt counts in order: looking at them later does not wait for the tile).
     // Unconditional loads -- the index is clamped, the verdict is a select -- so that hipcc issues them back to back instead of one
     // per branch with a wait each (6 us of a 22 us launch); the low dword of an int64 in [0, N) is the number
-    const int *idx_lo = reinterpret_cast<const int *>(idx);
-    auto raw = [&](size_t i) -> int { return idx_lo[2 * (i < proj ? i : proj - 1)]; };
+    // (rows of a seed: entry a of a batch is half a % 8 of Philox call (a / 8) * kThreads + tid -- computed below, behind the tile's requests)
+    sketch::Key key{0u, 0u};
+    if constexpr (ROWS::kSeeded) key = rows.device != nullptr ? *rows.device : rows.value;      // (one scalar load)
+    auto entry = [&](size_t first, int a) -> size_t {                 // index into idx of entry a of the batch that starts at call / entry `first`
+        if constexpr (ROWS::kSeeded) return kPerDraw * (first + static_cast<size_t>(a / kPerDraw) * kThreads + tid) + a % kPerDraw;
+        else return first + static_cast<size_t>(a) * kThreads + tid;
+    };
+    auto raw = [&](size_t i) -> int {
+        if constexpr (ROWS::kSeeded) return 0;
+        else return reinterpret_cast<const int *>(rows.idx)[2 * (i < proj ? i : proj - 1)];
+    };
+    auto draw = [&](size_t q, uint32_t (&w)[4]) __attribute__((always_inline)) {
+        sketch::philox4x32(static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32), 0u, kRowsDomain, key, w);
+    };
     int kraw[kAhead];
+    if constexpr (!ROWS::kSeeded) {
 #pragma unroll
-    for (int a = 0; a < kAhead; ++a) kraw[a] = raw(static_cast<size_t>(a) * kThreads + tid);
+        for (int a = 0; a < kAhead; ++a) kraw[a] = raw(entry(0, a));
+    }
     constexpr int kPerRow = N2 * (CB / 2), kTotal = 2 * kPerRow, kPieces = (kTotal + kThreads - 1) / kThreads;     // 16-byte pieces (two complex)
     f32x4 v[kPieces];
 #pragma unroll
@@ -376,6 +410,15 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
     for (int m = tid; m < kFine; m += kThreads) fine[m] = unit(m, 4 * N);
     for (int m = tid; m < kCoarse; m += kThreads) coarse[m] = unit(m * kFine, 4 * N);
     if (tid == 0) *count = 0;
+    if constexpr (ROWS::kSeeded) {
+#pragma unroll
+        for (int d = 0; d < kAhead / kPerDraw; ++d) {
+            uint32_t w[4];
+            draw(static_cast<size_t>(d) * kThreads + tid, w);
+#pragma unroll
+            for (int h = 0; h < kPerDraw; ++h) kraw[kPerDraw * d + h] = half_of(w, h);
+        }
+    }
     __syncthreads();                                                  // (the counter is zero for everybody; the tile is still on its way)
     // the workgroup's samples -> LDS list (order does not matter: every sample writes its own row of the result).  A thread first
     // counts its own matches among the prefetched entries and reserves their places with ONE atomic (not one per entry: sixteen
@@ -383,7 +426,7 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
     int verdict[kAhead], mine_count = 0;
 #pragma unroll
     for (int a = 0; a < kAhead; ++a) {
-        verdict[a] = mine(kraw[a], static_cast<size_t>(a) * kThreads + tid);
+        verdict[a] = mine(kraw[a], entry(0, a));
         mine_count += verdict[a] >= 0 ? 1 : 0;
     }
     if (mine_count > 0) {
@@ -393,20 +436,29 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
             if (verdict[a] >= 0) {
                 if (pos < kListCap) {
                     list_k[pos] = verdict[a];
-                    list_j[pos] = a * kThreads + tid;
+                    list_j[pos] = static_cast<int>(entry(0, a));
                 }
                 ++pos;
             }
         }
     }
     // (p > 4096: the rest of idx in batches of eight unconditional requests per thread -- eight latencies overlap instead of following one another)
-    for (size_t i0 = static_cast<size_t>(kAhead) * kThreads; i0 < proj; i0 += 8 * kThreads) {
+    // (rows of a seed: `first` counts Philox calls, eight entries each -- one call per thread and batch)
+    constexpr size_t kPerCall = ROWS::kSeeded ? kPerDraw : 1;
+    for (size_t first = static_cast<size_t>(kAhead) * kThreads / kPerCall; first * kPerCall < proj; first += 8 * kThreads / kPerCall) {
         int more[8];
+        if constexpr (ROWS::kSeeded) {
+            uint32_t w[4];
+            draw(first + tid, w);
 #pragma unroll
-        for (int a = 0; a < 8; ++a) more[a] = raw(i0 + static_cast<size_t>(a) * kThreads + tid);
+            for (int h = 0; h < kPerDraw; ++h) more[h] = half_of(w, h);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) more[a] = raw(entry(first, a));
+        }
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            const size_t i = i0 + static_cast<size_t>(a) * kThreads + tid;
+            const size_t i = entry(first, a);
             const int k = mine(more[a], i);
             if (k >= 0) {
                 const int pos = atomicAdd(count, 1);
@@ -471,9 +523,21 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
     }
     // more samples in these two classes than the list holds (p in the tens of thousands, or a skewed idx): every group of 16 lanes
     // walks its share of idx by itself (all 16 lanes read the same word) and writes the rows that belong here
-    for (size_t i = group; i < proj; i += kGroups) {
-        const int k = mine(raw(i), i);
-        if (k >= 0) write_row(k, i);
+    if constexpr (ROWS::kSeeded) {
+        for (size_t q = group; kPerDraw * q < proj; q += kGroups) {
+            uint32_t w[4];
+            draw(q, w);
+#pragma unroll
+            for (int h = 0; h < kPerDraw; ++h) {
+                const int k = mine(half_of(w, h), kPerDraw * q + h);
+                if (k >= 0) write_row(k, kPerDraw * q + h);
+            }
+        }
+    } else {
+        for (size_t i = group; i < proj; i += kGroups) {
+            const int k = mine(raw(i), i);
+            if (k >= 0) write_row(k, i);
+        }
     }
 }
 
@@ -509,29 +573,51 @@ template <typename K> int opt_in(K kern, size_t lds, std::atomic<unsigned long l
     return FEWBIT_OK;
 }
 
-template <int DT, int N1, int N2>
-int launch(const void *m, size_t features, size_t ld, const int64_t *idx, size_t proj, float scale, void *out, f32x2 *inter, hipStream_t s) {
+template <int DT, int N1, int N2, typename ROWS>
+int launch(const void *m, size_t features, size_t ld, ROWS idx, size_t proj, float scale, void *out, f32x2 *inter, hipStream_t s) {
     static std::atomic<unsigned long long> done_a{0}, done_b{0};
     constexpr size_t la = lds_bytes_a<N1>(N1 * N2), lb = lds_bytes_b<N2>(N1 * N2);
     if (const int rc = opt_in(dct_pass_a_kernel<DT, N1, N2>, la, done_a)) return rc;
-    if (const int rc = opt_in(dct_pass_b_kernel<DT, N1, N2>, lb, done_b)) return rc;
+    if (const int rc = opt_in(dct_pass_b_kernel<DT, N1, N2, ROWS>, lb, done_b)) return rc;
     const unsigned tiles = static_cast<unsigned>(tiles_of(features));
     hipLaunchKernelGGL((dct_pass_a_kernel<DT, N1, N2>), dim3(N2, tiles), dim3(kThreadsA), la, s, m, features, ld, inter);
     const unsigned half_tiles = static_cast<unsigned>((features + 2 * CB - 1) / (2 * CB));
-    hipLaunchKernelGGL((dct_pass_b_kernel<DT, N1, N2>), dim3(N1 / 2 + 1, half_tiles), dim3(kThreadsB), lb, s, inter, idx, proj, features, scale, out);
+    hipLaunchKernelGGL((dct_pass_b_kernel<DT, N1, N2, ROWS>), dim3(N1 / 2 + 1, half_tiles), dim3(kThreadsB), lb, s, inter, idx, proj, features, scale, out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sampled_dct: %s", hipGetErrorString(e));
     return FEWBIT_OK;
 }
 
-template <int DT>
-int launch_rows(Split sp, const void *m, size_t features, size_t ld, const int64_t *idx, size_t proj, float scale, void *out, f32x2 *inter, hipStream_t s) {
+template <int DT, typename ROWS>
+int launch_rows(Split sp, const void *m, size_t features, size_t ld, ROWS idx, size_t proj, float scale, void *out, f32x2 *inter, hipStream_t s) {
 #define FB_DCT_CASE(A, B) \
-    if (sp.n1 == A && sp.n2 == B) return launch<DT, A, B>(m, features, ld, idx, proj, scale, out, inter, s);
+    if (sp.n1 == A && sp.n2 == B) return launch<DT, A, B, ROWS>(m, features, ld, idx, proj, scale, out, inter, s);
     FB_DCT_CASE(16, 16) FB_DCT_CASE(32, 16) FB_DCT_CASE(32, 32) FB_DCT_CASE(64, 32) FB_DCT_CASE(64, 64) FB_DCT_CASE(128, 64) FB_DCT_CASE(128, 128)
     FB_DCT_CASE(256, 128) FB_DCT_CASE(256, 256)
 #undef FB_DCT_CASE
     return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: no kernel for %d x %d rows", sp.n1, sp.n2);
+}
+
+template <typename ROWS>
+int run(int dtype, const void *m, size_t rows, size_t features, size_t ld, ROWS idx, size_t proj, double scale, void *out, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+    Split sp;
+    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is not a power of two in [256, 65536]", rows);
+    if (m == nullptr || out == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: null pointer");
+    if (ld < features) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: leading dimension %zu < features %zu", ld, features);
+    const size_t need = inter_bytes(rows, features);
+    if (workspace == nullptr || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+        return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: a 16-byte aligned workspace of %zu bytes is needed (fewbit_hip_sampled_dct_workspace), got %zu", need, workspace_bytes);
+    if (tiles_of(features) > 32767) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: more than 32767 column tiles");
+    if (proj > 0x7fffffffull) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: more than 2^31 - 1 samples");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    f32x2 *inter = static_cast<f32x2 *>(workspace);
+    const float fs = static_cast<float>(scale);
+    switch (dtype) {
+    case FEWBIT_F32: return launch_rows<FEWBIT_F32, ROWS>(sp, m, features, ld, idx, proj, fs, out, inter, s);
+    case FEWBIT_F16: return launch_rows<FEWBIT_F16, ROWS>(sp, m, features, ld, idx, proj, fs, out, inter, s);
+    default: return launch_rows<FEWBIT_BF16, ROWS>(sp, m, features, ld, idx, proj, fs, out, inter, s);
+    }
 }
 
 }  // namespace dct
@@ -553,23 +639,30 @@ int fewbit_hip_sampled_dct(int dtype, const void *m, size_t rows, size_t feature
                            void *workspace, size_t workspace_bytes, void *stream) {
     if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: unknown dtype %d", dtype);
     if (proj == 0 || features == 0) return FEWBIT_OK;
+    if (idx == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: null pointer");
+    return run(dtype, m, rows, features, ld, RowsInMemory{idx}, proj, scale, out, workspace, workspace_bytes, stream);
+}
+
+int fewbit_hip_sampled_dct_seeded(int dtype, const void *m, size_t rows, size_t features, size_t ld, uint64_t seed, const uint64_t *seed_device, size_t proj,
+                                  double scale, void *out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (dtype != FEWBIT_F32 && dtype != FEWBIT_F16 && dtype != FEWBIT_BF16) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: unknown dtype %d", dtype);
+    if (proj == 0 || features == 0) return FEWBIT_OK;
+    if ((reinterpret_cast<uintptr_t>(seed_device) & 7) != 0) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: the seed word in device memory must be 8-byte aligned");
+    const RowsOfSeed of{sketch::Key{static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)}, reinterpret_cast<const sketch::Key *>(seed_device)};
+    return run(dtype, m, rows, features, ld, of, proj, scale, out, workspace, workspace_bytes, stream);
+}
+
+int fewbit_hip_sampled_rows(uint64_t seed, size_t rows, size_t proj, int64_t *idx) {
     Split sp;
-    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is not a power of two in [256, 65536]", rows);
-    if (m == nullptr || idx == nullptr || out == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: null pointer");
-    if (ld < features) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: leading dimension %zu < features %zu", ld, features);
-    const size_t need = inter_bytes(rows, features);
-    if (workspace == nullptr || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
-        return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: a 16-byte aligned workspace of %zu bytes is needed (fewbit_hip_sampled_dct_workspace), got %zu", need, workspace_bytes);
-    if (tiles_of(features) > 32767) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: more than 32767 column tiles");
-    if (proj > 0x7fffffffull) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: more than 2^31 - 1 samples");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    f32x2 *inter = static_cast<f32x2 *>(workspace);
-    const float fs = static_cast<float>(scale);
-    switch (dtype) {
-    case FEWBIT_F32: return launch_rows<FEWBIT_F32>(sp, m, features, ld, idx, proj, fs, out, inter, s);
-    case FEWBIT_F16: return launch_rows<FEWBIT_F16>(sp, m, features, ld, idx, proj, fs, out, inter, s);
-    default: return launch_rows<FEWBIT_BF16>(sp, m, features, ld, idx, proj, fs, out, inter, s);
+    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_rows: rows = %zu is not a power of two in [256, 65536]", rows);
+    if (proj > 0 && idx == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_rows: null pointer");
+    const sketch::Key key{static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
+    for (size_t q = 0; kPerDraw * q < proj; ++q) {
+        uint32_t w[4];
+        sketch::philox4x32(static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32), 0u, kRowsDomain, key, w);
+        for (int h = 0; h < kPerDraw && kPerDraw * q + h < proj; ++h) idx[kPerDraw * q + h] = static_cast<int64_t>(half_of(w, h) & (rows - 1));
     }
+    return FEWBIT_OK;
 }
 
 }  // extern "C"

@@ -60,6 +60,7 @@
 #include <type_traits>
 
 #include "fewbit_hip.h"
+#include "fewbit_philox.h"
 
 #define FEWBIT_HIDDEN __attribute__((visibility("hidden")))
 
@@ -93,7 +94,6 @@ template <int W, int NH = 1> struct Tile {
 // internal "distribution" of the product kernel: the A fragments were written to memory beforehand (sketch_fragments_kernel)
 constexpr int kFromMemory = 2;
 constexpr int kFragAhead = 4;               // MFMA steps a fragment load runs ahead of its use (registers: 4 dwords per step)
-constexpr int kPhiloxRounds = 10;
 constexpr int kGaussianRounds = 10;         // Philox rounds of the calls that seed the Gaussian streams
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -102,25 +102,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
-// ---- Philox4x32-10 -----------------------------------------------------------------------------------------------------
-struct Key { uint32_t k0, k1; };
-
-template <int ROUNDS = kPhiloxRounds>
-__host__ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, Key key, uint32_t (&out)[4]) {
-    uint32_t k0 = key.k0, k1 = key.k1;
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0, p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
-        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0, n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
-        c1 = static_cast<uint32_t>(p1);
-        c3 = static_cast<uint32_t>(p0);
-        c0 = n0;
-        c2 = n2;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
+// (Philox4x32-10, `Key`: fewbit_philox.h, shared with the sampled cosine transform)
 
 // ---- xoshiro128++ 1.0 (Blackman & Vigna, "Scrambled linear pseudorandom number generators", 2019; public-domain reference
 // xoshiro128plusplus.c) -- 9 one-cycle VALU instructions per 32 bits, against ~85 issue slots for the 128 bits of a Philox call

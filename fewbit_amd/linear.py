@@ -33,7 +33,7 @@ constructor / call signatures; the implementation is this repository's own:
   way into the matrix pipe (accumulation is fp32): a zero-mean relative perturbation of 2^-9 per element under an estimator
   whose own relative noise is ~ sqrt(rows / p).  ``use_native_sketch(False)`` (or ``FEWBIT_SKETCH_NATIVE=0``) selects
   the PyTorch formulation (randn / randint + matmul) instead, and so does an EXPLICIT ``sketch_dtype=torch.float32`` /
-  ``float64`` (a request for products of that precision); host tensors, float64 and the sampled transforms always take it;
+  ``float64`` (a request for products of that precision); host tensors, float64 and 'dft' always take it;
 * the native path can be captured into a hipGraph (``torch.cuda.graph``) after one eager warm-up call per device: while
   the stream is capturing, the seed is a device word that a recorded one-thread kernel re-derives on every replay
   (``_sketch_seed``), so a replayed training step draws a fresh ``S`` each time -- a seed recorded by value would repeat
@@ -41,7 +41,10 @@ constructor / call signatures; the implementation is this repository's own:
 
 The sampled transforms: 'dct' on 2-D GPU tensors of 2^8 .. 2^16 rows runs on this package's kernel pair (``fewbit_hip_sampled_dct``,
 ``fewbit_amd/csrc/fewbit_dct.hip``: a four-step fp32 FFT in LDS that writes only the sampled rows -- the torch.fft formulation costs
-110-120 x the bytes of the result, profiles/r06_sketch_bench.json); other shapes and 'dft' are PyTorch-level code.  SURVEY section 8f, row 4.
+110-120 x the bytes of the result, profiles/r06_sketch_bench.json); other shapes and 'dft' are PyTorch-level code.  Inside the layer the
+sampled rows are, like ``S``, a function of the call's 64-bit seed that the kernel evaluates itself (``fewbit_hip_sampled_dct_seeded``;
+``cabi.sampled_rows(seed, rows, p)`` is the same function on the host): no ``randint`` launch, no saved RNG state, and the layer can be
+captured into a hipGraph.  ``use_native_sketch(False)`` selects torch.fft + randint.  SURVEY section 8f, row 4.
 """
 import contextlib
 import os
@@ -53,7 +56,7 @@ import torch.nn.functional as F
 from .fft import dct
 
 __all__ = ('MATMUL_TYPES', 'projection_dim', 'linear_crs', 'linear_grp', 'linear_randomized', 'LinearCRS', 'LinearGRP',
-           'RandomizedLinear', 'use_native_sketch')
+           'RandomizedLinear', 'use_native_sketch', 'sampled_transform', 'sampled_transform_path')
 
 MATMUL_TYPES = ('dct', 'dft', 'gaussian', 'rademacher')
 
@@ -196,6 +199,19 @@ def _native_sketch(kind: str, mat: torch.Tensor, p: int, seed, scale: float) -> 
     return cabi.sketch(kind, mat, p, seed, scale)
 
 
+def _native_sketch_of(kind: str):
+    return lambda mat, p, seed, scale: _native_sketch(kind, mat, p, seed, scale)
+
+
+def _native_dct(mat: torch.Tensor, p: int, seed, scale: float) -> torch.Tensor:
+    """``scale * dct(mat, dim=0, norm='ortho')[rows(seed)]`` on this package's kernel pair: M is read once, one fp32 intermediate goes
+    out and back, only the p sampled rows are written (the torch formulation materialises the whole transform in fp32 first)"""
+    from . import cabi
+    if mat.stride(1) != 1 or mat.stride(0) < mat.shape[1]:
+        mat = mat.contiguous()
+    return cabi.sampled_dct_seeded(mat, p, seed, scale)
+
+
 _INJECTED: Optional[torch.Tensor] = None
 
 
@@ -243,8 +259,16 @@ def _native_dct_applies(mat: torch.Tensor) -> bool:
 def sampled_transform_path(kind: str, mat: torch.Tensor) -> str:
     """Which code computes the sampled transform ``kind`` ('dct' / 'dft') of ``mat`` (what bench.py prints beside its time)."""
     if kind == 'dct' and _native_dct_applies(mat):
-        return 'gfx950 kernel pair fewbit_hip_sampled_dct (four-step fp32 FFT in LDS, only the sampled rows are written)'
+        return 'gfx950 kernel pair fewbit_hip_sampled_dct (four-step fp32 FFT in LDS, only the sampled rows are written; in the layer: rows of a seed)'
     return 'torch.fft (rocFFT on the GPU): full transform along dim 0 in fp32, then the gather of the sampled rows'
+
+
+def sampled_transform(kind: str, mat: torch.Tensor, p: int, gen: torch.Generator, seed: int = 1234, scale: float = 1.0) -> torch.Tensor:
+    """One estimator product of the layer, ``scale * transform(mat)[p sampled rows]``, on the path ``linear_grp`` takes for this
+    ``kind`` and ``mat`` (what bench.py and tools/ time): the kernel pair with rows of ``seed``, or torch.fft + randint from ``gen``."""
+    if kind == 'dct' and _native_dct_applies(mat):
+        return _native_dct(mat, p, seed, scale)
+    return _sketch(kind, mat, p, gen, scale=scale)
 
 
 def _sketch(kind: str, mat: torch.Tensor, p: int, gen: torch.Generator, sketch_dtype=None, draw_dtype=None, scale: float = 1.0) -> torch.Tensor:
@@ -259,13 +283,6 @@ def _sketch(kind: str, mat: torch.Tensor, p: int, gen: torch.Generator, sketch_d
         return out if scale == 1.0 else out * scale
     idx = _sampled_rows(p, rows, mat, gen)
     if kind == 'dct':
-        if _native_dct_applies(mat):
-            # this package's kernel pair: M is read once, one fp32 intermediate goes out and back, only the p sampled rows are
-            # written (the torch formulation below materialises the whole rows x features transform in fp32 first)
-            from . import cabi
-            if mat.stride(1) != 1 or mat.stride(0) < mat.shape[1]:
-                mat = mat.contiguous()
-            return cabi.sampled_dct(mat, idx, scale)
         out = dct(mat, dim=0, norm='ortho')[idx]
         return out if scale == 1.0 else out * scale
     work = mat if mat.dtype in (torch.float32, torch.float64) else mat.float()
@@ -293,6 +310,16 @@ class _LinearGRP(torch.autograd.Function):
             ctx.p, ctx.kind = p, kind
             ctx.has_bias = bias is not None
             return F.linear(input, weight, bias)
+        if kind == 'dct' and _native_dct_applies(flat):
+            # the sampled rows live nowhere either: a function of the seed that the kernel evaluates itself (no randint launch, no
+            # RNG state to save and replay; while a graph is being captured the seed is a device word, like the dense sketches')
+            ctx.native_seed = _sketch_seed(generator, flat.device)
+            ctx.low = None
+            sketch = _native_dct(flat.detach(), p, ctx.native_seed, rows / p)
+            ctx.save_for_backward(sketch, weight)
+            ctx.p, ctx.kind = p, kind
+            ctx.has_bias = bias is not None
+            return F.linear(input, weight, bias)
         token, gen = _capture_rng(generator, input.device)
         scale = 1.0 / p if kind in ('gaussian', 'rademacher') else rows / p
         draw_dtype = sketch_dtype or flat.dtype
@@ -315,7 +342,7 @@ class _LinearGRP(torch.autograd.Function):
             g2 = flat if flat.dtype in (torch.float32, torch.float16, torch.bfloat16) else flat.float()
             if ctx.low is not None:
                 g2 = g2.to(ctx.low)
-            proj = _native_sketch(ctx.kind, g2, ctx.p, ctx.native_seed, 1.0)
+            proj = (_native_dct if ctx.kind == 'dct' else _native_sketch_of(ctx.kind))(g2, ctx.p, ctx.native_seed, 1.0)
             grad_weight = (proj.to(sketch.dtype).T @ sketch).to(weight.dtype)
         elif ctx.needs_input_grad[1]:
             proj = _sketch(ctx.kind, flat, ctx.p, _replay_rng(ctx.token), ctx.sketch_dtype, ctx.draw_dtype)

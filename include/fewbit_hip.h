@@ -58,8 +58,8 @@ extern "C" {
  *   3: + seeds in device memory (fewbit_hip_sketch_device_seed, fewbit_hip_sketch_next_seed, fewbit_hip_sketch_mix_seed).
  *   4: + fewbit_hip_xoshiro128pp; the Gaussian S redefined on xoshiro128++ streams (the same seed gives another matrix than under 3).
  *   5: FROZEN.  The six fewbit_hip_sketch_tune_* measurement hooks of versions 2-4 are gone from the interface: their settings are
- *      keys of the one remaining hook, fewbit_hip_tune ("sketch_slices", ...); + fewbit_hip_sampled_dct (the reference's 'dct'
- *      estimator).  What is declared below is what a binding needs (tests/test_api.py pins the exported symbol list). */
+ *      keys of the one remaining hook, fewbit_hip_tune ("sketch_slices", ...); + fewbit_hip_sampled_dct, _seeded, fewbit_hip_sampled_rows
+ *      (the reference's 'dct' estimator).  What is declared below is what a binding needs (tests/test_api.py pins the exported symbol list). */
 #define FEWBIT_HIP_ABI_VERSION 5
 
 typedef enum fewbit_status {
@@ -225,6 +225,18 @@ int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features
 size_t fewbit_hip_sampled_dct_workspace(int dtype, size_t rows, size_t features, size_t proj);
 int fewbit_hip_sampled_dct(int dtype, const void *m, size_t rows, size_t features, size_t ld, const int64_t *idx, size_t proj, double scale,
                            void *out, void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the sampled rows a FUNCTION of a 64-bit seed -- no array of row numbers, no launch that draws one (the reference
+ * draws `torch.randint` on the device per call, fewbit/functional/linear.py:113, and replays it in backward from a saved RNG state):
+ *     idx[j] = 16-bit half j % 8 of Philox4x32-10(counter = (j / 8, 0, 0, 3), key = (seed low, seed high))  mod  rows
+ * (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of output word h / 2; rows <= 2^16), uniform with replacement like randint; forward and
+ * backward pass the same seed and sample the same rows.  Every workgroup of the second launch evaluates the function for itself.
+ * seed_device != NULL: the seed is read from that 8-byte aligned DEVICE word when the kernel runs (`seed` is ignored) -- a launch
+ * recorded in a hipGraph then draws fresh rows on every replay, fed by fewbit_hip_sketch_next_seed exactly like
+ * fewbit_hip_sketch_device_seed.  fewbit_hip_sampled_rows: the function on the HOST (idx: proj int64 in host memory; what tests and
+ * a caller that wants the row numbers call). */
+int fewbit_hip_sampled_dct_seeded(int dtype, const void *m, size_t rows, size_t features, size_t ld, uint64_t seed, const uint64_t *seed_device,
+                                  size_t proj, double scale, void *out, void *workspace, size_t workspace_bytes, void *stream);
+int fewbit_hip_sampled_rows(uint64_t seed, size_t rows, size_t proj, int64_t *idx);
 /* Philox4x32-10 on the HOST (the generator behind S; known-answer tests run it without a GPU) */
 void fewbit_hip_philox4x32(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 /* xoshiro128++ 1.0 on the HOST (Blackman & Vigna; the stream generator of the Gaussian sketch, seeded by a Philox call per

@@ -50,7 +50,7 @@ fewbit_hip_describe_quantize_forward fewbit_hip_describe_quantize_backward fewbi
 fewbit_hip_describe_stepwise1_backward fewbit_hip_tune
 fewbit_hip_sketch_workspace fewbit_hip_sketch fewbit_hip_sketch_device_seed fewbit_hip_sketch_next_seed fewbit_hip_sketch_mix_seed
 fewbit_hip_sketch_matrix fewbit_hip_sketch_describe fewbit_hip_philox4x32 fewbit_hip_xoshiro128pp
-fewbit_hip_sampled_dct_workspace fewbit_hip_sampled_dct
+fewbit_hip_sampled_dct_workspace fewbit_hip_sampled_dct fewbit_hip_sampled_dct_seeded fewbit_hip_sampled_rows
 '''.split()
 
 

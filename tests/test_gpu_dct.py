@@ -85,22 +85,26 @@ def test_shapes_without_a_kernel_are_refused_by_name_and_keep_the_library_path()
 
 
 @pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16))
-def test_the_dct_layer_on_the_kernel_equals_the_layer_on_torch_fft(dtype):
-    """linear_grp(matmul='dct') with 512 rows: the same generator state gives the same sampled rows on both paths, so the weight
-    gradient of the native path equals that of the torch.fft formulation (which tests/test_gpu_linear.py pins to the reference's
-    deterministic outputs); forward, input gradient and bias gradient are exact on both"""
+def test_the_dct_layer_on_the_kernel_equals_the_layer_on_torch_fft(dtype, monkeypatch):
+    """linear_grp(matmul='dct') with 512 rows.  The native path samples rows(seed) (seed = one host draw from the generator); the torch.fft
+    formulation is handed the SAME rows (cabi.sampled_rows of that seed), so the weight gradient of the native path equals that of the
+    torch.fft formulation (which tests/test_gpu_linear.py pins to the reference's deterministic outputs); forward, input gradient and
+    bias gradient are exact on both"""
     from fewbit_amd import linear
     g = torch.Generator().manual_seed(3)
     x = torch.randn(4, 128, 40, generator=g).to(dtype).to(DEV)
     w = (torch.randn(24, 40, generator=g) * 0.3).to(dtype).to(DEV)
     b = torch.randn(24, generator=g).to(dtype).to(DEV)
     gy = torch.randn(4, 128, 24, generator=g).to(dtype).to(DEV)
+    seed = int(torch.randint(0, 2**62, (), dtype=torch.int64, generator=torch.Generator().manual_seed(99)).item())     # linear._draw_seed
     grads = {}
     for native in (True, False):
         prev = linear.use_native_sketch(native)
+        if not native:
+            monkeypatch.setattr(linear, '_sampled_rows', lambda p, rows, like, gen: cabi.sampled_rows(seed, rows, p).to(like.device))
         try:
             xi, wi, bi = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
-            gen = torch.Generator(device=DEV).manual_seed(99)
+            gen = torch.Generator().manual_seed(99)
             y = fewbit.functional.linear_grp(xi, wi, bi, proj_dim_ratio=0.25, matmul='dct', generator=gen)
             y.backward(gy)
             grads[native] = (y.detach().float(), xi.grad.float(), bi.grad.float(), wi.grad.float())
@@ -111,6 +115,57 @@ def test_the_dct_layer_on_the_kernel_equals_the_layer_on_torch_fft(dtype):
     gw_n, gw_t = grads[True][3], grads[False][3]
     rel = float((gw_n - gw_t).abs().max() / gw_t.abs().max())
     assert rel <= (2e-5 if dtype == torch.float32 else 3e-2), rel          # bf16: both paths round the sampled rows to 8 bits, at different points
+
+
+def test_the_seeded_transform_is_the_explicit_one_on_the_rows_of_the_seed():
+    """fewbit_hip_sampled_dct_seeded(seed) == fewbit_hip_sampled_dct(idx = fewbit_hip_sampled_rows(seed)), bit for bit: every row split, the
+    LDS list and its overflow (p >> the list: every workgroup walks the function group by group), the batched tail (p > 4096), p not a
+    multiple of four, the seed by value and as a device word"""
+    cases = [(256, 40, 9000), (256, 64, 1), (512, 66, 20001), (1024, 7, 300), (2048, 33, 2047), (4096, 64, 5000), (8192, 96, 1638),
+             (16384, 768, 3276), (16384, 130, 16387), (32768, 64, 6553), (65536, 32, 13107)]
+    for n, (rows, features, p) in enumerate(cases):
+        dtype = (torch.bfloat16, torch.float32, torch.float16)[n % 3]
+        x = torch.randn(rows, features, generator=torch.Generator().manual_seed(n)).to(dtype).to(DEV)
+        seed = 0x9e3779b97f4a7c15 * (n + 1) & 0xffffffffffffffff
+        idx = cabi.sampled_rows(seed, rows, p).to(DEV)
+        want = cabi.sampled_dct(x, idx, 0.5)
+        assert torch.equal(cabi.sampled_dct_seeded(x, p, seed, 0.5), want), (rows, features, p)
+        # (ctypes hands the value over as an unsigned 64-bit word: the int64 tensor holds the same bits)
+        word = torch.tensor([seed - (1 << 64) if seed >= 1 << 63 else seed], dtype=torch.int64, device=DEV)
+        assert torch.equal(cabi.sampled_dct_seeded(x, p, word, 0.5), want), (rows, features, p)
+        assert float(want.float().abs().max()) > 0
+
+
+def test_a_captured_dct_layer_step_samples_fresh_rows_on_every_replay(monkeypatch):
+    """The layer with matmul='dct' inside a hipGraph (the reference reads the RNG state back per call and cannot be captured): the recorded
+    seed kernel derives the seed of replay r from (the host draw made at capture time, the device counter); the replayed weight gradient
+    equals the explicit product on cabi.sampled_rows of that seed, backward meets forward's rows, replays differ"""
+    from fewbit_amd import linear
+    lin = fewbit.RandomizedLinear(64, 32, proj_dim=96, matmul='dct', bias=False, device=DEV)
+    x = torch.randn(512, 64, device=DEV, requires_grad=True)
+    wgt = torch.randn(512, 32, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.autograd.grad((lin(x) * wgt).sum(), lin.weight)
+    torch.cuda.current_stream().wait_stream(side)
+    base = 0x7654321
+    monkeypatch.setattr(linear, '_draw_seed', lambda generator: base)
+    counter = linear._replay_counter(torch.device(DEV))
+    c0 = int(counter)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gw, = torch.autograd.grad((lin(x) * wgt).sum(), lin.weight)
+    seen = []
+    for r in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(counter) == c0 + r + 1
+        idx = cabi.sampled_rows(cabi.mix_sketch_seed(base, c0 + r), 512, 96).to(DEV)
+        want = cabi.sampled_dct(wgt, idx).T @ cabi.sampled_dct(x.detach(), idx, 512 / 96)
+        assert torch.allclose(gw, want, rtol=1e-4, atol=1e-3), (r, float((gw - want).abs().max()))
+        seen.append(gw.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
 
 
 def _fuzz_cases(n, seed):

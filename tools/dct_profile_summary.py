@@ -27,7 +27,8 @@ for line in open(os.path.join(raw, 'run.log'), errors='replace'):
 if run is None:
     print(open(os.path.join(raw, 'run.log'), errors='replace').read()[-3000:])
     raise SystemExit('tools/dct_run.py printed no line under the profiler')
-print('# tools/profile_dct.sh: rocprofv3 --kernel-trace --stats -- python3 tools/dct_run.py', run['rows'], run['features'], run['proj'], run['dtype'], run['reps'], run['settle_ms'])
+print('# tools/profile_dct.sh: rocprofv3 --kernel-trace --stats -- python3 tools/dct_run.py', run['rows'], run['features'], run['proj'], run['dtype'], run['reps'], run['settle_ms'],
+      {'fewbit_hip_sampled_dct_seeded': 'seeded', 'fewbit_hip_sampled_dct': 'explicit'}.get(run.get('what'), ''), f"   [{run.get('what')}]")
 print(f"# {run['settle_calls']} settling calls precede the {run['reps']} timed calls; the table averages each kernel's last {reps} dispatches")
 per = collections.defaultdict(list)
 with open(find('trace', '*kernel_trace.csv'), newline='') as f:

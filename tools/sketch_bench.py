@@ -52,7 +52,7 @@ def sampled_transforms(m, proj):
     floor_bytes = (rows + proj) * features * m.element_size()
     rec = {'byte_floor_bytes': floor_bytes, 'byte_floor_us_at_8TBs': round(floor_bytes / 8e6, 2)}
     for kind in ('dct', 'dft'):
-        us = timed(lambda: linear._sketch(kind, m, proj, gen), reps=20)
+        us = timed(lambda: linear.sampled_transform(kind, m, proj, gen), reps=20)
         rec[kind] = {'us': round(us, 1), 'x_byte_floor': round(us / (floor_bytes / 8e6), 1), 'path': linear.sampled_transform_path(kind, m)}
     return rec
 
