@@ -186,5 +186,25 @@ int main() {
         }
     }
     std::printf("  sampled DCT of %zu x %zu, %zu rows picked (workspace %zu bytes): mismatches %zu\n", drows, dfeats, dproj, dct_ws_bytes, bad_dct);
-    return (bad_code || bad_gx || bad_y || bad_sketch || bad_seed || bad_dct) ? 1 : 0;
+    // ---- the same with the rows a function of a seed: equals the explicit call on fewbit_hip_sampled_rows(seed), bit for bit ----
+    int64_t seeded_picks[dproj];
+    std::vector<float> dseeded(dproj * dfeats);
+    const uint64_t dct_seed = 0x5eed0f00dull;
+    rc = fewbit_hip_sampled_rows(dct_seed, drows, dproj, seeded_picks);
+    HIP_OK(hipMemcpyAsync(didx, seeded_picks, sizeof seeded_picks, hipMemcpyHostToDevice, stream));
+    if (rc == FEWBIT_OK) rc = fewbit_hip_sampled_dct(FEWBIT_F32, ddm, drows, dfeats, dfeats, didx, dproj, 2.0, ddout, ddws, dct_ws_bytes, stream);
+    HIP_OK(hipMemcpyAsync(dgot.data(), ddout, dgot.size() * 4, hipMemcpyDeviceToHost, stream));
+    if (rc == FEWBIT_OK) rc = fewbit_hip_sampled_dct_seeded(FEWBIT_F32, ddm, drows, dfeats, dfeats, dct_seed, nullptr, dproj, 2.0, ddout, ddws, dct_ws_bytes, stream);
+    if (rc != FEWBIT_OK) {
+        std::fprintf(stderr, "sampled_dct_seeded error %d: %s\n", rc, fewbit_hip_last_error());
+        return 3;
+    }
+    HIP_OK(hipMemcpyAsync(dseeded.data(), ddout, dseeded.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    size_t bad_rows = 0;
+    for (size_t e = 0; e < dseeded.size(); ++e) bad_rows += std::memcmp(&dseeded[e], &dgot[e], 4) != 0;
+    std::printf("  rows of seed %#llx: %lld %lld %lld %lld %lld; seeded call against the explicit one: mismatches %zu\n", static_cast<unsigned long long>(dct_seed),
+                static_cast<long long>(seeded_picks[0]), static_cast<long long>(seeded_picks[1]), static_cast<long long>(seeded_picks[2]),
+                static_cast<long long>(seeded_picks[3]), static_cast<long long>(seeded_picks[4]), bad_rows);
+    return (bad_code || bad_gx || bad_y || bad_sketch || bad_seed || bad_dct || bad_rows) ? 1 : 0;
 }

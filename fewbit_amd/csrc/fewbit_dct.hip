@@ -340,7 +340,7 @@ constexpr int kAhead = 16;                  // idx entries per thread requested 
 
 // Where the sampled rows come from.  RowsInMemory: the caller's int64 array.  RowsOfSeed: a FUNCTION of a 64-bit seed,
 //     idx[j] = 16-bit half j % 8 of the 128 bits of Philox4x32-10(counter = (j / 8, 0, 0, 3), key = seed)  mod  rows      (rows <= 2^16)
-// (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of word h / 2; uniform, with replacement, like randint)
+// (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of word h / 2; uniform, with replacement, like the reference's T.multinomial of equal weights)
 // which every workgroup evaluates for itself while its tile travels: no array, no launch that draws one, nothing to keep for backward but
 // the seed -- and, with the seed read from device memory, a recorded launch draws fresh rows on every replay (fewbit_sketch.hip, same scheme).
 constexpr uint32_t kRowsDomain = 3u;        // counter word 3 (0 and 2: the dense sketches)

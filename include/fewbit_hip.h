@@ -225,10 +225,11 @@ int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features
 size_t fewbit_hip_sampled_dct_workspace(int dtype, size_t rows, size_t features, size_t proj);
 int fewbit_hip_sampled_dct(int dtype, const void *m, size_t rows, size_t features, size_t ld, const int64_t *idx, size_t proj, double scale,
                            void *out, void *workspace, size_t workspace_bytes, void *stream);
-/* The same with the sampled rows a FUNCTION of a 64-bit seed -- no array of row numbers, no launch that draws one (the reference
- * draws `torch.randint` on the device per call, fewbit/functional/linear.py:113, and replays it in backward from a saved RNG state):
+/* The same with the sampled rows a FUNCTION of a 64-bit seed -- no array of row numbers, no launch that draws one (the reference draws
+ * `T.multinomial` of uniform probabilities with replacement per call, fewbit/functional/linear.py:114-119, and draws it again in
+ * backward from the generator state it saved, :105,153,159-160,176-181):
  *     idx[j] = 16-bit half j % 8 of Philox4x32-10(counter = (j / 8, 0, 0, 3), key = (seed low, seed high))  mod  rows
- * (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of output word h / 2; rows <= 2^16), uniform with replacement like randint; forward and
+ * (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of output word h / 2; rows <= 2^16), uniform with replacement like that draw; forward and
  * backward pass the same seed and sample the same rows.  Every workgroup of the second launch evaluates the function for itself.
  * seed_device != NULL: the seed is read from that 8-byte aligned DEVICE word when the kernel runs (`seed` is ignored) -- a launch
  * recorded in a hipGraph then draws fresh rows on every replay, fed by fewbit_hip_sketch_next_seed exactly like
