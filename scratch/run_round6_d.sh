@@ -9,7 +9,7 @@ for v in ${VARIANTS:-prod}; do
   for shape in "16384 768 3276 bf16" "16384 3072 3276 bf16" "16384 768 3276 f32"; do
     if [ $v = prod ]; then unset FEWBIT_HIP_LIB; else export FEWBIT_HIP_LIB=$PWD/scratch/libfewbit_hip_dct_$v.so; fi
     RAW=gpurun_out/prof_dctvar_$v; rm -rf $RAW
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o d -- python3 tools/dct_run.py $shape 100 30 > $RAW.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o d -- python3 tools/dct_run.py $shape 100 30 ${MODE:-explicit} > $RAW.log 2>&1
     python3 - "$RAW" "$v" "$shape" >> $OUT <<'PY'
 import csv, glob, sys
 raw, v, shape = sys.argv[1:4]

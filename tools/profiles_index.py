@@ -32,6 +32,8 @@ ROWS = [
     ('r06_dct_rocprof_*.txt', 'tools/profile_dct.sh: settled kernel durations and PMC traffic of the sampled-DCT kernel pair', f'{D} 5, 7.3'),
     ('r06_dct_large_rows.txt', 'the kernel pair and the torch.fft formulation at 32768 and 65536 rows', f'{D} 7.3'),
     ('r06_dct_variants.txt', 'the sampled-DCT variants measured in round 6, phases compiled out, per-workgroup timeline', f'{D} 7.5'),
+    ('r06_dct_rounds.txt', 'both DCT passes against the number of workgroups (features swept): a fixed 7-9 us plus 7.5 ns per workgroup', f'{D} 7.5'),
+    ('r06_dct_stagger.txt|r06_dct_fused_upper_bound.txt|r06_dct_inter16.txt', 'DCT experiments not kept: staggered starts, both passes in one launch (timing only), a bf16 intermediate', 'EXPERIMENTS.md'),
     ('r0?_roberta_table_*.json', "tools/roberta_bench.py --table: the reference README's RoBERTa table per dtype and estimator", f'{D} 7.4'),
     ('r0?_roberta_ab_fp32.txt|r0?_roberta_ab_bf16.txt|r0?_roberta_randomized_insitu*.json', 'the randomized RoBERTa step, arms interleaved in one process; its GPU time by kernel class', f'{D} 7.4'),
     ('r06_roberta_overlap_ab.txt', 'the estimators on a side stream beside the layer GEMMs: slower, not kept', f'{E} round 6'),
