@@ -184,7 +184,8 @@ def _fuzz_cases(n, seed):
 def test_sampled_dct_fuzz_against_float64_on_the_device():
     """40 random cases (FEWBIT_DCT_FUZZ_CASES=N widens the sweep): every supported row count, ragged / odd / tiny feature counts (edge
     tiles, a last complex column with no partner), p from 1 to rows, all three dtypes, strided inputs, scales; expected = the float64
-    DCT-II of the same data computed by torch.fft on the device.  Plus the two list regimes of pass B forced on purpose: more samples of
+    DCT-II of the same data computed by torch.fft on the device; per case also fewbit_hip_sampled_dct_seeded against the explicit call on
+    fewbit_hip_sampled_rows of the same seed (bit-equal).  Plus the two list regimes of pass B forced on purpose: more samples of
     one residue pair than the LDS list holds (the group-by-group fallback), and p > 4096 (the batched tail of idx)."""
     import os
     n = int(os.environ.get('FEWBIT_DCT_FUZZ_CASES', '40'))
@@ -203,3 +204,6 @@ def test_sampled_dct_fuzz_against_float64_on_the_device():
         tol = REL[dtype] * want.abs() + 3e-6 * float(want.abs().max()) + 1e-30
         assert bool((err <= tol).all()), (rows, features, p, dtype, pad, float((err / tol).max()))
         assert not torch.isnan(wide).any()
+        # the rows as a function of a seed: the same bits as the explicit call on those rows
+        of_seed = cabi.sampled_rows(seed, rows, p).to(DEV)
+        assert torch.equal(cabi.sampled_dct_seeded(x, p, seed, scale), cabi.sampled_dct(x, of_seed, scale)), (rows, features, p, dtype, pad)
