@@ -38,6 +38,9 @@
 //               requested first, unconditionally, so that testing it never waits --, transforms along n2, collects the samples of its
 //               two residue classes in an LDS list (one atomic per thread) and serves them 16 at a time (one per group of 16 lanes;
 //               e^{-i pi k / 2N} from two small tables, no transcendental per sample).
+//   idx         an int64 array of the caller (fewbit_hip_sampled_dct, RowsInMemory) or a FUNCTION of a 64-bit seed that every pass-B
+//               workgroup evaluates for itself (fewbit_hip_sampled_dct_seeded, RowsOfSeed: eight row numbers per Philox4x32-10 call) --
+//               what the layer uses: no array, no launch that draws one, a seed to keep for backward, capturable into a hipGraph.
 //   traffic     M once + 2 x rows x features x 4 B of intermediate + the p sampled rows: 16384 x 768 bf16, p = 3276: 25 + 2 x 50 + 5 MB.
 // Measured and not kept (round 6, profiles/r06_dct_variants.txt): 64 KiB tiles with 512-thread workgroups (same time); persistent
 // workgroups that request the next tile before transforming the current one (the radix-16 butterfly leaves no registers for it: spills).
