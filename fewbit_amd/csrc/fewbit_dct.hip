@@ -1,7 +1,7 @@
 // fewbit_dct.hip -- the sampled cosine transform of the randomized linear layers (the reference's 'dct' estimator)
 // on gfx950:
 //
-//     out[j][:] = scale * DCT-II_ortho(M, along the rows)[idx[j]][:]        M: rows x features (bf16 / fp16 / fp32), rows = 2^m
+//     out[j][:] = scale * DCT-II_ortho(M, along the rows)[idx[j]][:]        M: rows x features (bf16 / fp16 / fp32), rows = 2^m or 3 x 2^m
 //
 // What it replaces in the reference (skolai/fewbit): `dct(input_view, dim=0, norm='ortho')[proj, ...]` in LinearGRPFunc.forward
 // (fewbit/functional/linear.py:113-122) and the same on the gradient in .backward (:174-183); dct = fewbit/fft.py:10-43 (shuffle,
@@ -15,7 +15,7 @@
 //      V = DFT_N(v):  DCT-II(x)[k] = Re(2 e^{-i pi k / 2N} V[k]).
 //   2. Two real columns per complex transform: M is row-major, so features (2c, 2c+1) of a row ARE a complex number in memory;
 //      Z = DFT_N(v_2c + i v_2c+1) gives V_2c[k] = (Z[k] + conj Z[N-k]) / 2 and V_2c+1[k] = (Z[k] - conj Z[N-k]) / 2i.
-//   3. Four-step DFT, N = N1 x N2 (each 16 .. 256; 16384 = 128 x 128, 65536 = 256 x 256), n = N2 n1 + n2, k = k1 + N1 k2:
+//   3. Four-step DFT, N = N1 x N2 (each 16 .. 256; 16384 = 128 x 128, 65536 = 256 x 256; 12288 = 128 x 96: a factor 3 goes to N2), n = N2 n1 + n2, k = k1 + N1 k2:
 //          pass A   for every n2:  A[k1][n2] = W_N^{n2 k1} * sum_{n1} z[N2 n1 + n2] W_N1^{n1 k1}        (length-N1 DFTs over rows N2 apart)
 //          pass B   for every k1:  Z[k1 + N1 k2] = sum_{n2} A[k1][n2] W_N2^{n2 k2}                       (length-N2 DFTs, contiguous)
 //      Pass B never writes Z: the workgroup that owns the residues k1 and N1 - k1 holds Z[k] AND Z[N-k] for every k of those
@@ -27,7 +27,7 @@
 //               Lanes run along the 32 entries of a point: every LDS access of a half-wave is 256 contiguous bytes (all 64 banks once,
 //               ds_read/write_b64: conflict-free), every twiddle is half-wave-uniform (an LDS broadcast).
 //   FFT         in place, decimation in frequency, TWO stages at L = 128 (radix 16 then radix 8, each butterfly entirely in the
-//               registers of one thread; 64 = 8 x 8, 32 = 8 x 4, 16 = 16), one barrier per stage; the result stands in digit-reversed
+//               registers of one thread; 64 = 8 x 8, 32 = 8 x 4, 16 = 16; 96 = 3 x 8 x 4, 192 = 3 x 8 x 8, 48 = 3 x 16), one barrier per stage; the result stands in digit-reversed
 //               positions (pos_to_freq / freq_to_pos), which costs nothing: both passes address their outputs through the map.
 //   pass A      workgroup (b, t): the rows n = N2 n1 + b of column tile t (32 complex columns = 64 features).  Loads N1 row segments
 //               (128 B of bf16: full cache lines, 16 B per lane, issued back to back), converts to fp32, transforms along n1,
@@ -80,8 +80,14 @@ __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) {
     return f32x2{__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
 }
 __device__ __forceinline__ f32x2 mul_mi(f32x2 a) { return f32x2{a.y, -a.x}; }                                   // a * (-i)
-// e^{-2 pi i num / den}, den a power of two (num / den is exact in fp32)
+// e^{-2 pi i num / den}: den a power of two (num / den is exact in fp32), or 3 x a power of two (the angle in double, then rounded;
+// `den` is a template constant at every call site: the branch folds)
 __device__ __forceinline__ f32x2 unit(int num, int den) {
+    if ((den & (den - 1)) != 0) {
+        double s, c;
+        sincospi(-2.0 * static_cast<double>(num) / static_cast<double>(den), &s, &c);
+        return f32x2{static_cast<float>(c), static_cast<float>(s)};
+    }
     float s, c;
     sincospif(-2.0f * static_cast<float>(num) / static_cast<float>(den), &s, &c);
     return f32x2{c, s};
@@ -102,9 +108,16 @@ __device__ __forceinline__ void dft4(f32x2 &a0, f32x2 &a1, f32x2 &a2, f32x2 &a3)
     a2 = t0 - t2;
     a3 = t1 - t3;
 }
+constexpr float kH3 = 0.86602540378443865f;                   // sqrt(3) / 2
 template <int R> __device__ __forceinline__ void dft(f32x2 (&x)[R]) {
     if constexpr (R == 2) {
         dft2(x[0], x[1]);
+    } else if constexpr (R == 3) {
+        // W3 = -1/2 - i sqrt(3)/2:  y1, y2 = x0 - (x1 + x2) / 2  +-  (-i) (sqrt(3) / 2) (x1 - x2)
+        const f32x2 t = x[1] + x[2], d = mul_mi(x[1] - x[2]) * kH3, m = x[0] - t * 0.5f;
+        x[0] = x[0] + t;
+        x[1] = m + d;
+        x[2] = m - d;
     } else if constexpr (R == 4) {
         dft4(x[0], x[1], x[2], x[3]);
     } else if constexpr (R == 8) {
@@ -122,7 +135,7 @@ template <int R> __device__ __forceinline__ void dft(f32x2 (&x)[R]) {
         x[2] = e2 + t2; x[6] = e2 - t2;
         x[3] = e3 + t3; x[7] = e3 - t3;
     } else {
-        static_assert(R == 16, "radix 2, 4, 8 or 16");
+        static_assert(R == 16, "radix 2, 3, 4, 8 or 16");
         // j = 4a + b, q = p + 4 q':  y[p + 4 q'] = sum_b W16^{bp} W4^{b q'} sum_a x[4a + b] W4^{ap}
         dft4(x[0], x[4], x[8], x[12]);
         dft4(x[1], x[5], x[9], x[13]);
@@ -154,8 +167,11 @@ template <int R> __device__ __forceinline__ void dft(f32x2 (&x)[R]) {
     }
 }
 
-// radix of the first stage of a block of length `len`: 256 = 16 x 16, 128 = 16 x 8, 64 = 8 x 8, 32 = 8 x 4, 16 = 16
-__host__ __device__ constexpr int first_radix(int len) { return len >= 128 ? 16 : len == 64 ? 8 : len == 32 ? 8 : len == 16 ? 16 : len == 8 ? 8 : len == 4 ? 4 : 2; }
+// radix of the first stage of a block of length `len`: 256 = 16 x 16, 128 = 16 x 8, 64 = 8 x 8, 32 = 8 x 4, 16 = 16; a factor 3
+// (48 = 3 x 16, 96 = 3 x 8 x 4, 192 = 3 x 8 x 8) goes first
+__host__ __device__ constexpr int first_radix(int len) {
+    return len % 3 == 0 ? 3 : len >= 128 ? 16 : len == 64 ? 8 : len == 32 ? 8 : len == 16 ? 16 : len == 8 ? 8 : len == 4 ? 4 : 2;
+}
 
 // position P (after the in-place DIF stages) -> frequency k.  Stage i with radix r_i on blocks of length L_i leaves digit q_i
 // (k = q_1 + r_1 q_2 + r_1 r_2 q_3 + ...) in sub-block q_i: P = sum q_i L_i / r_i.
@@ -342,14 +358,21 @@ constexpr int kListCap = 512;               // samples a workgroup serves from i
 constexpr int kAhead = 16;                  // idx entries per thread requested together with the tile: all of idx for p <= 4096
 
 // Where the sampled rows come from.  RowsInMemory: the caller's int64 array.  RowsOfSeed: a FUNCTION of a 64-bit seed,
-//     idx[j] = 16-bit half j % 8 of the 128 bits of Philox4x32-10(counter = (j / 8, 0, 0, 3), key = seed)  mod  rows      (rows <= 2^16)
-// (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of word h / 2; uniform, with replacement, like the reference's T.multinomial of equal weights)
+//     rows = 2^k:      idx[j] = 16-bit half j % 8 of the 128 bits of Philox4x32-10(counter = (j / 8, 0, 0, 3), key = seed)  mod  rows
+//                      (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of word h / 2)
+//     rows = 3 x 2^k:  idx[j] = (word j % 4 of Philox4x32-10(counter = (j / 4, 0, 0, 3), key = seed)  x  rows)  >>  32
+// (uniform -- in the second case up to rows / 2^32 --, with replacement, like the reference's T.multinomial of equal weights)
 // which every workgroup evaluates for itself while its tile travels: no array, no launch that draws one, nothing to keep for backward but
 // the seed -- and, with the seed read from device memory, a recorded launch draws fresh rows on every replay (fewbit_sketch.hip, same scheme).
 constexpr uint32_t kRowsDomain = 3u;        // counter word 3 (0 and 2: the dense sketches)
-constexpr int kPerDraw = 8;                 // row numbers per Philox call
-static_assert(kAhead % kPerDraw == 0 && 8 % kPerDraw == 0, "whole Philox calls per batch");
-__host__ __device__ __forceinline__ int half_of(const uint32_t (&w)[4], int h) { return static_cast<int>((w[h / 2] >> (16 * (h % 2))) & 0xffffu); }
+__host__ __device__ constexpr bool power_of_two(size_t n) { return (n & (n - 1)) == 0; }
+__host__ __device__ constexpr int per_draw(bool pow2) { return pow2 ? 8 : 4; }          // row numbers per Philox call
+static_assert(kAhead % per_draw(true) == 0 && 8 % per_draw(true) == 0 && kAhead % per_draw(false) == 0 && 8 % per_draw(false) == 0, "whole Philox calls per batch");
+// row number h of one Philox call (POW2: not yet reduced mod rows -- the caller masks)
+template <bool POW2> __host__ __device__ __forceinline__ int drawn_row(const uint32_t (&w)[4], int h, uint32_t rows) {
+    if constexpr (POW2) return static_cast<int>((w[h / 2] >> (16 * (h % 2))) & 0xffffu);
+    else return static_cast<int>((static_cast<uint64_t>(w[h]) * rows) >> 32);
+}
 struct RowsInMemory {
     static constexpr bool kSeeded = false;
     const int64_t *idx;
@@ -364,6 +387,8 @@ template <int DT, int N1, int N2, typename ROWS>
 __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, ROWS rows, size_t proj, size_t features,
                                                                   float scale, void *__restrict__ out) {
     constexpr int N = N1 * N2, kCoarse = coarse_entries(N), kThreads = kThreadsB, kSlots = kThreads / C, kGroups = kThreads / CB;
+    constexpr bool kPow2 = power_of_two(N);
+    constexpr int kPerDraw = per_draw(kPow2);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     f32x2 *tile = reinterpret_cast<f32x2 *>(lds_raw);                 // [N2][2][CB]
     f32x2 *tw = tile + N2 * 2 * CB;                                   // W_N2^m
@@ -376,7 +401,7 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
     // the row numbers this thread will test go out FIRST (vmcnt counts in order: looking at them later does not wait for the tile).
     // Unconditional loads -- the index is clamped, the verdict is a select -- so that hipcc issues them back to back instead of one
     // per branch with a wait each (6 us of a 22 us launch); the low dword of an int64 in [0, N) is the number
-    // (rows of a seed: entry a of a batch is half a % 8 of Philox call (a / 8) * kThreads + tid -- computed below, behind the tile's requests)
+    // (rows of a seed: entry a of a batch is number a % kPerDraw of Philox call (a / kPerDraw) * kThreads + tid -- computed below, behind the tile's requests)
     sketch::Key key{0u, 0u};
     if constexpr (ROWS::kSeeded) key = rows.device != nullptr ? *rows.device : rows.value;      // (one scalar load)
     auto entry = [&](size_t first, int a) -> size_t {                 // index into idx of entry a of the batch that starts at call / entry `first`
@@ -406,7 +431,9 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
     }
     // a sample belongs to this workgroup when its residue k % N1 is one of the two it holds; -1 = not ours
     auto mine = [&](int word, size_t i) -> int {
-        const int kk = word & (N - 1), k1 = kk % N1;
+        // (an explicit idx is reduced to [0, N) whatever it holds; the rows of a seed are below N already unless N is a power of two)
+        const int kk = kPow2 ? word & (N - 1) : ROWS::kSeeded ? word : static_cast<int>(static_cast<unsigned>(word) % static_cast<unsigned>(N));
+        const int k1 = kk % N1;
         return (i < proj && (k1 == k1a || k1 == k1b)) ? kk : -1;
     };
     for (int m = tid; m < N2; m += kThreads) tw[m] = unit(m, N2);
@@ -419,7 +446,7 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
             uint32_t w[4];
             draw(static_cast<size_t>(d) * kThreads + tid, w);
 #pragma unroll
-            for (int h = 0; h < kPerDraw; ++h) kraw[kPerDraw * d + h] = half_of(w, h);
+            for (int h = 0; h < kPerDraw; ++h) kraw[kPerDraw * d + h] = drawn_row<kPow2>(w, h, N);
         }
     }
     __syncthreads();                                                  // (the counter is zero for everybody; the tile is still on its way)
@@ -446,15 +473,18 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
         }
     }
     // (p > 4096: the rest of idx in batches of eight unconditional requests per thread -- eight latencies overlap instead of following one another)
-    // (rows of a seed: `first` counts Philox calls, eight entries each -- one call per thread and batch)
+    // (rows of a seed: `first` counts Philox calls, kPerDraw entries each)
     constexpr size_t kPerCall = ROWS::kSeeded ? kPerDraw : 1;
     for (size_t first = static_cast<size_t>(kAhead) * kThreads / kPerCall; first * kPerCall < proj; first += 8 * kThreads / kPerCall) {
         int more[8];
         if constexpr (ROWS::kSeeded) {
-            uint32_t w[4];
-            draw(first + tid, w);
 #pragma unroll
-            for (int h = 0; h < kPerDraw; ++h) more[h] = half_of(w, h);
+            for (int d = 0; d < 8 / kPerDraw; ++d) {
+                uint32_t w[4];
+                draw(first + static_cast<size_t>(d) * kThreads + tid, w);
+#pragma unroll
+                for (int h = 0; h < kPerDraw; ++h) more[kPerDraw * d + h] = drawn_row<kPow2>(w, h, N);
+            }
         } else {
 #pragma unroll
             for (int a = 0; a < 8; ++a) more[a] = raw(entry(first, a));
@@ -532,7 +562,7 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
             draw(q, w);
 #pragma unroll
             for (int h = 0; h < kPerDraw; ++h) {
-                const int k = mine(half_of(w, h), kPerDraw * q + h);
+                const int k = mine(drawn_row<kPow2>(w, h, N), kPerDraw * q + h);
                 if (k >= 0) write_row(k, kPerDraw * q + h);
             }
         }
@@ -546,13 +576,24 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 struct Split { int n1, n2; };
-// rows = N1 x N2 with 16 <= N2 <= N1 <= 256: 256 .. 65536 rows
+// rows = N1 x N2.  2^8 .. 2^16: 16 <= N2 <= N1 <= 256, both powers of two.  3 x 2^8 .. 3 x 2^14 (768 .. 49152): the factor 3 goes to
+// the second pass, N2 = 48 / 96 / 192 (N1 stays a power of two: residues and digit maps of pass A, the k % N1 of pass B)
 bool split_rows(size_t rows, Split &s) {
-    if (rows < 256 || rows > 65536 || (rows & (rows - 1)) != 0) return false;
+    if (rows < 256 || rows > 65536) return false;
+    const bool three = rows % 3 == 0;
+    const size_t two = three ? rows / 3 : rows;
+    if (!power_of_two(two) || (three && two < 256)) return false;
     int bits = 0;
-    while ((static_cast<size_t>(1) << bits) < rows) ++bits;
-    s.n1 = 1 << ((bits + 1) / 2);
-    s.n2 = 1 << (bits / 2);
+    while ((static_cast<size_t>(1) << bits) < two) ++bits;
+    if (!three) {
+        s.n1 = 1 << ((bits + 1) / 2);
+        s.n2 = 1 << (bits / 2);
+        return true;
+    }
+    // 3 x 2^bits, bits = 8 .. 14:  16 x 48, 32 x 48, 32 x 96, 64 x 96, 128 x 96, 128 x 192, 256 x 192
+    static const int n1_of[7] = {16, 32, 32, 64, 128, 128, 256};
+    s.n1 = n1_of[bits - 8];
+    s.n2 = static_cast<int>(rows / static_cast<size_t>(s.n1));
     return true;
 }
 size_t tiles_of(size_t features) { return (features + kFeatures - 1) / kFeatures; }
@@ -597,6 +638,7 @@ int launch_rows(Split sp, const void *m, size_t features, size_t ld, ROWS idx, s
     if (sp.n1 == A && sp.n2 == B) return launch<DT, A, B, ROWS>(m, features, ld, idx, proj, scale, out, inter, s);
     FB_DCT_CASE(16, 16) FB_DCT_CASE(32, 16) FB_DCT_CASE(32, 32) FB_DCT_CASE(64, 32) FB_DCT_CASE(64, 64) FB_DCT_CASE(128, 64) FB_DCT_CASE(128, 128)
     FB_DCT_CASE(256, 128) FB_DCT_CASE(256, 256)
+    FB_DCT_CASE(16, 48) FB_DCT_CASE(32, 48) FB_DCT_CASE(32, 96) FB_DCT_CASE(64, 96) FB_DCT_CASE(128, 96) FB_DCT_CASE(128, 192) FB_DCT_CASE(256, 192)
 #undef FB_DCT_CASE
     return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: no kernel for %d x %d rows", sp.n1, sp.n2);
 }
@@ -605,7 +647,7 @@ template <typename ROWS>
 int run(int dtype, const void *m, size_t rows, size_t features, size_t ld, ROWS idx, size_t proj, double scale, void *out, void *workspace,
                        size_t workspace_bytes, void *stream) {
     Split sp;
-    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is not a power of two in [256, 65536]", rows);
+    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is neither 2^k (256 .. 65536) nor 3 x 2^k (768 .. 49152)", rows);
     if (m == nullptr || out == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: null pointer");
     if (ld < features) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: leading dimension %zu < features %zu", ld, features);
     const size_t need = inter_bytes(rows, features);
@@ -657,13 +699,17 @@ int fewbit_hip_sampled_dct_seeded(int dtype, const void *m, size_t rows, size_t 
 
 int fewbit_hip_sampled_rows(uint64_t seed, size_t rows, size_t proj, int64_t *idx) {
     Split sp;
-    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_rows: rows = %zu is not a power of two in [256, 65536]", rows);
+    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_rows: rows = %zu is neither 2^k (256 .. 65536) nor 3 x 2^k (768 .. 49152)", rows);
     if (proj > 0 && idx == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_rows: null pointer");
     const sketch::Key key{static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
-    for (size_t q = 0; kPerDraw * q < proj; ++q) {
+    const bool pow2 = power_of_two(rows);
+    const size_t per = per_draw(pow2);
+    for (size_t q = 0; per * q < proj; ++q) {
         uint32_t w[4];
         sketch::philox4x32(static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32), 0u, kRowsDomain, key, w);
-        for (int h = 0; h < kPerDraw && kPerDraw * q + h < proj; ++h) idx[kPerDraw * q + h] = static_cast<int64_t>(half_of(w, h) & (rows - 1));
+        for (size_t h = 0; h < per && per * q + h < proj; ++h)
+            idx[per * q + h] = pow2 ? static_cast<int64_t>(drawn_row<true>(w, static_cast<int>(h), 0u) & (rows - 1))
+                                    : static_cast<int64_t>(drawn_row<false>(w, static_cast<int>(h), static_cast<uint32_t>(rows)));
     }
     return FEWBIT_OK;
 }
