@@ -199,10 +199,6 @@ def _native_sketch(kind: str, mat: torch.Tensor, p: int, seed, scale: float) -> 
     return cabi.sketch(kind, mat, p, seed, scale)
 
 
-def _native_sketch_of(kind: str):
-    return lambda mat, p, seed, scale: _native_sketch(kind, mat, p, seed, scale)
-
-
 def _native_dct(mat: torch.Tensor, p: int, seed, scale: float) -> torch.Tensor:
     """``scale * dct(mat, dim=0, norm='ortho')[rows(seed)]`` on this package's kernel pair: M is read once, one fp32 intermediate goes
     out and back, only the p sampled rows are written (the torch formulation materialises the whole transform in fp32 first)"""
@@ -349,7 +345,10 @@ class _LinearGRP(torch.autograd.Function):
             g2 = flat if flat.dtype in (torch.float32, torch.float16, torch.bfloat16) else flat.float()
             if ctx.low is not None:
                 g2 = g2.to(ctx.low)
-            proj = (_native_dct if ctx.kind == 'dct' else _native_sketch_of(ctx.kind))(g2, ctx.p, ctx.native_seed, 1.0)
+            if ctx.kind == 'dct':
+                proj = _native_dct(g2, ctx.p, ctx.native_seed, 1.0)
+            else:
+                proj = _native_sketch(ctx.kind, g2, ctx.p, ctx.native_seed, 1.0)
             grad_weight = (proj.to(sketch.dtype).T @ sketch).to(weight.dtype)
         elif ctx.needs_input_grad[1]:
             proj = _sketch(ctx.kind, flat, ctx.p, _replay_rng(ctx.token), ctx.sketch_dtype, ctx.draw_dtype)
