@@ -22,4 +22,5 @@ one() {
 if [ $# -ge 4 ]; then one "$@"; else
     for dtype in bf16 f32; do for features in 768 3072; do one 16384 $features 3276 $dtype; done; done
     one 16384 768 3276 bf16 explicit; one 16384 3072 3276 bf16 explicit
+    one 12288 768 2457 bf16                                                   # 3 x 2^12 rows: radix-3 first stage in pass B
 fi
