@@ -70,6 +70,7 @@ constexpr int kFeatures = 2 * C;
 // storing): pass A one row of transforms x 32 complex columns; pass B the two rows of a residue pair x 16 complex columns
 constexpr int kThreadsA = 256, kRowsA = 1;
 constexpr int kThreadsB = 256, CB = C / 2;  // pass B: 16 complex columns x the two rows of a residue pair
+constexpr int kServeLanes = 4;              // pass B: lanes that write one sampled row (CB / kServeLanes complex columns each)
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -513,51 +514,87 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
     __syncthreads();
     fft_tile<N2, 1, kSlots>(tile, tw, tid % C, tid / C);               // (ends with a barrier: the list is complete behind it)
 
-    // ---- the sampled rows of this workgroup's two residue classes: one per group of 16 lanes at a time, lanes along the columns
+    // ---- the sampled rows of this workgroup's two residue classes: one per group of kServeLanes lanes at a time, lanes along the columns
     const float base = scale * __builtin_sqrtf(0.5f / static_cast<float>(N));          // ortho: sqrt(1 / 2N) (k > 0), sqrt(1 / 4N) (k = 0)
+    // (four lanes per sample, four complex columns each: 64 samples at a time -- all of a typical workgroup's in one step; with 16 lanes
+    // per sample the four dependent steps of list -> tile -> table -> store cost 1.5 us of a 18.8 us launch, profiles/r06_dct_serve_lanes.txt)
+    constexpr int kLanes = kServeLanes, E = CB / kLanes, kSGroups = kThreads / kLanes;       // lanes per sample, complex columns per lane
+    const int lane = tid % kLanes, sgroup = tid / kLanes;
     auto write_row = [&](int km, size_t j) __attribute__((always_inline)) {
         const int k1 = km % N1, k2 = km / N1;
         const int r = k1 == k1a ? 0 : 1;
         const int k2m = k1 == 0 ? (N2 - k2) % N2 : N2 - 1 - k2;         // N - k = (N1 - k1) + N1 k2m
-        const f32x2 zk = tile[(freq_to_pos<N2>(k2) * 2 + r) * CB + c];
-        f32x2 zm = tile[(freq_to_pos<N2>(k2m) * 2 + (1 - r)) * CB + c];
-        zm.y = -zm.y;                                                   // conj Z[N - k]
-        const f32x2 va = (zk + zm) * 0.5f, d = (zk - zm) * 0.5f, vb = mul_mi(d);
+        const f32x2 *pk = tile + (freq_to_pos<N2>(k2) * 2 + r) * CB + E * lane;
+        const f32x2 *pm = tile + (freq_to_pos<N2>(k2m) * 2 + (1 - r)) * CB + E * lane;
+        f32x2 zk[E], zm[E];
+        if constexpr (E >= 2) {
+#pragma unroll
+            for (int e = 0; e < E; e += 2) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4 *>(pk + e), b4 = *reinterpret_cast<const f32x4 *>(pm + e);
+                zk[e] = f32x2{a4[0], a4[1]}; zk[e + 1] = f32x2{a4[2], a4[3]};
+                zm[e] = f32x2{b4[0], b4[1]}; zm[e + 1] = f32x2{b4[2], b4[3]};
+            }
+        } else {
+            zk[0] = pk[0]; zm[0] = pm[0];
+        }
         const f32x2 w = table_unit(fine, coarse, km, kCoarse > 1);      // e^{-i pi k / 2N}
         const float f = (km == 0 ? kR2 : 1.0f) * 2.0f * base;
-        const float ya = (w.x * va.x - w.y * va.y) * f, yb = (w.x * vb.x - w.y * vb.y) * f;       // Re(w V)
-        const size_t fa = f0 + 2 * c;
+        float y[2 * E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            f32x2 m = zm[e];
+            m.y = -m.y;                                                 // conj Z[N - k]
+            const f32x2 va = (zk[e] + m) * 0.5f, d = (zk[e] - m) * 0.5f, vb = mul_mi(d);
+            y[2 * e] = (w.x * va.x - w.y * va.y) * f;                   // Re(w V)
+            y[2 * e + 1] = (w.x * vb.x - w.y * vb.y) * f;
+        }
+        const size_t fa = f0 + 2 * E * lane;
         if constexpr (DT == FEWBIT_F32) {
             float *o = static_cast<float *>(out) + j * features + fa;
-            if (fa + 1 < features) *reinterpret_cast<f32x2 *>(o) = f32x2{ya, yb};
-            else if (fa < features) o[0] = ya;
+            if (fa + 2 * E <= features) {
+                if constexpr (E == 1) {
+                    *reinterpret_cast<f32x2 *>(o) = f32x2{y[0], y[1]};
+                } else {
+                    typedef f32x4 __attribute__((aligned(4))) f32x4u;
+#pragma unroll
+                    for (int e = 0; e < E; e += 2) *reinterpret_cast<f32x4u *>(o + 2 * e) = f32x4{y[2 * e], y[2 * e + 1], y[2 * e + 2], y[2 * e + 3]};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2 * E; ++e) if (fa + e < features) o[e] = y[e];
+            }
         } else {
             uint16_t *o = static_cast<uint16_t *>(out) + j * features + fa;
-            uint16_t ha, hb;
-            if constexpr (DT == FEWBIT_BF16) {
-                ha = __builtin_bit_cast(uint16_t, static_cast<__bf16>(ya));
-                hb = __builtin_bit_cast(uint16_t, static_cast<__bf16>(yb));
-            } else {
-                ha = __builtin_bit_cast(uint16_t, static_cast<_Float16>(ya));
-                hb = __builtin_bit_cast(uint16_t, static_cast<_Float16>(yb));
+            uint16_t h[2 * E];
+#pragma unroll
+            for (int e = 0; e < 2 * E; ++e) {
+                if constexpr (DT == FEWBIT_BF16) h[e] = __builtin_bit_cast(uint16_t, static_cast<__bf16>(y[e]));
+                else h[e] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(y[e]));
             }
-            if (fa + 1 < features) {
+            if (fa + 2 * E <= features) {
                 typedef uint32_t __attribute__((aligned(2))) u32u;
-                *reinterpret_cast<u32u *>(o) = static_cast<uint32_t>(ha) | (static_cast<uint32_t>(hb) << 16);
-            } else if (fa < features) {
-                o[0] = ha;
+                typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+                typedef u32x2 __attribute__((aligned(2))) u32x2u;
+                typedef u32x4 __attribute__((aligned(2))) u32x4u;
+                auto pair = [&](int e) -> uint32_t { return static_cast<uint32_t>(h[2 * e]) | (static_cast<uint32_t>(h[2 * e + 1]) << 16); };
+                if constexpr (E == 1) *reinterpret_cast<u32u *>(o) = pair(0);
+                else if constexpr (E == 2) *reinterpret_cast<u32x2u *>(o) = u32x2{pair(0), pair(1)};
+                else *reinterpret_cast<u32x4u *>(o) = u32x4{pair(0), pair(1), pair(2), pair(3)};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2 * E; ++e) if (fa + e < features) o[e] = h[e];
             }
         }
     };
     const int total = *count;                                          // block-uniform
     if (total <= kListCap) {
-        for (int e = group; e < total; e += kGroups) write_row(list_k[e], static_cast<size_t>(list_j[e]));
+        for (int e = sgroup; e < total; e += kSGroups) write_row(list_k[e], static_cast<size_t>(list_j[e]));
         return;
     }
     // more samples in these two classes than the list holds (p in the tens of thousands, or a skewed idx): every group of 16 lanes
     // walks its share of idx by itself (all 16 lanes read the same word) and writes the rows that belong here
     if constexpr (ROWS::kSeeded) {
-        for (size_t q = group; kPerDraw * q < proj; q += kGroups) {
+        for (size_t q = sgroup; kPerDraw * q < proj; q += kSGroups) {
             uint32_t w[4];
             draw(q, w);
 #pragma unroll
@@ -567,7 +604,7 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
             }
         }
     } else {
-        for (size_t i = group; i < proj; i += kGroups) {
+        for (size_t i = sgroup; i < proj; i += kSGroups) {
             const int k = mine(raw(i), i);
             if (k >= 0) write_row(k, i);
         }
