@@ -351,9 +351,10 @@ def settled_us(f, reps=SKETCH_REPS, rounds=3):
     return sorted(event_time_us([f], reps, preroll=2) for _ in range(rounds))[rounds // 2]
 
 
-def cabi_dct_workspace(rows, features, proj, dtype):
-    from fewbit_amd import cabi
-    return cabi.sampled_dct_workspace_bytes(rows, features, proj, dtype)
+def dct_intermediate_bytes(rows, features):
+    """the fp32 intermediate of the sampled-DCT kernel pair: 64-feature tiles of rows x 32 complex (the rest of its workspace, the sorted
+    samples, is 8 bytes per sample)"""
+    return ((features + 63) // 64) * rows * 256
 
 
 def measure_sampled_transform(device, rows, features, proj, dtype, dense_rademacher_us=None):
@@ -372,7 +373,7 @@ def measure_sampled_transform(device, rows, features, proj, dtype, dense_rademac
         rec[kind] = {'us': round(us, 1), 'x_byte_floor': round(us / (floor_bytes / HBM_PEAK_GBS / 1e3), 1), 'path': linear.sampled_transform_path(kind, m)}
         if kind == 'dct' and 'fewbit_hip_sampled_dct' in rec[kind]['path']:
             # the kernel pair's own roofline: the bytes its design moves (M once, the fp32 intermediate out and back, the sampled rows)
-            moved = rows * features * es + 2 * cabi_dct_workspace(rows, features, proj, dtype) + proj * features * es
+            moved = rows * features * es + 2 * dct_intermediate_bytes(rows, features) + proj * features * es
             rec[kind]['roofline'] = {'bound': 'hbm', 'bytes_moved_by_design': moved, 'achieved': round(moved / us / 1e3, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                      'frac': round(moved / us / 1e3 / HBM_PEAK_GBS, 4)}
     if dense_rademacher_us is not None:

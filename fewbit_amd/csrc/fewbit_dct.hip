@@ -34,13 +34,13 @@
 //               multiplies by W_N^{n2 k1} (two table lookups, one complex multiply) and writes the intermediate per HALF tile,
 //               [half tile][k1][n2][16 columns]: 128 contiguous bytes per (k1, half).
 //   pass B      workgroup (u, t): residues k1 = u and N1 - u of half tile t (16 complex columns).  Its 32 entries per point are the two
-//               residue rows side by side, so one butterfly serves both.  Reads two contiguous N2 x 128 B blocks -- its share of idx is
-//               requested first, unconditionally, so that testing it never waits --, transforms along n2, collects the samples of its
-//               two residue classes in an LDS list (one atomic per thread) and serves them 16 at a time (one per group of 16 lanes;
-//               e^{-i pi k / 2N} from two small tables, no transcendental per sample).
-//   idx         an int64 array of the caller (fewbit_hip_sampled_dct, RowsInMemory) or a FUNCTION of a 64-bit seed that every pass-B
-//               workgroup evaluates for itself (fewbit_hip_sampled_dct_seeded, RowsOfSeed: eight row numbers per Philox4x32-10 call) --
-//               what the layer uses: no array, no launch that draws one, a seed to keep for backward, capturable into a hipGraph.
+//               residue rows side by side, so one butterfly serves both.  Reads two contiguous N2 x 128 B blocks, transforms along n2 and
+//               writes the samples of its two residue classes: four lanes per sampled row (four complex columns each), 64 rows at a time,
+//               e^{-i pi k / 2N} from two small tables (no transcendental per sample).
+//   idx         an int64 array of the caller (fewbit_hip_sampled_dct, RowsInMemory) or a FUNCTION of a 64-bit seed (fewbit_hip_sampled_dct_seeded,
+//               RowsOfSeed: Philox4x32-10) -- what the layer uses: no array, no launch that draws one, a seed to keep for backward, capturable
+//               into a hipGraph.  Either way ONE workgroup of pass A sorts the samples by residue class into the workspace (sort_rows), so
+//               that a pass-B workgroup reads exactly its own (each of them testing all of idx was a third of pass B's time).
 //   traffic     M once + 2 x rows x features x 4 B of intermediate + the p sampled rows: 16384 x 768 bf16, p = 3276: 25 + 2 x 50 + 5 MB.
 // Measured and not kept (round 6, profiles/r06_dct_variants.txt): 64 KiB tiles with 512-thread workgroups (same time); persistent
 // workgroups that request the next tile before transforming the current one (the radix-16 butterfly leaves no registers for it: spills).
@@ -287,10 +287,115 @@ __device__ __forceinline__ f32x2 table_unit(const f32x2 *fine, const f32x2 *coar
     return has_coarse ? cmul(fine[e % kFine], coarse[e / kFine]) : fine[e % kFine];
 }
 
+// ---- the sampled rows ------------------------------------------------------------------------------------------------------------
+// Where they come from.  RowsInMemory: the caller's int64 array.  RowsOfSeed: a FUNCTION of a 64-bit seed,
+//     rows = 2^k:      idx[j] = 16-bit half j % 8 of the 128 bits of Philox4x32-10(counter = (j / 8, 0, 0, 3), key = seed)  mod  rows
+//                      (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of word h / 2)
+//     rows = 3 x 2^k:  idx[j] = (word j % 4 of Philox4x32-10(counter = (j / 4, 0, 0, 3), key = seed)  x  rows)  >>  32
+// (uniform -- in the second case up to rows / 2^32 --, with replacement, like the reference's T.multinomial of equal weights): no array, no
+// launch that draws one, nothing to keep for backward but the seed -- and, with the seed read from device memory, a recorded launch draws
+// fresh rows on every replay (fewbit_sketch.hip, same scheme).
+constexpr uint32_t kRowsDomain = 3u;        // counter word 3 (0 and 2: the dense sketches)
+__host__ __device__ constexpr bool power_of_two(size_t n) { return (n & (n - 1)) == 0; }
+__host__ __device__ constexpr int per_draw(bool pow2) { return pow2 ? 8 : 4; }          // row numbers per Philox call
+// row number h of one Philox call (POW2: not yet reduced mod rows -- the caller masks)
+template <bool POW2> __host__ __device__ __forceinline__ int drawn_row(const uint32_t (&w)[4], int h, uint32_t rows) {
+    if constexpr (POW2) return static_cast<int>((w[h / 2] >> (16 * (h % 2))) & 0xffffu);
+    else return static_cast<int>((static_cast<uint64_t>(w[h]) * rows) >> 32);
+}
+struct RowsInMemory {
+    static constexpr bool kSeeded = false;
+    const int64_t *idx;
+};
+struct RowsOfSeed {
+    static constexpr bool kSeeded = true;
+    sketch::Key value;
+    const sketch::Key *device;              // != nullptr: the key is read from there when the kernel runs
+};
+
+// Pass B's workgroup (u, t) writes the samples k with k % N1 in {u, N1 - u}.  So that its 24 .. 96 siblings (one per half tile) need
+// not each test all of idx -- a third of pass B's time when they did (profiles/r06_dct_variants.txt: "noenlist") -- ONE workgroup, pass
+// A's (0, 0) before it turns to its own tile, sorts the samples by u into the workspace:
+//     sorted[offsets[u] .. offsets[u + 1])  =  the samples (k, j) with min(k % N1, N1 - k % N1) = u,   u = 0 .. N1 / 2
+// A counting sort in LDS: histogram, prefix, placement.  The order inside a class is whatever the atomics give; no result depends on it
+// (every sample writes its own row of the output).
+struct Sample { int k, j; };                // frequency, row of the output
+constexpr size_t kOffsetsBytes = 1024;      // (N1 / 2 + 2 ints, N1 <= 256, rounded up)
+
+template <int N1, int N, typename ROWS>
+__device__ __forceinline__ void sort_rows(ROWS rows, size_t proj, int *__restrict__ offsets, Sample *__restrict__ sorted, int *lds, int tid) {
+    constexpr int U = N1 / 2 + 1, kThreads = kThreadsA;
+    constexpr bool kPow2 = power_of_two(N);
+    constexpr int kPerDraw = per_draw(kPow2);
+    int *hist = lds, *cursor = lds + U + 1;
+    sketch::Key key{0u, 0u};
+    if constexpr (ROWS::kSeeded) {
+        key = rows.value;
+        if (rows.device != nullptr) key = *rows.device;               // (one scalar load)
+    }
+    auto bucket = [](int k) -> int {
+        const int k1 = k % N1;
+        return k1 <= N1 / 2 ? k1 : N1 - k1;
+    };
+    // every (k, j) this thread looks after: of an array j = tid, tid + 256, ...; of a seed the numbers of the Philox calls tid, tid + 256, ...
+    auto for_each = [&](auto &&f) __attribute__((always_inline)) {
+        if constexpr (ROWS::kSeeded) {
+            for (size_t q = tid; kPerDraw * q < proj; q += kThreads) {
+                uint32_t w[4];
+                sketch::philox4x32(static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32), 0u, kRowsDomain, key, w);
+#pragma unroll
+                for (int h = 0; h < kPerDraw; ++h) {
+                    const size_t j = kPerDraw * q + h;
+                    const int drawn = drawn_row<kPow2>(w, h, N);
+                    if (j < proj) f(kPow2 ? drawn & (N - 1) : drawn, j);
+                }
+            }
+        } else {
+            // (the low dword of an int64 in [0, N) is the number; whatever else the array holds is reduced to [0, N))
+            // eight unconditional requests (a clamped index) before the first is looked at: eight latencies overlap instead of following one another
+            const int *lo = reinterpret_cast<const int *>(rows.idx);
+            for (size_t j0 = tid; j0 < proj; j0 += 8 * kThreads) {
+                int word[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const size_t j = j0 + static_cast<size_t>(a) * kThreads;
+                    word[a] = lo[2 * (j < proj ? j : proj - 1)];
+                }
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const size_t j = j0 + static_cast<size_t>(a) * kThreads;
+                    if (j < proj) f(kPow2 ? word[a] & (N - 1) : static_cast<int>(static_cast<unsigned>(word[a]) % static_cast<unsigned>(N)), j);
+                }
+            }
+        }
+    };
+    for (int b = tid; b <= U; b += kThreads) hist[b] = 0;
+    __syncthreads();
+    for_each([&](int k, size_t) { atomicAdd(&hist[bucket(k)], 1); });
+    __syncthreads();
+    if (tid <= U) {                                                    // offsets[b] = the classes before b (every lane reads the same word: a broadcast)
+        int run = 0;
+#pragma unroll 8
+        for (int b = 0; b < U; ++b) {
+            const int n = hist[b];
+            run += b < tid ? n : 0;
+        }
+        cursor[tid] = run;
+        offsets[tid] = run;
+    }
+    __syncthreads();
+    for_each([&](int k, size_t j) {
+        const int pos = atomicAdd(&cursor[bucket(k)], 1);
+        sorted[pos] = Sample{k, static_cast<int>(j)};
+    });
+    __syncthreads();                                                   // (the tile takes this LDS over)
+}
+
 // ---- pass A -----------------------------------------------------------------------------------------------------------------
 // grid (N2, column tiles): workgroup (b, t) transforms the rows n = N2 n1 + b of column tile t.  inter: [half tile][k1][n2][16] complex fp32.
-template <int DT, int N1, int N2>
-__global__ __launch_bounds__(kThreadsA, (N1 > 128 ? 2 : 4)) void dct_pass_a_kernel(const void *__restrict__ x, size_t features, size_t ld, f32x2 *__restrict__ inter) {
+template <int DT, int N1, int N2, typename ROWS>
+__global__ __launch_bounds__(kThreadsA, (N1 > 128 ? 2 : 4)) void dct_pass_a_kernel(const void *__restrict__ x, size_t features, size_t ld, f32x2 *__restrict__ inter, ROWS rows,
+                                                                  size_t proj, int *__restrict__ offsets, Sample *__restrict__ sorted) {
     constexpr int N = N1 * N2, kCoarse = coarse_entries(N), kThreads = kThreadsA, kSlots = kThreads / C;
     static_assert(kRowsA == 1, "one n2 per workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -300,6 +405,8 @@ __global__ __launch_bounds__(kThreadsA, (N1 > 128 ? 2 : 4)) void dct_pass_a_kern
     const int tid = threadIdx.x, c = tid % C, slot = tid / C;
     const int b = blockIdx.x;
     const size_t t = blockIdx.y, f0 = t * kFeatures;
+    // one workgroup of the launch sorts the sampled rows for pass B first (~2 us of its own time; the launch takes 16)
+    if (blockIdx.x == 0 && blockIdx.y == 0) sort_rows<N1, N, ROWS>(rows, proj, offsets, sorted, reinterpret_cast<int *>(lds_raw), tid);
 
     // ---- loads first (all in flight), tables while they travel, then registers -> LDS
     constexpr int PF = In<DT>::kPieceFeatures, PPS = In<DT>::kPiecesPerSegment, kTotal = N1 * PPS, kPieces = (kTotal + kThreads - 1) / kThreads;
@@ -355,71 +462,32 @@ __global__ __launch_bounds__(kThreadsA, (N1 > 128 ? 2 : 4)) void dct_pass_a_kern
 // grid (N1 / 2 + 1, half tiles of 16 complex columns): residues k1 = u and (N1 - u) % N1.  The LDS tile is [N2][2][16]: the two
 // residue rows sit side by side, so that a half-wave still touches 256 contiguous bytes per position and one butterfly serves
 // both rows -- to the transform it is one row of 32 columns.
-constexpr int kListCap = 512;               // samples a workgroup serves from its LDS list (more: the group-by-group fallback)
-constexpr int kAhead = 16;                  // idx entries per thread requested together with the tile: all of idx for p <= 4096
-
-// Where the sampled rows come from.  RowsInMemory: the caller's int64 array.  RowsOfSeed: a FUNCTION of a 64-bit seed,
-//     rows = 2^k:      idx[j] = 16-bit half j % 8 of the 128 bits of Philox4x32-10(counter = (j / 8, 0, 0, 3), key = seed)  mod  rows
-//                      (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of word h / 2)
-//     rows = 3 x 2^k:  idx[j] = (word j % 4 of Philox4x32-10(counter = (j / 4, 0, 0, 3), key = seed)  x  rows)  >>  32
-// (uniform -- in the second case up to rows / 2^32 --, with replacement, like the reference's T.multinomial of equal weights)
-// which every workgroup evaluates for itself while its tile travels: no array, no launch that draws one, nothing to keep for backward but
-// the seed -- and, with the seed read from device memory, a recorded launch draws fresh rows on every replay (fewbit_sketch.hip, same scheme).
-constexpr uint32_t kRowsDomain = 3u;        // counter word 3 (0 and 2: the dense sketches)
-__host__ __device__ constexpr bool power_of_two(size_t n) { return (n & (n - 1)) == 0; }
-__host__ __device__ constexpr int per_draw(bool pow2) { return pow2 ? 8 : 4; }          // row numbers per Philox call
-static_assert(kAhead % per_draw(true) == 0 && 8 % per_draw(true) == 0 && kAhead % per_draw(false) == 0 && 8 % per_draw(false) == 0, "whole Philox calls per batch");
-// row number h of one Philox call (POW2: not yet reduced mod rows -- the caller masks)
-template <bool POW2> __host__ __device__ __forceinline__ int drawn_row(const uint32_t (&w)[4], int h, uint32_t rows) {
-    if constexpr (POW2) return static_cast<int>((w[h / 2] >> (16 * (h % 2))) & 0xffffu);
-    else return static_cast<int>((static_cast<uint64_t>(w[h]) * rows) >> 32);
-}
-struct RowsInMemory {
-    static constexpr bool kSeeded = false;
-    const int64_t *idx;
-};
-struct RowsOfSeed {
-    static constexpr bool kSeeded = true;
-    sketch::Key value;
-    const sketch::Key *device;              // != nullptr: the key is read from there when the kernel runs
-};
-
-template <int DT, int N1, int N2, typename ROWS>
-__global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, ROWS rows, size_t proj, size_t features,
-                                                                  float scale, void *__restrict__ out) {
-    constexpr int N = N1 * N2, kCoarse = coarse_entries(N), kThreads = kThreadsB, kSlots = kThreads / C, kGroups = kThreads / CB;
-    constexpr bool kPow2 = power_of_two(N);
-    constexpr int kPerDraw = per_draw(kPow2);
+template <int DT, int N1, int N2>
+__global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kernel(const f32x2 *__restrict__ inter, const int *__restrict__ offsets, const Sample *__restrict__ sorted,
+                                                                  size_t proj, size_t features, float scale, void *__restrict__ out) {
+    constexpr int N = N1 * N2, kCoarse = coarse_entries(N), kThreads = kThreadsB, kSlots = kThreads / C;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     f32x2 *tile = reinterpret_cast<f32x2 *>(lds_raw);                 // [N2][2][CB]
     f32x2 *tw = tile + N2 * 2 * CB;                                   // W_N2^m
     f32x2 *fine = tw + N2, *coarse = fine + kFine;                    // W_4N^m (m < 128), W_4N^{128 m}: e^{-i pi k / 2N} = W_4N^k
-    int *list_k = reinterpret_cast<int *>(coarse + kCoarse), *list_j = list_k + kListCap, *count = list_j + kListCap;
-    const int tid = threadIdx.x, c = tid % CB, group = tid / CB;
+    const int tid = threadIdx.x;
     const int u = blockIdx.x, k1a = u, k1b = (N1 - u) % N1;
     const size_t t = blockIdx.y, f0 = t * (2 * CB);
+    // four lanes write one sampled row, four complex columns each: 64 rows at a time -- all of a typical workgroup's in one step (with 16
+    // lanes per row the four dependent steps of sample -> tile -> table -> store cost 1.5 us of a 18.8 us launch, profiles/r06_dct_serve_lanes.txt)
+    constexpr int kLanes = kServeLanes, E = CB / kLanes, kSGroups = kThreads / kLanes;       // lanes per sample, complex columns per lane
+    const int lane = tid % kLanes, sgroup = tid / kLanes;
 
-    // the row numbers this thread will test go out FIRST (vmcnt counts in order: looking at them later does not wait for the tile).
-    // Unconditional loads -- the index is clamped, the verdict is a select -- so that hipcc issues them back to back instead of one
-    // per branch with a wait each (6 us of a 22 us launch); the low dword of an int64 in [0, N) is the number
-    // (rows of a seed: entry a of a batch is number a % kPerDraw of Philox call (a / kPerDraw) * kThreads + tid -- computed below, behind the tile's requests)
-    sketch::Key key{0u, 0u};
-    if constexpr (ROWS::kSeeded) key = rows.device != nullptr ? *rows.device : rows.value;      // (one scalar load)
-    auto entry = [&](size_t first, int a) -> size_t {                 // index into idx of entry a of the batch that starts at call / entry `first`
-        if constexpr (ROWS::kSeeded) return kPerDraw * (first + static_cast<size_t>(a / kPerDraw) * kThreads + tid) + a % kPerDraw;
-        else return first + static_cast<size_t>(a) * kThreads + tid;
-    };
-    auto raw = [&](size_t i) -> int {
-        if constexpr (ROWS::kSeeded) return 0;
-        else return reinterpret_cast<const int *>(rows.idx)[2 * (i < proj ? i : proj - 1)];
-    };
-    auto draw = [&](size_t q, uint32_t (&w)[4]) __attribute__((always_inline)) {
-        sketch::philox4x32(static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32), 0u, kRowsDomain, key, w);
-    };
-    int kraw[kAhead];
-    if constexpr (!ROWS::kSeeded) {
+    // this workgroup's samples (pass A's workgroup (0, 0) sorted them): the first two of every group of lanes are requested FIRST (vmcnt
+    // counts in order: looking at them after the transform does not wait for anything), unconditionally (a clamped index: hipcc gives a
+    // load under a lane-divergent guard its own wait)
+    const int begin = offsets[u], count = offsets[u + 1] - begin;      // (scalar loads)
+    constexpr int kPre = 2;
+    Sample pre[kPre];
 #pragma unroll
-        for (int a = 0; a < kAhead; ++a) kraw[a] = raw(entry(0, a));
+    for (int i = 0; i < kPre; ++i) {
+        const size_t e = static_cast<size_t>(begin) + sgroup + i * kSGroups;
+        pre[i] = sorted[e < proj ? e : proj - 1];
     }
     constexpr int kPerRow = N2 * (CB / 2), kTotal = 2 * kPerRow, kPieces = (kTotal + kThreads - 1) / kThreads;     // 16-byte pieces (two complex)
     f32x4 v[kPieces];
@@ -430,81 +498,9 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
         const f32x2 *src = inter + (t * N1 + (r == 0 ? k1a : k1b)) * static_cast<size_t>(N2) * CB;
         v[i] = reinterpret_cast<const f32x4 *>(src)[rest];
     }
-    // a sample belongs to this workgroup when its residue k % N1 is one of the two it holds; -1 = not ours
-    auto mine = [&](int word, size_t i) -> int {
-        // (an explicit idx is reduced to [0, N) whatever it holds; the rows of a seed are below N already unless N is a power of two)
-        const int kk = kPow2 ? word & (N - 1) : ROWS::kSeeded ? word : static_cast<int>(static_cast<unsigned>(word) % static_cast<unsigned>(N));
-        const int k1 = kk % N1;
-        return (i < proj && (k1 == k1a || k1 == k1b)) ? kk : -1;
-    };
     for (int m = tid; m < N2; m += kThreads) tw[m] = unit(m, N2);
     for (int m = tid; m < kFine; m += kThreads) fine[m] = unit(m, 4 * N);
     for (int m = tid; m < kCoarse; m += kThreads) coarse[m] = unit(m * kFine, 4 * N);
-    if (tid == 0) *count = 0;
-    if constexpr (ROWS::kSeeded) {
-#pragma unroll
-        for (int d = 0; d < kAhead / kPerDraw; ++d) {
-            uint32_t w[4];
-            draw(static_cast<size_t>(d) * kThreads + tid, w);
-#pragma unroll
-            for (int h = 0; h < kPerDraw; ++h) kraw[kPerDraw * d + h] = drawn_row<kPow2>(w, h, N);
-        }
-    }
-    __syncthreads();                                                  // (the counter is zero for everybody; the tile is still on its way)
-    // the workgroup's samples -> LDS list (order does not matter: every sample writes its own row of the result).  A thread first
-    // counts its own matches among the prefetched entries and reserves their places with ONE atomic (not one per entry: sixteen
-    // divergent branches each waiting for its returned value cost 1.9 us of a 18.7 us launch)
-    int verdict[kAhead], mine_count = 0;
-#pragma unroll
-    for (int a = 0; a < kAhead; ++a) {
-        verdict[a] = mine(kraw[a], entry(0, a));
-        mine_count += verdict[a] >= 0 ? 1 : 0;
-    }
-    if (mine_count > 0) {
-        int pos = atomicAdd(count, mine_count);
-#pragma unroll
-        for (int a = 0; a < kAhead; ++a) {
-            if (verdict[a] >= 0) {
-                if (pos < kListCap) {
-                    list_k[pos] = verdict[a];
-                    list_j[pos] = static_cast<int>(entry(0, a));
-                }
-                ++pos;
-            }
-        }
-    }
-    // (p > 4096: the rest of idx in batches of eight unconditional requests per thread -- eight latencies overlap instead of following one another)
-    // (rows of a seed: `first` counts Philox calls, kPerDraw entries each)
-    constexpr size_t kPerCall = ROWS::kSeeded ? kPerDraw : 1;
-    for (size_t first = static_cast<size_t>(kAhead) * kThreads / kPerCall; first * kPerCall < proj; first += 8 * kThreads / kPerCall) {
-        int more[8];
-        if constexpr (ROWS::kSeeded) {
-#pragma unroll
-            for (int d = 0; d < 8 / kPerDraw; ++d) {
-                uint32_t w[4];
-                draw(first + static_cast<size_t>(d) * kThreads + tid, w);
-#pragma unroll
-                for (int h = 0; h < kPerDraw; ++h) more[kPerDraw * d + h] = drawn_row<kPow2>(w, h, N);
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 8; ++a) more[a] = raw(entry(first, a));
-        }
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const size_t i = entry(first, a);
-            const int k = mine(more[a], i);
-            if (k >= 0) {
-                const int pos = atomicAdd(count, 1);
-                if (pos < kListCap) {
-                    list_k[pos] = k;
-                    list_j[pos] = static_cast<int>(i);
-                }
-            }
-        }
-    }
-
-    // registers -> LDS only now: the list was built while the tile travelled (idx went out first, vmcnt counts in order)
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
         const int pid = tid + kThreads * i, r = pid / kPerRow, rest = pid % kPerRow, n2 = rest / (CB / 2), c2 = rest % (CB / 2);
@@ -512,14 +508,10 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
         *reinterpret_cast<f32x4 *>(tile + (n2 * 2 + r) * CB + 2 * c2) = v[i];
     }
     __syncthreads();
-    fft_tile<N2, 1, kSlots>(tile, tw, tid % C, tid / C);               // (ends with a barrier: the list is complete behind it)
+    fft_tile<N2, 1, kSlots>(tile, tw, tid % C, tid / C);               // (ends with a barrier)
 
     // ---- the sampled rows of this workgroup's two residue classes: one per group of kServeLanes lanes at a time, lanes along the columns
     const float base = scale * __builtin_sqrtf(0.5f / static_cast<float>(N));          // ortho: sqrt(1 / 2N) (k > 0), sqrt(1 / 4N) (k = 0)
-    // (four lanes per sample, four complex columns each: 64 samples at a time -- all of a typical workgroup's in one step; with 16 lanes
-    // per sample the four dependent steps of list -> tile -> table -> store cost 1.5 us of a 18.8 us launch, profiles/r06_dct_serve_lanes.txt)
-    constexpr int kLanes = kServeLanes, E = CB / kLanes, kSGroups = kThreads / kLanes;       // lanes per sample, complex columns per lane
-    const int lane = tid % kLanes, sgroup = tid / kLanes;
     auto write_row = [&](int km, size_t j) __attribute__((always_inline)) {
         const int k1 = km % N1, k2 = km / N1;
         const int r = k1 == k1a ? 0 : 1;
@@ -586,28 +578,13 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
             }
         }
     };
-    const int total = *count;                                          // block-uniform
-    if (total <= kListCap) {
-        for (int e = sgroup; e < total; e += kSGroups) write_row(list_k[e], static_cast<size_t>(list_j[e]));
-        return;
-    }
-    // more samples in these two classes than the list holds (p in the tens of thousands, or a skewed idx): every group of 16 lanes
-    // walks its share of idx by itself (all 16 lanes read the same word) and writes the rows that belong here
-    if constexpr (ROWS::kSeeded) {
-        for (size_t q = sgroup; kPerDraw * q < proj; q += kSGroups) {
-            uint32_t w[4];
-            draw(q, w);
 #pragma unroll
-            for (int h = 0; h < kPerDraw; ++h) {
-                const int k = mine(drawn_row<kPow2>(w, h, N), kPerDraw * q + h);
-                if (k >= 0) write_row(k, kPerDraw * q + h);
-            }
-        }
-    } else {
-        for (size_t i = sgroup; i < proj; i += kSGroups) {
-            const int k = mine(raw(i), i);
-            if (k >= 0) write_row(k, i);
-        }
+    for (int i = 0; i < kPre; ++i)
+        if (sgroup + i * kSGroups < count) write_row(pre[i].k, static_cast<size_t>(pre[i].j));
+    // (more than 128 samples in these two classes: p beyond ~8000, or a skewed idx)
+    for (int e = sgroup + kPre * kSGroups; e < count; e += kSGroups) {
+        const Sample smp = sorted[static_cast<size_t>(begin) + e];
+        write_row(smp.k, static_cast<size_t>(smp.j));
     }
 }
 
@@ -635,9 +612,11 @@ bool split_rows(size_t rows, Split &s) {
 }
 size_t tiles_of(size_t features) { return (features + kFeatures - 1) / kFeatures; }
 size_t inter_bytes(size_t rows, size_t features) { return tiles_of(features) * rows * C * sizeof(f32x2); }
+// workspace: [the intermediate | offsets of the sorted samples (1 KiB) | the sorted samples, 8 bytes each]
+size_t workspace_bytes_of(size_t rows, size_t features, size_t proj) { return inter_bytes(rows, features) + kOffsetsBytes + ((proj * sizeof(Sample) + 15) & ~static_cast<size_t>(15)); }
 
 template <int L> constexpr size_t lds_bytes_a(int n) { return (kRowsA * L * C + L + kFine + coarse_entries(n)) * sizeof(f32x2); }
-template <int L> constexpr size_t lds_bytes_b(int n) { return (2 * L * CB + L + kFine + coarse_entries(n)) * sizeof(f32x2) + (2 * kListCap + 4) * sizeof(int); }
+template <int L> constexpr size_t lds_bytes_b(int n) { return (2 * L * CB + L + kFine + coarse_entries(n)) * sizeof(f32x2); }
 
 template <typename K> int opt_in(K kern, size_t lds, std::atomic<unsigned long long> &done) {
     if (lds <= 65536) return FEWBIT_OK;
@@ -655,24 +634,25 @@ template <typename K> int opt_in(K kern, size_t lds, std::atomic<unsigned long l
 }
 
 template <int DT, int N1, int N2, typename ROWS>
-int launch(const void *m, size_t features, size_t ld, ROWS idx, size_t proj, float scale, void *out, f32x2 *inter, hipStream_t s) {
+int launch(const void *m, size_t features, size_t ld, ROWS idx, size_t proj, float scale, void *out, f32x2 *inter, int *offsets, Sample *sorted, hipStream_t s) {
     static std::atomic<unsigned long long> done_a{0}, done_b{0};
     constexpr size_t la = lds_bytes_a<N1>(N1 * N2), lb = lds_bytes_b<N2>(N1 * N2);
-    if (const int rc = opt_in(dct_pass_a_kernel<DT, N1, N2>, la, done_a)) return rc;
-    if (const int rc = opt_in(dct_pass_b_kernel<DT, N1, N2, ROWS>, lb, done_b)) return rc;
+    static_assert(la >= 2 * (N1 / 2 + 2) * sizeof(int) && (N1 / 2 + 2) * sizeof(int) <= kOffsetsBytes, "the sort's counters fit pass A's LDS and the offsets their slot");
+    if (const int rc = opt_in(dct_pass_a_kernel<DT, N1, N2, ROWS>, la, done_a)) return rc;
+    if (const int rc = opt_in(dct_pass_b_kernel<DT, N1, N2>, lb, done_b)) return rc;
     const unsigned tiles = static_cast<unsigned>(tiles_of(features));
-    hipLaunchKernelGGL((dct_pass_a_kernel<DT, N1, N2>), dim3(N2, tiles), dim3(kThreadsA), la, s, m, features, ld, inter);
+    hipLaunchKernelGGL((dct_pass_a_kernel<DT, N1, N2, ROWS>), dim3(N2, tiles), dim3(kThreadsA), la, s, m, features, ld, inter, idx, proj, offsets, sorted);
     const unsigned half_tiles = static_cast<unsigned>((features + 2 * CB - 1) / (2 * CB));
-    hipLaunchKernelGGL((dct_pass_b_kernel<DT, N1, N2, ROWS>), dim3(N1 / 2 + 1, half_tiles), dim3(kThreadsB), lb, s, inter, idx, proj, features, scale, out);
+    hipLaunchKernelGGL((dct_pass_b_kernel<DT, N1, N2>), dim3(N1 / 2 + 1, half_tiles), dim3(kThreadsB), lb, s, inter, offsets, sorted, proj, features, scale, out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FEWBIT_ERR_LAUNCH, "sampled_dct: %s", hipGetErrorString(e));
     return FEWBIT_OK;
 }
 
 template <int DT, typename ROWS>
-int launch_rows(Split sp, const void *m, size_t features, size_t ld, ROWS idx, size_t proj, float scale, void *out, f32x2 *inter, hipStream_t s) {
+int launch_rows(Split sp, const void *m, size_t features, size_t ld, ROWS idx, size_t proj, float scale, void *out, f32x2 *inter, int *offsets, Sample *sorted, hipStream_t s) {
 #define FB_DCT_CASE(A, B) \
-    if (sp.n1 == A && sp.n2 == B) return launch<DT, A, B, ROWS>(m, features, ld, idx, proj, scale, out, inter, s);
+    if (sp.n1 == A && sp.n2 == B) return launch<DT, A, B, ROWS>(m, features, ld, idx, proj, scale, out, inter, offsets, sorted, s);
     FB_DCT_CASE(16, 16) FB_DCT_CASE(32, 16) FB_DCT_CASE(32, 32) FB_DCT_CASE(64, 32) FB_DCT_CASE(64, 64) FB_DCT_CASE(128, 64) FB_DCT_CASE(128, 128)
     FB_DCT_CASE(256, 128) FB_DCT_CASE(256, 256)
     FB_DCT_CASE(16, 48) FB_DCT_CASE(32, 48) FB_DCT_CASE(32, 96) FB_DCT_CASE(64, 96) FB_DCT_CASE(128, 96) FB_DCT_CASE(128, 192) FB_DCT_CASE(256, 192)
@@ -687,18 +667,20 @@ int run(int dtype, const void *m, size_t rows, size_t features, size_t ld, ROWS 
     if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is neither 2^k (256 .. 65536) nor 3 x 2^k (768 .. 49152)", rows);
     if (m == nullptr || out == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: null pointer");
     if (ld < features) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: leading dimension %zu < features %zu", ld, features);
-    const size_t need = inter_bytes(rows, features);
+    const size_t need = workspace_bytes_of(rows, features, proj);
     if (workspace == nullptr || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
         return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: a 16-byte aligned workspace of %zu bytes is needed (fewbit_hip_sampled_dct_workspace), got %zu", need, workspace_bytes);
     if (tiles_of(features) > 32767) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: more than 32767 column tiles");
     if (proj > 0x7fffffffull) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: more than 2^31 - 1 samples");
     hipStream_t s = static_cast<hipStream_t>(stream);
     f32x2 *inter = static_cast<f32x2 *>(workspace);
+    int *offsets = reinterpret_cast<int *>(static_cast<uint8_t *>(workspace) + inter_bytes(rows, features));
+    Sample *sorted = reinterpret_cast<Sample *>(reinterpret_cast<uint8_t *>(offsets) + kOffsetsBytes);
     const float fs = static_cast<float>(scale);
     switch (dtype) {
-    case FEWBIT_F32: return launch_rows<FEWBIT_F32, ROWS>(sp, m, features, ld, idx, proj, fs, out, inter, s);
-    case FEWBIT_F16: return launch_rows<FEWBIT_F16, ROWS>(sp, m, features, ld, idx, proj, fs, out, inter, s);
-    default: return launch_rows<FEWBIT_BF16, ROWS>(sp, m, features, ld, idx, proj, fs, out, inter, s);
+    case FEWBIT_F32: return launch_rows<FEWBIT_F32, ROWS>(sp, m, features, ld, idx, proj, fs, out, inter, offsets, sorted, s);
+    case FEWBIT_F16: return launch_rows<FEWBIT_F16, ROWS>(sp, m, features, ld, idx, proj, fs, out, inter, offsets, sorted, s);
+    default: return launch_rows<FEWBIT_BF16, ROWS>(sp, m, features, ld, idx, proj, fs, out, inter, offsets, sorted, s);
     }
 }
 
@@ -714,7 +696,7 @@ size_t fewbit_hip_sampled_dct_workspace(int dtype, size_t rows, size_t features,
     Split sp;
     (void)dtype;
     if (features == 0 || proj == 0 || !split_rows(rows, sp)) return 0;
-    return inter_bytes(rows, features);
+    return workspace_bytes_of(rows, features, proj);
 }
 
 int fewbit_hip_sampled_dct(int dtype, const void *m, size_t rows, size_t features, size_t ld, const int64_t *idx, size_t proj, double scale, void *out,

@@ -220,7 +220,8 @@ int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features
  *        caller keeps the library formulation for those); arithmetic and the intermediate are fp32 whatever the dtype
  *   idx  proj row numbers in [0, rows) as int64 in DEVICE memory (drawn with replacement: duplicates are served one by one)
  *   out  proj x features, contiguous, the dtype of m (fully written)
- *   workspace  fewbit_hip_sampled_dct_workspace(...) = ceil(features / 64) * rows * 256 bytes, 16-byte aligned; contents are scratch
+ *   workspace  fewbit_hip_sampled_dct_workspace(...) = ceil(features / 64) * rows * 256 (the fp32 intermediate) + 1024 + 8 * proj rounded up to
+ *              16 (the samples sorted by residue class) bytes, 16-byte aligned; contents are scratch
  * Two launches on `stream` (fewbit_amd/csrc/fewbit_dct.hip); deterministic. */
 size_t fewbit_hip_sampled_dct_workspace(int dtype, size_t rows, size_t features, size_t proj);
 int fewbit_hip_sampled_dct(int dtype, const void *m, size_t rows, size_t features, size_t ld, const int64_t *idx, size_t proj, double scale,

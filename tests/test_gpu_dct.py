@@ -70,9 +70,9 @@ def test_every_row_of_the_transform_scale_strides_and_buffers():
 
 
 def test_shapes_without_a_kernel_are_refused_by_name_and_keep_the_library_path():
-    assert cabi.sampled_dct_workspace_bytes(16384, 768, 3276) == 12 * 16384 * 256
-    assert cabi.sampled_dct_workspace_bytes(16384, 70, 1) == 2 * 16384 * 256
-    assert cabi.sampled_dct_workspace_bytes(12288, 768, 2457) == 12 * 12288 * 256
+    assert cabi.sampled_dct_workspace_bytes(16384, 768, 3276) == 12 * 16384 * 256 + 1024 + 8 * 3276
+    assert cabi.sampled_dct_workspace_bytes(16384, 70, 1) == 2 * 16384 * 256 + 1024 + 16
+    assert cabi.sampled_dct_workspace_bytes(12288, 768, 2457) == 12 * 12288 * 256 + 1024 + 19664
     for rows in (48, 128, 384, 3000, 1280, 98304, 131072):
         assert cabi.sampled_dct_workspace_bytes(rows, 64, 10) == 0
         x = torch.randn(rows, 8, device=DEV)
