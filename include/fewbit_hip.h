@@ -233,7 +233,8 @@ int fewbit_hip_sampled_dct(int dtype, const void *m, size_t rows, size_t feature
  *                      (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of output word h / 2)
  *     rows = 3 x 2^k:  idx[j] = (output word j % 4 of Philox4x32-10(counter = (j / 4, 0, 0, 3), key)  x  rows)  >>  32
  * uniform (the second form up to rows / 2^32) with replacement like that draw; forward and
- * backward pass the same seed and sample the same rows.  Every workgroup of the second launch evaluates the function for itself.
+ * backward pass the same seed and sample the same rows.  One workgroup of the first launch evaluates the function (and sorts the samples
+ * by residue class for the second launch -- as it does with an explicit idx).
  * seed_device != NULL: the seed is read from that 8-byte aligned DEVICE word when the kernel runs (`seed` is ignored) -- a launch
  * recorded in a hipGraph then draws fresh rows on every replay, fed by fewbit_hip_sketch_next_seed exactly like
  * fewbit_hip_sketch_device_seed.  fewbit_hip_sampled_rows: the function on the HOST (idx: proj int64 in host memory; what tests and

@@ -33,6 +33,7 @@ ROWS = [
     ('r06_dct_large_rows.txt', 'the kernel pair and the torch.fft formulation at 32768 and 65536 rows', f'{D} 7.3'),
     ('r06_dct_rows_3x.txt', 'the kernel pair and the torch.fft formulation at 3 x 2^k rows (768 .. 49152)', f'{D} 7.3'),
     ('r06_dct_variants.txt', 'the sampled-DCT variants measured in round 6, phases compiled out, per-workgroup timeline', f'{D} 7.5'),
+    ('r06_dct_sorted_samples.txt', 'the samples sorted by residue class once, in pass A, instead of tested by every pass-B workgroup: pass B 17.3 -> 12.7 us', f'{D} 5'),
     ('r06_dct_serve_lanes.txt', 'pass B writing a sampled row with 16 / 8 / 4 lanes: 4 shipped (pass B -8 %)', f'{D} 7.5'),
     ('r06_dct_rounds.txt', 'both DCT passes against the number of workgroups (features swept): a fixed 7-9 us plus 7.5 ns per workgroup', f'{D} 7.5'),
     ('r06_dct_stagger.txt|r06_dct_fused_upper_bound.txt|r06_dct_inter16.txt', 'DCT experiments not kept: staggered starts, both passes in one launch (timing only), a bf16 intermediate', 'EXPERIMENTS.md'),
