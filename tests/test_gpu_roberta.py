@@ -62,8 +62,7 @@ def test_roberta_base_all_gelu_fewbit(dtype, shipped_routes):
     labels = torch.randint(0, 2, (BATCH,), generator=g).to(dev)
     es = torch.empty(0, dtype=dtype).element_size()
 
-    res = {}
-    for name in ('vanilla', 'fewbit', 'op'):
+    def make(name):
         model = rb.build(dtype, dev)                                  # same seed -> same weights
         if name == 'op':
             # the REFERENCE'S caller route (benchmark/bench-roberta.py:123-149): the raw operator with its literal tables, in
@@ -72,6 +71,11 @@ def test_roberta_base_all_gelu_fewbit(dtype, shipped_routes):
         else:
             swapped = rb.swap_gelu(model, BITS) if name == 'fewbit' else 0
         assert swapped == (0 if name == 'vanilla' else 12)
+        return model
+
+    res = {}
+    for name in ('vanilla', 'fewbit', 'op'):
+        model = make(name)
         # first step: same weights, same dropout stream -> the loss may differ only by the GELU arithmetic
         torch.manual_seed(123)
         torch.cuda.reset_peak_memory_stats(dev)
@@ -84,6 +88,13 @@ def test_roberta_base_all_gelu_fewbit(dtype, shipped_routes):
         del out
         times = _step_times(model, ids, labels, steps=8)
         res[name] = dict(loss=loss, saved=usage.forward, peak=peak, ms=statistics.median(times) * 1e3)
+        del model
+        torch.cuda.empty_cache()
+    # a second timing round (the ratios below compare arms timed seconds apart: one clock event of the box during one arm's eight steps
+    # would otherwise decide them -- seen once in ~20 whole-suite runs); each arm keeps the better of its two medians
+    for name in ('vanilla', 'fewbit', 'op'):
+        model = make(name)
+        res[name]['ms'] = min(res[name]['ms'], statistics.median(_step_times(model, ids, labels, steps=8)) * 1e3)
         del model
         torch.cuda.empty_cache()
 
