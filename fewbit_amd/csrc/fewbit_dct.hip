@@ -15,7 +15,7 @@
 //      V = DFT_N(v):  DCT-II(x)[k] = Re(2 e^{-i pi k / 2N} V[k]).
 //   2. Two real columns per complex transform: M is row-major, so features (2c, 2c+1) of a row ARE a complex number in memory;
 //      Z = DFT_N(v_2c + i v_2c+1) gives V_2c[k] = (Z[k] + conj Z[N-k]) / 2 and V_2c+1[k] = (Z[k] - conj Z[N-k]) / 2i.
-//   3. Four-step DFT, N = N1 x N2 (each 16 .. 256; 16384 = 128 x 128, 65536 = 256 x 256; 12288 = 128 x 96: a factor 3 goes to N2), n = N2 n1 + n2, k = k1 + N1 k2:
+//   3. Four-step DFT, N = N1 x N2 (each 16 .. 512; 16384 = 128 x 128, 262144 = 512 x 512; 12288 = 128 x 96: a factor 3 goes to N2), n = N2 n1 + n2, k = k1 + N1 k2:
 //          pass A   for every n2:  A[k1][n2] = W_N^{n2 k1} * sum_{n1} z[N2 n1 + n2] W_N1^{n1 k1}        (length-N1 DFTs over rows N2 apart)
 //          pass B   for every k1:  Z[k1 + N1 k2] = sum_{n2} A[k1][n2] W_N2^{n2 k2}                       (length-N2 DFTs, contiguous)
 //      Pass B never writes Z: the workgroup that owns the residues k1 and N1 - k1 holds Z[k] AND Z[N-k] for every k of those
@@ -281,7 +281,7 @@ template <int DT> __device__ __forceinline__ void unpack_piece(u32x4 q, float (&
     }
 }
 
-constexpr int kFine = 128;                  // W_D^e = fine[e % 128] * coarse[e / 128] for e < N (coarse: N / 128 entries, at most 512)
+constexpr int kFine = 128;                  // W_D^e = fine[e % 128] * coarse[e / 128] for e < N (coarse: N / 128 entries, at most 2048)
 constexpr int coarse_entries(int n) { return n / kFine > 0 ? n / kFine : 1; }
 __device__ __forceinline__ f32x2 table_unit(const f32x2 *fine, const f32x2 *coarse, int e, bool has_coarse) {
     return has_coarse ? cmul(fine[e % kFine], coarse[e / kFine]) : fine[e % kFine];
@@ -297,10 +297,12 @@ __device__ __forceinline__ f32x2 table_unit(const f32x2 *fine, const f32x2 *coar
 // fresh rows on every replay (fewbit_sketch.hip, same scheme).
 constexpr uint32_t kRowsDomain = 3u;        // counter word 3 (0 and 2: the dense sketches)
 __host__ __device__ constexpr bool power_of_two(size_t n) { return (n & (n - 1)) == 0; }
-__host__ __device__ constexpr int per_draw(bool pow2) { return pow2 ? 8 : 4; }          // row numbers per Philox call
-// row number h of one Philox call (POW2: not yet reduced mod rows -- the caller masks)
-template <bool POW2> __host__ __device__ __forceinline__ int drawn_row(const uint32_t (&w)[4], int h, uint32_t rows) {
-    if constexpr (POW2) return static_cast<int>((w[h / 2] >> (16 * (h % 2))) & 0xffffu);
+// rows = 2^k <= 2^16: eight 16-bit halves per Philox call; any other row count (3 x 2^k, 2^17, 2^18): four 32-bit words, word x rows >> 32
+__host__ __device__ constexpr bool draws_halves(size_t n) { return power_of_two(n) && n <= 65536; }
+__host__ __device__ constexpr int per_draw(bool halves) { return halves ? 8 : 4; }      // row numbers per Philox call
+// row number h of one Philox call (HALVES: not yet reduced mod rows -- the caller masks)
+template <bool HALVES> __host__ __device__ __forceinline__ int drawn_row(const uint32_t (&w)[4], int h, uint32_t rows) {
+    if constexpr (HALVES) return static_cast<int>((w[h / 2] >> (16 * (h % 2))) & 0xffffu);
     else return static_cast<int>((static_cast<uint64_t>(w[h]) * rows) >> 32);
 }
 struct RowsInMemory {
@@ -320,13 +322,13 @@ struct RowsOfSeed {
 // A counting sort in LDS: histogram, prefix, placement.  The order inside a class is whatever the atomics give; no result depends on it
 // (every sample writes its own row of the output).
 struct Sample { int k, j; };                // frequency, row of the output
-constexpr size_t kOffsetsBytes = 1024;      // (N1 / 2 + 2 ints, N1 <= 256, rounded up)
+constexpr size_t kOffsetsBytes = 2048;      // (N1 / 2 + 2 ints, N1 <= 512, rounded up)
 
 template <int N1, int N, typename ROWS>
 __device__ __forceinline__ void sort_rows(ROWS rows, size_t proj, int *__restrict__ offsets, Sample *__restrict__ sorted, int *lds, int tid) {
     constexpr int U = N1 / 2 + 1, kThreads = kThreadsA;
-    constexpr bool kPow2 = power_of_two(N);
-    constexpr int kPerDraw = per_draw(kPow2);
+    constexpr bool kPow2 = power_of_two(N), kHalves = draws_halves(N);
+    constexpr int kPerDraw = per_draw(kHalves);
     int *hist = lds, *cursor = lds + U + 1;
     sketch::Key key{0u, 0u};
     if constexpr (ROWS::kSeeded) {
@@ -346,8 +348,8 @@ __device__ __forceinline__ void sort_rows(ROWS rows, size_t proj, int *__restric
 #pragma unroll
                 for (int h = 0; h < kPerDraw; ++h) {
                     const size_t j = kPerDraw * q + h;
-                    const int drawn = drawn_row<kPow2>(w, h, N);
-                    if (j < proj) f(kPow2 ? drawn & (N - 1) : drawn, j);
+                    const int drawn = drawn_row<kHalves>(w, h, N);
+                    if (j < proj) f(kHalves ? drawn & (N - 1) : drawn, j);
                 }
             }
         } else {
@@ -373,15 +375,15 @@ __device__ __forceinline__ void sort_rows(ROWS rows, size_t proj, int *__restric
     __syncthreads();
     for_each([&](int k, size_t) { atomicAdd(&hist[bucket(k)], 1); });
     __syncthreads();
-    if (tid <= U) {                                                    // offsets[b] = the classes before b (every lane reads the same word: a broadcast)
+    for (int mine = tid; mine <= U; mine += kThreads) {                // offsets[b] = the classes before b (every lane reads the same word: a broadcast)
         int run = 0;
 #pragma unroll 8
         for (int b = 0; b < U; ++b) {
             const int n = hist[b];
-            run += b < tid ? n : 0;
+            run += b < mine ? n : 0;
         }
-        cursor[tid] = run;
-        offsets[tid] = run;
+        cursor[mine] = run;
+        offsets[mine] = run;
     }
     __syncthreads();
     for_each([&](int k, size_t j) {
@@ -590,13 +592,14 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 struct Split { int n1, n2; };
-// rows = N1 x N2.  2^8 .. 2^16: 16 <= N2 <= N1 <= 256, both powers of two.  3 x 2^8 .. 3 x 2^14 (768 .. 49152): the factor 3 goes to
-// the second pass, N2 = 48 / 96 / 192 (N1 stays a power of two: residues and digit maps of pass A, the k % N1 of pass B)
+// rows = N1 x N2.  2^8 .. 2^18: 16 <= N2 <= N1 <= 512, both powers of two (2^17 = 512 x 256 and 2^18 = 512 x 512: 128 KiB tiles, one
+// workgroup per CU).  3 x 2^8 .. 3 x 2^14 (768 .. 49152): the factor 3 goes to the second pass, N2 = 48 / 96 / 192 (N1 stays a power of
+// two: residues and digit maps of pass A, the k % N1 of pass B)
 bool split_rows(size_t rows, Split &s) {
-    if (rows < 256 || rows > 65536) return false;
+    if (rows < 256 || rows > 262144) return false;
     const bool three = rows % 3 == 0;
     const size_t two = three ? rows / 3 : rows;
-    if (!power_of_two(two) || (three && two < 256)) return false;
+    if (!power_of_two(two) || (three && (two < 256 || two > 16384))) return false;
     int bits = 0;
     while ((static_cast<size_t>(1) << bits) < two) ++bits;
     if (!three) {
@@ -612,7 +615,7 @@ bool split_rows(size_t rows, Split &s) {
 }
 size_t tiles_of(size_t features) { return (features + kFeatures - 1) / kFeatures; }
 size_t inter_bytes(size_t rows, size_t features) { return tiles_of(features) * rows * C * sizeof(f32x2); }
-// workspace: [the intermediate | offsets of the sorted samples (1 KiB) | the sorted samples, 8 bytes each]
+// workspace: [the intermediate | offsets of the sorted samples (2 KiB) | the sorted samples, 8 bytes each]
 size_t workspace_bytes_of(size_t rows, size_t features, size_t proj) { return inter_bytes(rows, features) + kOffsetsBytes + ((proj * sizeof(Sample) + 15) & ~static_cast<size_t>(15)); }
 
 template <int L> constexpr size_t lds_bytes_a(int n) { return (kRowsA * L * C + L + kFine + coarse_entries(n)) * sizeof(f32x2); }
@@ -654,7 +657,7 @@ int launch_rows(Split sp, const void *m, size_t features, size_t ld, ROWS idx, s
 #define FB_DCT_CASE(A, B) \
     if (sp.n1 == A && sp.n2 == B) return launch<DT, A, B, ROWS>(m, features, ld, idx, proj, scale, out, inter, offsets, sorted, s);
     FB_DCT_CASE(16, 16) FB_DCT_CASE(32, 16) FB_DCT_CASE(32, 32) FB_DCT_CASE(64, 32) FB_DCT_CASE(64, 64) FB_DCT_CASE(128, 64) FB_DCT_CASE(128, 128)
-    FB_DCT_CASE(256, 128) FB_DCT_CASE(256, 256)
+    FB_DCT_CASE(256, 128) FB_DCT_CASE(256, 256) FB_DCT_CASE(512, 256) FB_DCT_CASE(512, 512)
     FB_DCT_CASE(16, 48) FB_DCT_CASE(32, 48) FB_DCT_CASE(32, 96) FB_DCT_CASE(64, 96) FB_DCT_CASE(128, 96) FB_DCT_CASE(128, 192) FB_DCT_CASE(256, 192)
 #undef FB_DCT_CASE
     return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: no kernel for %d x %d rows", sp.n1, sp.n2);
@@ -664,7 +667,7 @@ template <typename ROWS>
 int run(int dtype, const void *m, size_t rows, size_t features, size_t ld, ROWS idx, size_t proj, double scale, void *out, void *workspace,
                        size_t workspace_bytes, void *stream) {
     Split sp;
-    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is neither 2^k (256 .. 65536) nor 3 x 2^k (768 .. 49152)", rows);
+    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is neither 2^k (256 .. 262144) nor 3 x 2^k (768 .. 49152)", rows);
     if (m == nullptr || out == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: null pointer");
     if (ld < features) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: leading dimension %zu < features %zu", ld, features);
     const size_t need = workspace_bytes_of(rows, features, proj);
@@ -718,10 +721,10 @@ int fewbit_hip_sampled_dct_seeded(int dtype, const void *m, size_t rows, size_t 
 
 int fewbit_hip_sampled_rows(uint64_t seed, size_t rows, size_t proj, int64_t *idx) {
     Split sp;
-    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_rows: rows = %zu is neither 2^k (256 .. 65536) nor 3 x 2^k (768 .. 49152)", rows);
+    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_rows: rows = %zu is neither 2^k (256 .. 262144) nor 3 x 2^k (768 .. 49152)", rows);
     if (proj > 0 && idx == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_rows: null pointer");
     const sketch::Key key{static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
-    const bool pow2 = power_of_two(rows);
+    const bool pow2 = draws_halves(rows);
     const size_t per = per_draw(pow2);
     for (size_t q = 0; per * q < proj; ++q) {
         uint32_t w[4];

@@ -215,12 +215,12 @@ int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features
  * Sampled cosine transform of the randomized linear layers:  out[j][:] = scale * DCT-II_ortho(M along its rows)[idx[j]][:]
  *   replaces  `dct(input_view, dim=0, norm='ortho')[proj, ...]`, fewbit/functional/linear.py:113-122 (forward) and :174-183
  *             (backward), with dct = fewbit/fft.py:10-43 -- a full fp32 transform through the FFT library, then a gather
- *   m    rows x features, row-major with leading dimension `ld` (elements), dtype F32 / F16 / BF16; rows = 2^k in [256, 65536] or
+ *   m    rows x features, row-major with leading dimension `ld` (elements), dtype F32 / F16 / BF16; rows = 2^k in [256, 262144] or
  *        3 x 2^k in [768, 49152] (anything else: FEWBIT_ERR_UNSUPPORTED, and fewbit_hip_sampled_dct_workspace returns 0 -- the
  *        caller keeps the library formulation for those); arithmetic and the intermediate are fp32 whatever the dtype
  *   idx  proj row numbers in [0, rows) as int64 in DEVICE memory (drawn with replacement: duplicates are served one by one)
  *   out  proj x features, contiguous, the dtype of m (fully written)
- *   workspace  fewbit_hip_sampled_dct_workspace(...) = ceil(features / 64) * rows * 256 (the fp32 intermediate) + 1024 + 8 * proj rounded up to
+ *   workspace  fewbit_hip_sampled_dct_workspace(...) = ceil(features / 64) * rows * 256 (the fp32 intermediate) + 2048 + 8 * proj rounded up to
  *              16 (the samples sorted by residue class) bytes, 16-byte aligned; contents are scratch
  * Two launches on `stream` (fewbit_amd/csrc/fewbit_dct.hip); deterministic. */
 size_t fewbit_hip_sampled_dct_workspace(int dtype, size_t rows, size_t features, size_t proj);
@@ -229,9 +229,9 @@ int fewbit_hip_sampled_dct(int dtype, const void *m, size_t rows, size_t feature
 /* The same with the sampled rows a FUNCTION of a 64-bit seed -- no array of row numbers, no launch that draws one (the reference draws
  * `T.multinomial` of uniform probabilities with replacement per call, fewbit/functional/linear.py:114-119, and draws it again in
  * backward from the generator state it saved, :105,153,159-160,176-181):
- *     rows = 2^k:      idx[j] = 16-bit half j % 8 of Philox4x32-10(counter = (j / 8, 0, 0, 3), key = (seed low, seed high))  mod  rows
- *                      (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of output word h / 2)
- *     rows = 3 x 2^k:  idx[j] = (output word j % 4 of Philox4x32-10(counter = (j / 4, 0, 0, 3), key)  x  rows)  >>  32
+ *     rows = 2^k <= 2^16:  idx[j] = 16-bit half j % 8 of Philox4x32-10(counter = (j / 8, 0, 0, 3), key = (seed low, seed high))  mod  rows
+ *                          (half h = bits 16 (h % 2) .. 16 (h % 2) + 15 of output word h / 2)
+ *     any other rows:      idx[j] = (output word j % 4 of Philox4x32-10(counter = (j / 4, 0, 0, 3), key)  x  rows)  >>  32
  * uniform (the second form up to rows / 2^32) with replacement like that draw; forward and
  * backward pass the same seed and sample the same rows.  One workgroup of the first launch evaluates the function (and sorts the samples
  * by residue class for the second launch -- as it does with an explicit idx).

@@ -89,12 +89,13 @@ def test_tune_is_the_single_hook_and_validates_its_keys():
 
 
 def test_sampled_dct_workspace_is_a_host_side_formula():
-    """no GPU needed: ceil(features / 64) * rows * 256 + 1024 + 8 * proj (rounded up to 16) bytes for 2^k rows in [256, 65536] or 3 x 2^k rows in
+    """no GPU needed: ceil(features / 64) * rows * 256 + 2048 + 8 * proj (rounded up to 16) bytes for 2^k rows in [256, 262144] or 3 x 2^k rows in
     [768, 49152], 0 = no kernel for this shape"""
-    assert cabi.sampled_dct_workspace_bytes(16384, 768, 3276) == 12 * 16384 * 256 + 1024 + 8 * 3276
-    assert cabi.sampled_dct_workspace_bytes(65536, 70, 1, torch.float32) == 2 * 65536 * 256 + 1024 + 16
-    assert cabi.sampled_dct_workspace_bytes(12288, 64, 5) == 12288 * 256 + 1024 + 48
-    for rows in (0, 48, 128, 255, 3000, 131072):
+    assert cabi.sampled_dct_workspace_bytes(16384, 768, 3276) == 12 * 16384 * 256 + 2048 + 8 * 3276
+    assert cabi.sampled_dct_workspace_bytes(65536, 70, 1, torch.float32) == 2 * 65536 * 256 + 2048 + 16
+    assert cabi.sampled_dct_workspace_bytes(12288, 64, 5) == 12288 * 256 + 2048 + 48
+    assert cabi.sampled_dct_workspace_bytes(262144, 64, 8) == 262144 * 256 + 2048 + 64
+    for rows in (0, 48, 128, 255, 3000, 98304, 524288):
         assert cabi.sampled_dct_workspace_bytes(rows, 64, 10) == 0
     assert cabi.sampled_dct_workspace_bytes(1024, 0, 10) == 0 == cabi.sampled_dct_workspace_bytes(1024, 64, 0)
     assert cabi.sampled_dct_workspace_bytes(1024, 64, 10, torch.float64) == 0

@@ -19,9 +19,9 @@ DEV = 'cuda:0'
 REL = {torch.float32: 0.0, torch.float16: 2.0**-11, torch.bfloat16: 2.0**-8}
 
 
-@pytest.fixture(scope='module', params=('sampled_dct_ref.npz', 'sampled_dct_ref_3x.npz'))
+@pytest.fixture(scope='module', params=('sampled_dct_ref.npz', 'sampled_dct_ref_3x.npz', 'sampled_dct_ref_big.npz'))
 def ref(request):
-    """the reference's own rows: 2^8 .. 2^16 rows, and 3 x 2^8 .. 3 x 2^14 (the radix-3 first stage of pass B)"""
+    """the reference's own rows: 2^8 .. 2^16 rows, 3 x 2^8 .. 3 x 2^14 (the radix-3 first stage of pass B), 2^17 and 2^18 (512-point tiles)"""
     with np.load(GOLDEN / request.param) as z:
         return {k: z[k].copy() for k in z.files}
 
@@ -35,7 +35,7 @@ def close(got, want, dtype):
 
 @pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16, torch.float16))
 def test_sampled_rows_equal_the_reference_run(ref, dtype):
-    """9 shapes, 256 .. 65536 rows, and 7 shapes, 768 .. 49152 = 3 x 2^k rows; ragged and odd feature counts, corner rows (0, rows/2, rows-1, the self-paired residue classes,
+    """9 shapes, 256 .. 65536 rows, 7 shapes, 768 .. 49152 = 3 x 2^k rows, and 131072 / 262144 rows; ragged and odd feature counts, corner rows (0, rows/2, rows-1, the self-paired residue classes,
     duplicates): every dtype against the reference's float64 rows (the inputs are exact in all three dtypes)"""
     for i in range(int(ref['cases'])):
         x = torch.from_numpy(ref[f'case{i}_x_times_16'].astype(np.float32) / 16.0).to(dtype).to(DEV)
@@ -53,7 +53,7 @@ def test_every_row_of_the_transform_scale_strides_and_buffers():
     """p = rows (every k once, shuffled) against torch's float64 transform of the same data on the host; `scale`, a strided input
     (leading dimension > features), caller-provided out / workspace, and bit-identical repeats"""
     g = torch.Generator().manual_seed(12)
-    for rows, features in ((1024, 130), (256, 64), (16384, 66), (32768, 34), (65536, 4), (768, 64), (1536, 130), (12288, 66), (49152, 4)):
+    for rows, features in ((1024, 130), (256, 64), (16384, 66), (32768, 34), (65536, 4), (768, 64), (1536, 130), (12288, 66), (49152, 4), (131072, 6), (262144, 2)):
         wide = torch.randn(rows, features + 6, generator=g).to(DEV)
         x = wide[:, 3:3 + features]                                           # unit stride along the features, ld = features + 6
         assert not x.is_contiguous()
@@ -70,10 +70,10 @@ def test_every_row_of_the_transform_scale_strides_and_buffers():
 
 
 def test_shapes_without_a_kernel_are_refused_by_name_and_keep_the_library_path():
-    assert cabi.sampled_dct_workspace_bytes(16384, 768, 3276) == 12 * 16384 * 256 + 1024 + 8 * 3276
-    assert cabi.sampled_dct_workspace_bytes(16384, 70, 1) == 2 * 16384 * 256 + 1024 + 16
-    assert cabi.sampled_dct_workspace_bytes(12288, 768, 2457) == 12 * 12288 * 256 + 1024 + 19664
-    for rows in (48, 128, 384, 3000, 1280, 98304, 131072):
+    assert cabi.sampled_dct_workspace_bytes(16384, 768, 3276) == 12 * 16384 * 256 + 2048 + 8 * 3276
+    assert cabi.sampled_dct_workspace_bytes(16384, 70, 1) == 2 * 16384 * 256 + 2048 + 16
+    assert cabi.sampled_dct_workspace_bytes(12288, 768, 2457) == 12 * 12288 * 256 + 2048 + 19664
+    for rows in (48, 128, 384, 3000, 1280, 98304, 524288):
         assert cabi.sampled_dct_workspace_bytes(rows, 64, 10) == 0
         x = torch.randn(rows, 8, device=DEV)
         idx = torch.zeros(4, dtype=torch.int64, device=DEV)
@@ -127,6 +127,7 @@ def test_the_seeded_transform_is_the_explicit_one_on_the_rows_of_the_seed():
     multiple of four, the seed by value and as a device word"""
     cases = [(256, 40, 9000), (256, 64, 1), (512, 66, 20001), (1024, 7, 300), (2048, 33, 2047), (4096, 64, 5000), (8192, 96, 1638),
              (16384, 768, 3276), (16384, 130, 16387), (32768, 64, 6553), (65536, 32, 13107),
+             (131072, 64, 26214), (262144, 70, 52428), (262144, 2, 7),
              (768, 40, 9000), (1536, 64, 3), (3072, 66, 20001), (6144, 96, 1229), (12288, 768, 2457), (24576, 64, 4915), (49152, 32, 9830)]
     for n, (rows, features, p) in enumerate(cases):
         dtype = (torch.bfloat16, torch.float32, torch.float16)[n % 3]
@@ -198,7 +199,8 @@ def test_sampled_dct_fuzz_against_float64_on_the_device():
     n = int(os.environ.get('FEWBIT_DCT_FUZZ_CASES', '40'))
     cases = list(_fuzz_cases(n, 2026))
     cases += [(256, 40, 9000, torch.float32, 0, 1.0, 1), (512, 66, 20000, torch.bfloat16, 2, 1.0, 2), (16384, 34, 16384, torch.float32, 0, 1.0, 3),
-              (768, 40, 9000, torch.float32, 0, 1.0, 1), (1536, 66, 20000, torch.bfloat16, 2, 1.0, 4), (12288, 34, 12288, torch.float32, 0, 1.0, 5)]
+              (768, 40, 9000, torch.float32, 0, 1.0, 1), (1536, 66, 20000, torch.bfloat16, 2, 1.0, 4), (12288, 34, 12288, torch.float32, 0, 1.0, 5),
+              (131072, 34, 5000, torch.bfloat16, 0, 1.0, 6), (262144, 7, 300, torch.float32, 3, 0.25, 7), (262144, 66, 52428, torch.float16, 0, 1.0, 8)]
     for rows, features, p, dtype, pad, scale, seed in cases:
         g = torch.Generator().manual_seed(seed)
         wide = torch.randn(rows, features + pad, generator=g).to(dtype).to(DEV)

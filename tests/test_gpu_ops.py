@@ -526,7 +526,7 @@ def test_torch_free_host_program_on_the_c_abi():
     assert 'mismatches: codes 0, gradients 0, forward 0' in out.stdout
     assert '(Rademacher, seed 123456789abcdef): mismatches 0' in out.stdout      # the random-projection kernel, S rebuilt on the host
     assert 'seed in device memory (counter 6 -> 7): differences from the seed by value 0' in out.stdout
-    assert 'sampled DCT of 256 x 6, 5 rows picked (workspace 66608 bytes): mismatches 0' in out.stdout                 # vs the cosine sum in double
+    assert 'sampled DCT of 256 x 6, 5 rows picked (workspace 67632 bytes): mismatches 0' in out.stdout                 # vs the cosine sum in double
     assert 'seeded call against the explicit one: mismatches 0' in out.stdout and out.stdout.rstrip().endswith('mismatches 0')
 
 

@@ -169,6 +169,10 @@ def test_rows_of_a_seed_are_the_documented_function_and_uniform():
     assert idx.tolist() == want and 0 <= min(want) and max(want) < 12288
     counts = torch.bincount(cabi.sampled_rows(6, 768, 3 << 20), minlength=768).double()
     assert float(((counts - 4096.0) ** 2 / 4096.0).sum()) < 920.0            # 767 degrees of freedom: 99.99 % point 917
-    for rows in (1000, 384, 98304, 131072, 128):
+    # rows = 2^17, 2^18: 32-bit words too
+    idx = cabi.sampled_rows(seed, 262144, 1003)
+    want = [(int(w) * 262144) >> 32 for q in range(251) for w in ref.philox4x32(q, 0, 0, 3, *key)][:1003]
+    assert idx.tolist() == want
+    for rows in (1000, 384, 98304, 524288, 128):
         with pytest.raises(cabi.FewbitHipError):
             cabi.sampled_rows(1, rows, 4)
