@@ -217,3 +217,37 @@ def test_sampled_dct_fuzz_against_float64_on_the_device():
         # the rows as a function of a seed: the same bits as the explicit call on those rows
         of_seed = cabi.sampled_rows(seed, rows, p).to(DEV)
         assert torch.equal(cabi.sampled_dct_seeded(x, p, seed, scale), cabi.sampled_dct(x, of_seed, scale)), (rows, features, p, dtype, pad)
+
+
+def test_the_seeded_dct_estimator_has_the_mean_and_spread_of_the_formulation_with_drawn_rows():
+    """The rows of a seed are another stream than the reference's T.multinomial draw, so this link is statistical (like the dense sketches'
+    in tests/test_gpu_linear.py): over 3000 draws each, linear_grp(matmul='dct') on the kernel pair (rows of a seed) and on the torch.fft
+    formulation (rows from randint -- the path tests/test_gpu_linear.py pins to the reference's outputs) both average to the exact weight
+    gradient, and their mean squared deviations from it agree within 5 % (standard error of the ratio ~ 2 %).  256 and 768 rows."""
+    from fewbit_amd import linear
+    for rows in (256, 768):
+        g = torch.Generator().manual_seed(rows)
+        x = torch.randn(rows, 12, generator=g).to(DEV)
+        w = (torch.randn(6, 12, generator=g) * 0.3).to(DEV)
+        gy = torch.randn(rows, 6, generator=g).to(DEV)
+        exact = gy.T @ x
+        p, draws = rows // 4, 3000
+        torch.manual_seed(9)
+        msd = {}
+        for native in (True, False):
+            prev = linear.use_native_sketch(native)
+            try:
+                acc, dev2 = torch.zeros_like(exact, dtype=torch.float64), torch.zeros((), device=DEV, dtype=torch.float64)
+                for _ in range(draws):
+                    wi = w.clone().requires_grad_()
+                    fewbit.functional.linear_grp(x, wi, None, proj_dim=p, matmul='dct').backward(gy)
+                    acc += wi.grad
+                    dev2 += ((wi.grad - exact) ** 2).sum()
+                msd[native] = float(dev2) / draws
+                bias = float(torch.linalg.norm(acc / draws - exact) / torch.linalg.norm(exact))
+                spread = (msd[native] / draws) ** 0.5 / float(torch.linalg.norm(exact))     # one sigma of that norm
+                assert bias <= 4.0 * spread + 1e-3, (rows, native, bias, spread)
+            finally:
+                linear.use_native_sketch(prev)
+        print(f'\nseeded DCT estimator, {rows} rows: mean squared deviation kernel pair / torch formulation = {msd[True] / msd[False]:.4f}')
+        assert abs(msd[True] / msd[False] - 1.0) <= 0.05, (rows, msd)
