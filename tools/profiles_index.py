@@ -31,6 +31,7 @@ ROWS = [
     ('r0?_sketch_rocprof_*.txt', 'tools/profile_sketch.sh: rocprofv3 kernel durations (round 6: >= 200 settled dispatches) + PMC counters of the dense sketches', f'{D} 7.3'),
     ('r06_dct_rocprof_*.txt', 'tools/profile_dct.sh: settled kernel durations and PMC traffic of the sampled-DCT kernel pair', f'{D} 5, 7.3'),
     ('r06_dct_large_rows.txt', 'the kernel pair and the torch.fft formulation at 32768 and 65536 rows', f'{D} 7.3'),
+    ('r06_convergence_demo_*.txt', 'a student MLP fitted with torch layers and with each few-bit configuration (tools/convergence_demo.py); the DCT estimator at lr 1.0', f'{D} 7.4'),
     ('r06_dct_rows_big.txt', 'the kernel pair and the torch.fft formulation at 2^17 and 2^18 rows (512-point tiles)', f'{D} 7.3'),
     ('r06_dct_rows_3x.txt', 'the kernel pair and the torch.fft formulation at 3 x 2^k rows (768 .. 49152)', f'{D} 7.3'),
     ('r06_dct_variants.txt', 'the sampled-DCT variants measured in round 6, phases compiled out, per-workgroup timeline', f'{D} 7.5'),
