@@ -68,12 +68,25 @@ def test_moments_of_the_matrix_the_device_generates():
         assert abs(float((a * b).mean())) < 1.5e-3
 
 
+_MODEL_MATRICES = {}
+
+
+def _model_matrix(dist, seed, proj, rows, dtype):
+    """the host model's S for these arguments (generated once per module run: the tune sweeps below ask for the same matrix several times)"""
+    key = (dist, seed, proj, rows, dtype)
+    if key not in _MODEL_MATRICES:
+        if len(_MODEL_MATRICES) >= 4:                                  # (bounded: a 1290 x 70000 matrix in float64 is 0.7 GB)
+            _MODEL_MATRICES.pop(next(iter(_MODEL_MATRICES)))
+        _MODEL_MATRICES[key] = ref.matrix(dist, seed, proj, rows, dtype).double()
+    return _MODEL_MATRICES[key]
+
+
 def _product_case(dist, dtype, rows, features, proj, seed, ld=None, scale=1.0):
     g = torch.Generator().manual_seed(rows * 31 + features)
     m = torch.randn(rows, ld or features, generator=g).to(dtype)[:, :features]
     got = cabi.sketch(dist, m.to(DEV) if ld is None else m.to(DEV), proj, seed, scale)
     assert got.shape == (proj, features) and got.dtype == dtype
-    S = ref.matrix(dist, seed, proj, rows, dtype).double()
+    S = _model_matrix(dist, seed, proj, rows, dtype)
     op = torch.float16 if dtype == torch.float16 else torch.bfloat16
     mm = m.to(op).double()
     want = scale * (S @ mm)
