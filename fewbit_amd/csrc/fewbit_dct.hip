@@ -595,7 +595,7 @@ struct Split { int n1, n2; };
 // rows = N1 x N2.  2^8 .. 2^18: 16 <= N2 <= N1 <= 512, both powers of two (2^17 = 512 x 256 and 2^18 = 512 x 512: 128 KiB tiles, one
 // workgroup per CU).  3 x 2^8 .. 3 x 2^14 (768 .. 49152): the factor 3 goes to the second pass, N2 = 48 / 96 / 192 (N1 stays a power of
 // two: residues and digit maps of pass A, the k % N1 of pass B)
-bool split_rows(size_t rows, Split &s) {
+inline bool split_rows(size_t rows, Split &s) {
     if (rows < 256 || rows > 262144) return false;
     const bool three = rows % 3 == 0;
     const size_t two = three ? rows / 3 : rows;
@@ -613,10 +613,10 @@ bool split_rows(size_t rows, Split &s) {
     s.n2 = static_cast<int>(rows / static_cast<size_t>(s.n1));
     return true;
 }
-size_t tiles_of(size_t features) { return (features + kFeatures - 1) / kFeatures; }
-size_t inter_bytes(size_t rows, size_t features) { return tiles_of(features) * rows * C * sizeof(f32x2); }
+inline size_t tiles_of(size_t features) { return (features + kFeatures - 1) / kFeatures; }
+inline size_t inter_bytes(size_t rows, size_t features) { return tiles_of(features) * rows * C * sizeof(f32x2); }
 // workspace: [the intermediate | offsets of the sorted samples (2 KiB) | the sorted samples, 8 bytes each]
-size_t workspace_bytes_of(size_t rows, size_t features, size_t proj) { return inter_bytes(rows, features) + kOffsetsBytes + ((proj * sizeof(Sample) + 15) & ~static_cast<size_t>(15)); }
+inline size_t workspace_bytes_of(size_t rows, size_t features, size_t proj) { return inter_bytes(rows, features) + kOffsetsBytes + ((proj * sizeof(Sample) + 15) & ~static_cast<size_t>(15)); }
 
 template <int L> constexpr size_t lds_bytes_a(int n) { return (kRowsA * L * C + L + kFine + coarse_entries(n)) * sizeof(f32x2); }
 template <int L> constexpr size_t lds_bytes_b(int n) { return (2 * L * CB + L + kFine + coarse_entries(n)) * sizeof(f32x2); }
@@ -663,6 +663,24 @@ int launch_rows(Split sp, const void *m, size_t features, size_t ld, ROWS idx, s
     return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: no kernel for %d x %d rows", sp.n1, sp.n2);
 }
 
+// The file is compiled as three translation units in parallel, one per dtype (-DFEWBIT_DCT_TU=0 / 1 / 2 = FEWBIT_F32 / F16 / BF16: 54
+// kernels each; the C entry points with unit 0), and linked into the one library -- 50 s instead of 2.5 min; without the define everything
+// is one unit (make variant).
+#ifndef FEWBIT_DCT_TU
+#define FEWBIT_DCT_TU -1
+#endif
+#define FB_DCT_LAUNCH_ROWS(KEYWORD, DT, ROWS) \
+    KEYWORD template int launch_rows<DT, ROWS>(Split, const void *, size_t, size_t, ROWS, size_t, float, void *, f32x2 *, int *, Sample *, hipStream_t);
+#if FEWBIT_DCT_TU >= 0
+FB_DCT_LAUNCH_ROWS(, FEWBIT_DCT_TU, RowsInMemory) FB_DCT_LAUNCH_ROWS(, FEWBIT_DCT_TU, RowsOfSeed)
+#endif
+#if FEWBIT_DCT_TU == 0
+FB_DCT_LAUNCH_ROWS(extern, FEWBIT_F16, RowsInMemory) FB_DCT_LAUNCH_ROWS(extern, FEWBIT_F16, RowsOfSeed)
+FB_DCT_LAUNCH_ROWS(extern, FEWBIT_BF16, RowsInMemory) FB_DCT_LAUNCH_ROWS(extern, FEWBIT_BF16, RowsOfSeed)
+#endif
+#undef FB_DCT_LAUNCH_ROWS
+
+#if FEWBIT_DCT_TU <= 0
 template <typename ROWS>
 int run(int dtype, const void *m, size_t rows, size_t features, size_t ld, ROWS idx, size_t proj, double scale, void *out, void *workspace,
                        size_t workspace_bytes, void *stream) {
@@ -687,9 +705,12 @@ int run(int dtype, const void *m, size_t rows, size_t features, size_t ld, ROWS 
     }
 }
 
+#endif  // FEWBIT_DCT_TU <= 0
+
 }  // namespace dct
 }  // namespace fewbit_hip
 
+#if FEWBIT_DCT_TU <= 0
 using namespace fewbit_hip;
 using namespace fewbit_hip::dct;
 
@@ -737,3 +758,4 @@ int fewbit_hip_sampled_rows(uint64_t seed, size_t rows, size_t proj, int64_t *id
 }
 
 }  // extern "C"
+#endif  // FEWBIT_DCT_TU <= 0
