@@ -491,7 +491,7 @@ def tune_sketch_materialise(materialise: int) -> None:
 
 # ---- sampled cosine transform (fewbit_amd/csrc/fewbit_dct.hip): out = scale * dct(m, dim=0, norm='ortho')[idx] -------------------
 def sampled_dct_workspace_bytes(rows: int, features: int, proj: int, dtype: torch.dtype = torch.bfloat16) -> int:
-    """bytes of scratch a ``sampled_dct`` call needs; 0 = this shape has no kernel (rows neither 2^k in [256, 262144] nor 3 x 2^k in [768, 49152])"""
+    """bytes of scratch a ``sampled_dct`` call needs; 0 = this shape has no kernel (rows none of 2^k in [256, 262144], 3 x 2^k in [768, 49152], 5 x 2^k in [1280, 40960])"""
     if dtype not in DTYPES:
         return 0
     return lib().fewbit_hip_sampled_dct_workspace(DTYPES[dtype], rows, features, proj)
@@ -508,7 +508,7 @@ def _sampled_dct_call(m: torch.Tensor, proj: int, out: Optional[torch.Tensor], w
     ld = m.stride(0) if rows > 1 else features
     need = sampled_dct_workspace_bytes(rows, features, proj, m.dtype)
     if need == 0 and proj and features:
-        raise FewbitHipError(f'sampled_dct: no kernel for {rows} rows (2^k in [256, 262144] or 3 x 2^k in [768, 49152] is needed)')
+        raise FewbitHipError(f'sampled_dct: no kernel for {rows} rows (2^k in [256, 262144], 3 x 2^k in [768, 49152] or 5 x 2^k in [1280, 40960] is needed)')
     with _on(m.device):
         if out is None:
             out = torch.empty((proj, features), dtype=m.dtype, device=m.device)
@@ -525,7 +525,7 @@ def _sampled_dct_call(m: torch.Tensor, proj: int, out: Optional[torch.Tensor], w
 def sampled_dct(m: torch.Tensor, idx: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None,
                 workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
     """``scale * dct(m, dim=0, norm='ortho')[idx]`` (DCT-II along the rows, orthonormal; the reference's 'dct' sketch) for a 2-D
-    ``m`` (rows x features, unit stride along the features) whose row count is 2^k in [256, 262144] or 3 x 2^k in [768, 49152]; ``idx``: int64 row
+    ``m`` (rows x features, unit stride along the features) whose row count is 2^k in [256, 262144], 3 x 2^k in [768, 49152] or 5 x 2^k in [1280, 40960]; ``idx``: int64 row
     numbers on the device of ``m``.  fp32 arithmetic, result in the dtype of ``m``."""
     if idx.dtype != torch.int64 or idx.dim() != 1 or idx.device != m.device or not idx.is_contiguous():
         raise FewbitHipError('idx must be a contiguous 1-D int64 tensor on the device of m')

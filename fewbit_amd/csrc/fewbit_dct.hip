@@ -1,7 +1,7 @@
 // fewbit_dct.hip -- the sampled cosine transform of the randomized linear layers (the reference's 'dct' estimator)
 // on gfx950:
 //
-//     out[j][:] = scale * DCT-II_ortho(M, along the rows)[idx[j]][:]        M: rows x features (bf16 / fp16 / fp32), rows = 2^m or 3 x 2^m
+//     out[j][:] = scale * DCT-II_ortho(M, along the rows)[idx[j]][:]        M: rows x features (bf16 / fp16 / fp32), rows = 2^m, 3 x 2^m or 5 x 2^m
 //
 // What it replaces in the reference (skolai/fewbit): `dct(input_view, dim=0, norm='ortho')[proj, ...]` in LinearGRPFunc.forward
 // (fewbit/functional/linear.py:113-122) and the same on the gradient in .backward (:174-183); dct = fewbit/fft.py:10-43 (shuffle,
@@ -81,7 +81,7 @@ __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 b) {
     return f32x2{__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
 }
 __device__ __forceinline__ f32x2 mul_mi(f32x2 a) { return f32x2{a.y, -a.x}; }                                   // a * (-i)
-// e^{-2 pi i num / den}: den a power of two (num / den is exact in fp32), or 3 x a power of two (the angle in double, then rounded;
+// e^{-2 pi i num / den}: den a power of two (num / den is exact in fp32), or 3 x / 5 x a power of two (the angle in double, then rounded;
 // `den` is a template constant at every call site: the branch folds)
 __device__ __forceinline__ f32x2 unit(int num, int den) {
     if ((den & (den - 1)) != 0) {
@@ -121,6 +121,17 @@ template <int R> __device__ __forceinline__ void dft(f32x2 (&x)[R]) {
         x[2] = m - d;
     } else if constexpr (R == 4) {
         dft4(x[0], x[1], x[2], x[3]);
+    } else if constexpr (R == 5) {
+        // W5^j = cos(2 pi j / 5) - i sin(2 pi j / 5):  y1, y4 = m1 -+ i n1,  y2, y3 = m2 -+ i n2
+        constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f, s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+        const f32x2 a1 = x[1] + x[4], a2 = x[2] + x[3], b1 = x[1] - x[4], b2 = x[2] - x[3];
+        const f32x2 m1 = x[0] + a1 * c1 + a2 * c2, m2 = x[0] + a1 * c2 + a2 * c1;
+        const f32x2 n1 = mul_mi(b1 * s1 + b2 * s2), n2 = mul_mi(b1 * s2 - b2 * s1);
+        x[0] = x[0] + a1 + a2;
+        x[1] = m1 + n1;
+        x[4] = m1 - n1;
+        x[2] = m2 + n2;
+        x[3] = m2 - n2;
     } else if constexpr (R == 8) {
         // j = 2a + b, q = p + 4 q':  y[p + 4 q'] = sum_b W8^{bp} (-1)^{b q'} sum_a x[2a + b] W4^{ap}
         dft4(x[0], x[2], x[4], x[6]);
@@ -136,7 +147,7 @@ template <int R> __device__ __forceinline__ void dft(f32x2 (&x)[R]) {
         x[2] = e2 + t2; x[6] = e2 - t2;
         x[3] = e3 + t3; x[7] = e3 - t3;
     } else {
-        static_assert(R == 16, "radix 2, 3, 4, 8 or 16");
+        static_assert(R == 16, "radix 2, 3, 4, 5, 8 or 16");
         // j = 4a + b, q = p + 4 q':  y[p + 4 q'] = sum_b W16^{bp} W4^{b q'} sum_a x[4a + b] W4^{ap}
         dft4(x[0], x[4], x[8], x[12]);
         dft4(x[1], x[5], x[9], x[13]);
@@ -169,9 +180,9 @@ template <int R> __device__ __forceinline__ void dft(f32x2 (&x)[R]) {
 }
 
 // radix of the first stage of a block of length `len`: 256 = 16 x 16, 128 = 16 x 8, 64 = 8 x 8, 32 = 8 x 4, 16 = 16; a factor 3
-// (48 = 3 x 16, 96 = 3 x 8 x 4, 192 = 3 x 8 x 8) goes first
+// (48 = 3 x 16, 96 = 3 x 8 x 4, 192 = 3 x 8 x 8) or 5 (80 = 5 x 16, 160 = 5 x 8 x 4) goes first
 __host__ __device__ constexpr int first_radix(int len) {
-    return len % 3 == 0 ? 3 : len >= 128 ? 16 : len == 64 ? 8 : len == 32 ? 8 : len == 16 ? 16 : len == 8 ? 8 : len == 4 ? 4 : 2;
+    return len % 3 == 0 ? 3 : len % 5 == 0 ? 5 : len >= 128 ? 16 : len == 64 ? 8 : len == 32 ? 8 : len == 16 ? 16 : len == 8 ? 8 : len == 4 ? 4 : 2;
 }
 
 // position P (after the in-place DIF stages) -> frequency k.  Stage i with radix r_i on blocks of length L_i leaves digit q_i
@@ -297,7 +308,7 @@ __device__ __forceinline__ f32x2 table_unit(const f32x2 *fine, const f32x2 *coar
 // fresh rows on every replay (fewbit_sketch.hip, same scheme).
 constexpr uint32_t kRowsDomain = 3u;        // counter word 3 (0 and 2: the dense sketches)
 __host__ __device__ constexpr bool power_of_two(size_t n) { return (n & (n - 1)) == 0; }
-// rows = 2^k <= 2^16: eight 16-bit halves per Philox call; any other row count (3 x 2^k, 2^17, 2^18): four 32-bit words, word x rows >> 32
+// rows = 2^k <= 2^16: eight 16-bit halves per Philox call; any other row count (3 x 2^k, 5 x 2^k, 2^17, 2^18): four 32-bit words, word x rows >> 32
 __host__ __device__ constexpr bool draws_halves(size_t n) { return power_of_two(n) && n <= 65536; }
 __host__ __device__ constexpr int per_draw(bool halves) { return halves ? 8 : 4; }      // row numbers per Philox call
 // row number h of one Philox call (HALVES: not yet reduced mod rows -- the caller masks)
@@ -593,23 +604,24 @@ __global__ __launch_bounds__(kThreadsB, (N2 > 128 ? 2 : 4)) void dct_pass_b_kern
 // ---- host side --------------------------------------------------------------------------------------------------------------
 struct Split { int n1, n2; };
 // rows = N1 x N2.  2^8 .. 2^18: 16 <= N2 <= N1 <= 512, both powers of two (2^17 = 512 x 256 and 2^18 = 512 x 512: 128 KiB tiles, one
-// workgroup per CU).  3 x 2^8 .. 3 x 2^14 (768 .. 49152): the factor 3 goes to the second pass, N2 = 48 / 96 / 192 (N1 stays a power of
-// two: residues and digit maps of pass A, the k % N1 of pass B)
+// workgroup per CU).  3 x 2^8 .. 3 x 2^14 (768 .. 49152) and 5 x 2^8 .. 5 x 2^13 (1280 .. 40960): the odd factor goes to the second pass,
+// N2 = 48 / 96 / 192 or 80 / 160 (N1 stays a power of two: residues and digit maps of pass A, the k % N1 of pass B)
 inline bool split_rows(size_t rows, Split &s) {
     if (rows < 256 || rows > 262144) return false;
-    const bool three = rows % 3 == 0;
-    const size_t two = three ? rows / 3 : rows;
-    if (!power_of_two(two) || (three && (two < 256 || two > 16384))) return false;
+    const bool three = rows % 3 == 0, five = !three && rows % 5 == 0;
+    const size_t two = three ? rows / 3 : five ? rows / 5 : rows;
+    if (!power_of_two(two) || (three && (two < 256 || two > 16384)) || (five && (two < 256 || two > 8192))) return false;
     int bits = 0;
     while ((static_cast<size_t>(1) << bits) < two) ++bits;
-    if (!three) {
+    if (!three && !five) {
         s.n1 = 1 << ((bits + 1) / 2);
         s.n2 = 1 << (bits / 2);
         return true;
     }
     // 3 x 2^bits, bits = 8 .. 14:  16 x 48, 32 x 48, 32 x 96, 64 x 96, 128 x 96, 128 x 192, 256 x 192
-    static const int n1_of[7] = {16, 32, 32, 64, 128, 128, 256};
-    s.n1 = n1_of[bits - 8];
+    // 5 x 2^bits, bits = 8 .. 13:  16 x 80, 32 x 80, 64 x 80, 64 x 160, 128 x 160, 256 x 160
+    static const int n1_of_3[7] = {16, 32, 32, 64, 128, 128, 256}, n1_of_5[6] = {16, 32, 64, 64, 128, 256};
+    s.n1 = three ? n1_of_3[bits - 8] : n1_of_5[bits - 8];
     s.n2 = static_cast<int>(rows / static_cast<size_t>(s.n1));
     return true;
 }
@@ -659,6 +671,7 @@ int launch_rows(Split sp, const void *m, size_t features, size_t ld, ROWS idx, s
     FB_DCT_CASE(16, 16) FB_DCT_CASE(32, 16) FB_DCT_CASE(32, 32) FB_DCT_CASE(64, 32) FB_DCT_CASE(64, 64) FB_DCT_CASE(128, 64) FB_DCT_CASE(128, 128)
     FB_DCT_CASE(256, 128) FB_DCT_CASE(256, 256) FB_DCT_CASE(512, 256) FB_DCT_CASE(512, 512)
     FB_DCT_CASE(16, 48) FB_DCT_CASE(32, 48) FB_DCT_CASE(32, 96) FB_DCT_CASE(64, 96) FB_DCT_CASE(128, 96) FB_DCT_CASE(128, 192) FB_DCT_CASE(256, 192)
+    FB_DCT_CASE(16, 80) FB_DCT_CASE(32, 80) FB_DCT_CASE(64, 80) FB_DCT_CASE(64, 160) FB_DCT_CASE(128, 160) FB_DCT_CASE(256, 160)
 #undef FB_DCT_CASE
     return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: no kernel for %d x %d rows", sp.n1, sp.n2);
 }
@@ -685,7 +698,7 @@ template <typename ROWS>
 int run(int dtype, const void *m, size_t rows, size_t features, size_t ld, ROWS idx, size_t proj, double scale, void *out, void *workspace,
                        size_t workspace_bytes, void *stream) {
     Split sp;
-    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is neither 2^k (256 .. 262144) nor 3 x 2^k (768 .. 49152)", rows);
+    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_dct: rows = %zu is none of 2^k (256 .. 262144), 3 x 2^k (768 .. 49152), 5 x 2^k (1280 .. 40960)", rows);
     if (m == nullptr || out == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: null pointer");
     if (ld < features) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_dct: leading dimension %zu < features %zu", ld, features);
     const size_t need = workspace_bytes_of(rows, features, proj);
@@ -742,7 +755,7 @@ int fewbit_hip_sampled_dct_seeded(int dtype, const void *m, size_t rows, size_t 
 
 int fewbit_hip_sampled_rows(uint64_t seed, size_t rows, size_t proj, int64_t *idx) {
     Split sp;
-    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_rows: rows = %zu is neither 2^k (256 .. 262144) nor 3 x 2^k (768 .. 49152)", rows);
+    if (!split_rows(rows, sp)) return fail(FEWBIT_ERR_UNSUPPORTED, "sampled_rows: rows = %zu is none of 2^k (256 .. 262144), 3 x 2^k (768 .. 49152), 5 x 2^k (1280 .. 40960)", rows);
     if (proj > 0 && idx == nullptr) return fail(FEWBIT_ERR_INVALID_ARGUMENT, "sampled_rows: null pointer");
     const sketch::Key key{static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32)};
     const bool pow2 = draws_halves(rows);

@@ -39,7 +39,7 @@ constructor / call signatures; the implementation is this repository's own:
   (``_sketch_seed``), so a replayed training step draws a fresh ``S`` each time -- a seed recorded by value would repeat
   one matrix for ever.  (The reference reads the generator state back in forward and cannot be captured.)
 
-The sampled transforms: 'dct' on 2-D GPU tensors of 2^8 .. 2^18 or 3 x 2^8 .. 3 x 2^14 rows runs on this package's kernel pair (``fewbit_hip_sampled_dct``,
+The sampled transforms: 'dct' on 2-D GPU tensors of 2^8 .. 2^18, 3 x 2^8 .. 3 x 2^14 or 5 x 2^8 .. 5 x 2^13 rows runs on this package's kernel pair (``fewbit_hip_sampled_dct``,
 ``fewbit_amd/csrc/fewbit_dct.hip``: a four-step fp32 FFT in LDS that writes only the sampled rows -- the torch.fft formulation costs
 110-120 x the bytes of the result, profiles/r06_sketch_bench.json); other shapes and 'dft' are PyTorch-level code.  Inside the layer the
 sampled rows are, like ``S``, a function of the call's 64-bit seed that the kernel evaluates itself (``fewbit_hip_sampled_dct_seeded``;
@@ -245,7 +245,7 @@ def _sampled_rows(p: int, rows: int, like: torch.Tensor, gen: torch.Generator) -
 
 def _native_dct_applies(mat: torch.Tensor) -> bool:
     """The gfx950 sampled-DCT kernel pair (fewbit_amd/csrc/fewbit_dct.hip) takes 2-D fp32 / fp16 / bf16 GPU tensors whose row count is
-    2^k in [256, 262144] (RoBERTa's 128 x 128 tokens = 16384) or 3 x 2^k in [768, 49152] (32 sequences of 384 tokens = 12288); everything
+    2^k in [256, 262144] (RoBERTa's 128 x 128 tokens = 16384) or 3 x 2^k in [768, 49152] (32 sequences of 384 tokens = 12288) or 5 x 2^k in [1280, 40960]; everything
     else keeps the torch.fft formulation."""
     if not (_NATIVE_SKETCH and mat.device.type == 'cuda' and mat.dim() == 2 and mat.dtype in (torch.float32, torch.float16, torch.bfloat16)):
         return False
@@ -254,10 +254,11 @@ def _native_dct_applies(mat: torch.Tensor) -> bool:
 
 
 def _dct_rows_supported(rows: int) -> bool:
-    """2^k rows, k = 8 .. 18, or 3 x 2^k rows, k = 8 .. 14 (fewbit_dct.hip::split_rows)"""
+    """2^k rows, k = 8 .. 18, 3 x 2^k rows, k = 8 .. 14, or 5 x 2^k rows, k = 8 .. 13 (fewbit_dct.hip::split_rows)"""
     three = rows % 3 == 0
-    two = rows // 3 if three else rows
-    return 256 <= two <= (16384 if three else 262144) and two & (two - 1) == 0
+    five = not three and rows % 5 == 0
+    two = rows // 3 if three else rows // 5 if five else rows
+    return 256 <= two <= (16384 if three else 8192 if five else 262144) and two & (two - 1) == 0
 
 
 def sampled_transform_path(kind: str, mat: torch.Tensor) -> str:

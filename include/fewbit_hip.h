@@ -216,8 +216,9 @@ int fewbit_hip_sketch_describe(int dist, int dtype, size_t rows, size_t features
  *   replaces  `dct(input_view, dim=0, norm='ortho')[proj, ...]`, fewbit/functional/linear.py:113-122 (forward) and :174-183
  *             (backward), with dct = fewbit/fft.py:10-43 -- a full fp32 transform through the FFT library, then a gather
  *   m    rows x features, row-major with leading dimension `ld` (elements), dtype F32 / F16 / BF16; rows = 2^k in [256, 262144] or
- *        3 x 2^k in [768, 49152] (anything else: FEWBIT_ERR_UNSUPPORTED, and fewbit_hip_sampled_dct_workspace returns 0 -- the
- *        caller keeps the library formulation for those); arithmetic and the intermediate are fp32 whatever the dtype
+ *        3 x 2^k in [768, 49152] or 5 x 2^k in [1280, 40960] (anything else: FEWBIT_ERR_UNSUPPORTED, and
+ *        fewbit_hip_sampled_dct_workspace returns 0 -- the caller keeps the library formulation for those); arithmetic and the
+ *        intermediate are fp32 whatever the dtype
  *   idx  proj row numbers in [0, rows) as int64 in DEVICE memory (drawn with replacement: duplicates are served one by one)
  *   out  proj x features, contiguous, the dtype of m (fully written)
  *   workspace  fewbit_hip_sampled_dct_workspace(...) = ceil(features / 64) * rows * 256 (the fp32 intermediate) + 2048 + 8 * proj rounded up to

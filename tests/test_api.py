@@ -95,7 +95,8 @@ def test_sampled_dct_workspace_is_a_host_side_formula():
     assert cabi.sampled_dct_workspace_bytes(65536, 70, 1, torch.float32) == 2 * 65536 * 256 + 2048 + 16
     assert cabi.sampled_dct_workspace_bytes(12288, 64, 5) == 12288 * 256 + 2048 + 48
     assert cabi.sampled_dct_workspace_bytes(262144, 64, 8) == 262144 * 256 + 2048 + 64
-    for rows in (0, 48, 128, 255, 3000, 98304, 524288):
+    assert cabi.sampled_dct_workspace_bytes(20480, 64, 8) == 20480 * 256 + 2048 + 64
+    for rows in (0, 48, 128, 255, 3000, 1792, 81920, 98304, 524288):
         assert cabi.sampled_dct_workspace_bytes(rows, 64, 10) == 0
     assert cabi.sampled_dct_workspace_bytes(1024, 0, 10) == 0 == cabi.sampled_dct_workspace_bytes(1024, 64, 0)
     assert cabi.sampled_dct_workspace_bytes(1024, 64, 10, torch.float64) == 0

@@ -19,9 +19,9 @@ DEV = 'cuda:0'
 REL = {torch.float32: 0.0, torch.float16: 2.0**-11, torch.bfloat16: 2.0**-8}
 
 
-@pytest.fixture(scope='module', params=('sampled_dct_ref.npz', 'sampled_dct_ref_3x.npz', 'sampled_dct_ref_big.npz'))
+@pytest.fixture(scope='module', params=('sampled_dct_ref.npz', 'sampled_dct_ref_3x.npz', 'sampled_dct_ref_5x.npz', 'sampled_dct_ref_big.npz'))
 def ref(request):
-    """the reference's own rows: 2^8 .. 2^16 rows, 3 x 2^8 .. 3 x 2^14 (the radix-3 first stage of pass B), 2^17 and 2^18 (512-point tiles)"""
+    """the reference's own rows: 2^8 .. 2^16 rows, 3 x 2^8 .. 3 x 2^14 and 5 x 2^8 .. 5 x 2^13 (the radix-3 / radix-5 first stage of pass B), 2^17 and 2^18 (512-point tiles)"""
     with np.load(GOLDEN / request.param) as z:
         return {k: z[k].copy() for k in z.files}
 
@@ -35,7 +35,7 @@ def close(got, want, dtype):
 
 @pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16, torch.float16))
 def test_sampled_rows_equal_the_reference_run(ref, dtype):
-    """9 shapes, 256 .. 65536 rows, 7 shapes, 768 .. 49152 = 3 x 2^k rows, and 131072 / 262144 rows; ragged and odd feature counts, corner rows (0, rows/2, rows-1, the self-paired residue classes,
+    """9 shapes, 256 .. 65536 rows, 7 shapes, 768 .. 49152 = 3 x 2^k rows, 6 shapes, 1280 .. 40960 = 5 x 2^k rows, and 131072 / 262144 rows; ragged and odd feature counts, corner rows (0, rows/2, rows-1, the self-paired residue classes,
     duplicates): every dtype against the reference's float64 rows (the inputs are exact in all three dtypes)"""
     for i in range(int(ref['cases'])):
         x = torch.from_numpy(ref[f'case{i}_x_times_16'].astype(np.float32) / 16.0).to(dtype).to(DEV)
@@ -53,7 +53,7 @@ def test_every_row_of_the_transform_scale_strides_and_buffers():
     """p = rows (every k once, shuffled) against torch's float64 transform of the same data on the host; `scale`, a strided input
     (leading dimension > features), caller-provided out / workspace, and bit-identical repeats"""
     g = torch.Generator().manual_seed(12)
-    for rows, features in ((1024, 130), (256, 64), (16384, 66), (32768, 34), (65536, 4), (768, 64), (1536, 130), (12288, 66), (49152, 4), (131072, 6), (262144, 2)):
+    for rows, features in ((1024, 130), (256, 64), (16384, 66), (32768, 34), (65536, 4), (768, 64), (1536, 130), (12288, 66), (49152, 4), (131072, 6), (262144, 2), (1280, 64), (20480, 66), (40960, 4)):
         wide = torch.randn(rows, features + 6, generator=g).to(DEV)
         x = wide[:, 3:3 + features]                                           # unit stride along the features, ld = features + 6
         assert not x.is_contiguous()
@@ -73,7 +73,7 @@ def test_shapes_without_a_kernel_are_refused_by_name_and_keep_the_library_path()
     assert cabi.sampled_dct_workspace_bytes(16384, 768, 3276) == 12 * 16384 * 256 + 2048 + 8 * 3276
     assert cabi.sampled_dct_workspace_bytes(16384, 70, 1) == 2 * 16384 * 256 + 2048 + 16
     assert cabi.sampled_dct_workspace_bytes(12288, 768, 2457) == 12 * 12288 * 256 + 2048 + 19664
-    for rows in (48, 128, 384, 3000, 1280, 98304, 524288):
+    for rows in (48, 128, 384, 3000, 1792, 640, 81920, 98304, 524288):
         assert cabi.sampled_dct_workspace_bytes(rows, 64, 10) == 0
         x = torch.randn(rows, 8, device=DEV)
         idx = torch.zeros(4, dtype=torch.int64, device=DEV)
@@ -86,10 +86,10 @@ def test_shapes_without_a_kernel_are_refused_by_name_and_keep_the_library_path()
     assert cabi.sampled_dct(torch.randn(256, 8, device=DEV), torch.zeros(0, dtype=torch.int64, device=DEV)).shape == (0, 8)
 
 
-@pytest.mark.parametrize('batch,seq', ((4, 128), (2, 384)))
+@pytest.mark.parametrize('batch,seq', ((4, 128), (2, 384), (10, 128)))
 @pytest.mark.parametrize('dtype', (torch.float32, torch.bfloat16))
 def test_the_dct_layer_on_the_kernel_equals_the_layer_on_torch_fft(dtype, batch, seq, monkeypatch):
-    """linear_grp(matmul='dct') with 512 and with 768 = 3 x 256 rows.  The native path samples rows(seed) (seed = one host draw from the generator); the torch.fft
+    """linear_grp(matmul='dct') with 512, with 768 = 3 x 256 and with 1280 = 5 x 256 rows.  The native path samples rows(seed) (seed = one host draw from the generator); the torch.fft
     formulation is handed the SAME rows (cabi.sampled_rows of that seed), so the weight gradient of the native path equals that of the
     torch.fft formulation (which tests/test_gpu_linear.py pins to the reference's deterministic outputs); forward, input gradient and
     bias gradient are exact on both"""
@@ -128,6 +128,7 @@ def test_the_seeded_transform_is_the_explicit_one_on_the_rows_of_the_seed():
     cases = [(256, 40, 9000), (256, 64, 1), (512, 66, 20001), (1024, 7, 300), (2048, 33, 2047), (4096, 64, 5000), (8192, 96, 1638),
              (16384, 768, 3276), (16384, 130, 16387), (32768, 64, 6553), (65536, 32, 13107),
              (131072, 64, 26214), (262144, 70, 52428), (262144, 2, 7),
+             (1280, 40, 9000), (2560, 64, 5), (5120, 66, 1024), (10240, 96, 2048), (20480, 768, 4096), (40960, 32, 8192),
              (768, 40, 9000), (1536, 64, 3), (3072, 66, 20001), (6144, 96, 1229), (12288, 768, 2457), (24576, 64, 4915), (49152, 32, 9830)]
     for n, (rows, features, p) in enumerate(cases):
         dtype = (torch.bfloat16, torch.float32, torch.float16)[n % 3]
@@ -180,6 +181,8 @@ def _fuzz_cases(n, seed):
         rows = 1 << int(rng.integers(8, 17))
         if rng.integers(0, 3) == 0:
             rows = 3 << int(rng.integers(8, 15))
+            if rng.integers(0, 2) == 0:
+                rows = 5 << int(rng.integers(8, 14))
         features = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 63, 64, 65, 96, 127, 130, int(rng.integers(1, 200))]))
         if rows * features > (1 << 24):
             features = max(1, (1 << 24) // rows)
@@ -190,7 +193,7 @@ def _fuzz_cases(n, seed):
 
 
 def test_sampled_dct_fuzz_against_float64_on_the_device():
-    """40 random cases (FEWBIT_DCT_FUZZ_CASES=N widens the sweep): every supported row count (2^k and 3 x 2^k), ragged / odd / tiny feature counts (edge
+    """40 random cases (FEWBIT_DCT_FUZZ_CASES=N widens the sweep): every supported row count (2^k, 3 x 2^k, 5 x 2^k), ragged / odd / tiny feature counts (edge
     tiles, a last complex column with no partner), p from 1 to rows, all three dtypes, strided inputs, scales; expected = the float64
     DCT-II of the same data computed by torch.fft on the device; per case also fewbit_hip_sampled_dct_seeded against the explicit call on
     fewbit_hip_sampled_rows of the same seed (bit-equal).  Plus the two list regimes of pass B forced on purpose: more samples of

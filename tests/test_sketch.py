@@ -173,6 +173,7 @@ def test_rows_of_a_seed_are_the_documented_function_and_uniform():
     idx = cabi.sampled_rows(seed, 262144, 1003)
     want = [(int(w) * 262144) >> 32 for q in range(251) for w in ref.philox4x32(q, 0, 0, 3, *key)][:1003]
     assert idx.tolist() == want
-    for rows in (1000, 384, 98304, 524288, 128):
+    assert int(cabi.sampled_rows(seed, 20480, 4000).max()) < 20480
+    for rows in (1000, 384, 1792, 81920, 98304, 524288, 128):
         with pytest.raises(cabi.FewbitHipError):
             cabi.sampled_rows(1, rows, 4)

@@ -33,6 +33,7 @@ ROWS = [
     ('r06_dct_large_rows.txt', 'the kernel pair and the torch.fft formulation at 32768 and 65536 rows', f'{D} 7.3'),
     ('r06_convergence_demo_*.txt', 'a student MLP fitted with torch layers and with each few-bit configuration (tools/convergence_demo.py); the DCT estimator at lr 1.0', f'{D} 7.4'),
     ('r06_dct_rows_big.txt', 'the kernel pair and the torch.fft formulation at 2^17 and 2^18 rows (512-point tiles)', f'{D} 7.3'),
+    ('r06_dct_rows_5x.txt', 'the kernel pair and the torch.fft formulation at 5 x 2^k rows (1280 .. 40960)', f'{D} 7.3'),
     ('r06_dct_rows_3x.txt', 'the kernel pair and the torch.fft formulation at 3 x 2^k rows (768 .. 49152)', f'{D} 7.3'),
     ('r06_dct_variants.txt', 'the sampled-DCT variants measured in round 6, phases compiled out, per-workgroup timeline', f'{D} 7.5'),
     ('r06_dct_sorted_samples.txt', 'the samples sorted by residue class once, in pass A, instead of tested by every pass-B workgroup: pass B 17.3 -> 12.7 us', f'{D} 5'),
